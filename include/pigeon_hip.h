@@ -1,0 +1,179 @@
+/* pigeon_hip.h -- C ABI of libpigeon_hip.so: the MI355X (gfx950) kernels behind PIGEON's inference hot path.
+ *
+ * The reference (LukasHaas/PIGEON) is 100% Python and has NO native boundary of its own:
+ * every GPU FLOP is issued by stock PyTorch ops reached through HuggingFace transformers.  The drop-in
+ * boundary is therefore the Python class surface (CLIPEmbedding / SuperGuessr / ProtoRefiner, mirrored in
+ * pigeon_amd/), and THIS header is the FFI those mirrors bind with ctypes -- exactly what a maintainer of
+ * the reference would bind to replace the library kernels it reaches today.  Each entry point cites the
+ * reference call site(s) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain C types only; every pointer documented as DEVICE (HBM, on the handle's device) or HOST;
+ *   - every function returns 0 on success or a negative PG_E* code; pg_last_error() gives a message;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); all work is asynchronous on it, the
+ *     library never synchronises the device inside a forward call;
+ *   - the caller owns all inputs, outputs and workspaces (torch tensors in the Python host); the library
+ *     owns only the packed weight copies held inside a pg_vit handle;
+ *   - handles are not thread-safe: one per (device, stream).
+ */
+#ifndef PIGEON_HIP_H
+#define PIGEON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_OK            0
+#define PG_EINVAL       -1   /* bad argument / unsupported shape */
+#define PG_ENOMEM       -2   /* device allocation failed / workspace too small */
+#define PG_EHIP         -3   /* a HIP runtime call failed (see pg_last_error) */
+#define PG_ESTATE       -4   /* handle not finalized / weight missing */
+
+#define PG_DTYPE_F32     0
+#define PG_DTYPE_BF16    1
+
+#define PG_ABI_VERSION   1
+
+const char* pg_last_error(void);
+int pg_abi_version(void);
+/* Number of HIP devices visible; <0 on error.  Lets the host fail loudly when there is no GPU. */
+int pg_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * ViT-L/14-336 image encoder.
+ * Replaces: transformers CLIPVisionModel.forward as called at reference models/clip_embedder.py:63 and
+ * models/super_guessr.py:395, plus the token mean at models/clip_embedder.py:64-65 /
+ * models/super_guessr.py:397-398 (embedding = mean over ALL 577 tokens of last_hidden_state, taken
+ * before post_layernorm).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct pg_vit pg_vit;
+
+typedef struct pg_vit_cfg {
+    int32_t layers;       /* 24 for ViT-L; any >=1 accepted (tests use 2) */
+    int32_t image_size;   /* must be 336 */
+    int32_t patch;        /* must be 14  */
+    int32_t hidden;       /* must be 1024 */
+    int32_t heads;        /* must be 16  */
+    int32_t mlp;          /* must be 4096 */
+    float   ln_eps;       /* 1e-5 */
+    int32_t max_chunk;    /* images processed per internal pass (0 = default 256) */
+} pg_vit_cfg;
+
+int pg_vit_create(pg_vit** out, int device, const pg_vit_cfg* cfg);
+/* Copy one parameter into the handle.  `name` is the state-dict key of transformers' CLIPVisionModel, either
+ * layout: 4.23.1 "vision_model.embeddings.patch_embedding.weight" or 5.x "embeddings.patch_embedding.weight"
+ * (reference loads by name: models/utils.py:24-45, models/super_guessr.py:222-238).  `data` is a HOST pointer
+ * to contiguous fp32 (PG_DTYPE_F32); the library converts GEMM weights to bf16 and keeps its own device copy.
+ * Unknown names (post_layernorm.*, position_ids) are accepted and ignored (dead on this path). */
+int pg_vit_load_weight(pg_vit* h, const char* name, const void* data, int dtype,
+                       const int64_t* shape, int ndim);
+/* Checks that every required parameter was loaded and uploads fused/packed forms. */
+int pg_vit_finalize(pg_vit* h);
+/* Bytes of DEVICE workspace pg_vit_forward needs for n_images (caller allocates, e.g. a torch uint8 tensor). */
+int pg_vit_workspace_bytes(const pg_vit* h, int n_images, size_t* bytes);
+/* pixels: DEVICE (n_images,3,336,336) contiguous NCHW, fp32 (PG_DTYPE_F32) or bf16.
+ * emb_out: DEVICE (n_images,1024) fp32 -- mean over the 577 tokens of last_hidden_state. */
+int pg_vit_forward(pg_vit* h, const void* pixels, int pix_dtype, int n_images, float* emb_out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+/* Same, additionally copying the final residual stream (n_images,577,1024) fp32 to `hidden_out` (DEVICE,
+ * may be NULL).  Used by parity tests to compare last_hidden_state itself. */
+int pg_vit_forward_hidden(pg_vit* h, const void* pixels, int pix_dtype, int n_images, float* emb_out,
+                          float* hidden_out, void* workspace, size_t workspace_bytes, void* stream);
+int pg_vit_destroy(pg_vit* h);
+
+/* Per-kernel-class timing (HIP events on `stream`), for bench.py's roofline object.
+ * pg_vit_profile_enable(h,1) makes subsequent forwards bracket every launch with events;
+ * pg_vit_profile_read synchronises those events and returns, per class, launches and total milliseconds.
+ * Classes: 0 gemm_qkv 1 gemm_out 2 gemm_fc1 3 gemm_fc2 4 gemm_patch 5 attention 6 layernorm 7 im2col
+ *          8 token_mean  (PG_PROF_CLASSES entries). */
+#define PG_PROF_CLASSES 9
+int pg_vit_profile_enable(pg_vit* h, int on);
+int pg_vit_profile_read(pg_vit* h, int64_t* launches /*[PG_PROF_CLASSES]*/, double* ms /*[PG_PROF_CLASSES]*/);
+int pg_vit_profile_reset(pg_vit* h);
+
+/* ------------------------------------------------------------------------------------------------
+ * SuperGuessr geocell head.
+ * Replaces: models/super_guessr.py:437 (panel mean), :447 (cell_layer Linear), :448 (softmax), :454 (argmax),
+ * :455 (index_select of lla_geocells), :459 (topk).  fp32 throughout; centroids float64.
+ *   emb      DEVICE (B,P,1024) fp32, P = 4 (panorama) or 1
+ *   W, bias  DEVICE (C,1024) / (C) fp32 -- cell_layer.weight / .bias
+ *   centroids DEVICE (C,2) float64 [lng,lat] -- lla_geocells
+ *   logits   DEVICE (B,C) fp32 out (required; also scratch)
+ *   topk_val DEVICE (B,k) fp32 out: softmax probabilities, descending; ties -> lower index first
+ *   topk_idx DEVICE (B,k) int64 out
+ *   argmax   DEVICE (B) int64 out (== topk_idx[:,0])
+ *   pred_llh DEVICE (B,2) float64 out = centroids[argmax]
+ * ------------------------------------------------------------------------------------------------ */
+int pg_head_forward(const float* emb, int B, int P, const float* W, const float* bias,
+                    const double* centroids, int C, int k, float* logits,
+                    float* topk_val, int64_t* topk_idx, int64_t* argmax, double* pred_llh, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ProtoRefiner prototype-distance refinement over a CSR prototype bank.
+ * Replaces: models/proto_refiner.py:154-222 (the per-sample / per-candidate Python loop), :233-255
+ * (within-cluster refinement: FARTHEST member), :332-344 (torch.cdist L2), :346-357 (temperature softmax
+ * without max shift) and preprocessing/geo_utils.py:40-55 (haversine veto, float64).
+ * The bank arrays are BORROWED device pointers (caller keeps the tensors alive):
+ *   proto_emb (P,1024) f32; cell_off (C+1) i64; proto_lnglat (P,2) f32; proto_count (P) i32;
+ *   member_off (P+1) i64; member_idx (Nm) i64; train_emb (Ntr,1024) f32; train_lnglat (Ntr,2) f32.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct pg_bank {
+    const float*   proto_emb;
+    const int64_t* cell_off;
+    const float*   proto_lnglat;
+    const int32_t* proto_count;
+    const int64_t* member_off;
+    const int64_t* member_idx;
+    const float*   train_emb;
+    const float*   train_lnglat;
+    int64_t num_cells;
+    int64_t num_protos;
+    int64_t num_train;
+} pg_bank;
+
+/*   q          DEVICE (B,P,1024) fp32 query embeddings (P panels are averaged first: proto_refiner.py:139-140)
+ *   init_llh   DEVICE (B,2) float64 initial [lng,lat] predictions
+ *   cand       DEVICE (B,k) int64 candidate geocells;  cand_prob DEVICE (B,k) fp32 (NULL -> [1,0,0,...], :143-145)
+ *   topk <= k, topk <= 64
+ *   scratch    DEVICE >= B*topk*4 floats (score, lng, lat, pad per candidate)
+ *   out_llh    DEVICE (B,2) fp32; out_cell DEVICE (B) int64; out_choice DEVICE (B) int32 (index of the chosen
+ *              candidate, the reference's guess_index, proto_refiner.py:220)                              */
+int pg_refine_forward(const pg_bank* bank, const float* q, int B, int P, const double* init_llh,
+                      const int64_t* cand, const float* cand_prob, int k, int topk,
+                      float temperature, double max_refine_km, float* scratch,
+                      float* out_llh, int64_t* out_cell, int32_t* out_choice, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Building-block ops (exported so the parity tests can check every kernel in isolation through the ABI).
+ * ------------------------------------------------------------------------------------------------ */
+/* C = A (M,K bf16, row stride lda) x W^T (N,K bf16) with fp32 accumulation and a fused epilogue:
+ *   epi 0: out bf16 (M,ldc) = acc + bias; columns < qcols additionally scaled by qscale      (QKV)
+ *   epi 1: out bf16 = quick_gelu(acc + bias) = x*sigmoid(1.702x)                              (fc1)
+ *   epi 2: out fp32 (M,ldc) += acc + bias  (in-place residual add)                            (out_proj, fc2)
+ *   epi 3: patch embed: row = img*576+p -> out fp32 row (img*577+1+p) = acc + aux[(1+p)*N + col] (aux = pos emb)
+ *   epi 4: out fp32 = acc + bias (bias may be NULL)                                           (tests)
+ * N must be a multiple of 256, K a multiple of 64.  variant selects the tile configuration (0 = default). */
+int pg_op_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
+                    int M, int N, int K, int epi, float qscale, int qcols, const float* aux,
+                    int variant, void* stream);
+/* y = LayerNorm(x) over the last dim (1024), eps, gamma/beta fp32.  x fp32 (rows,1024).
+ * out_dtype PG_DTYPE_BF16 -> y bf16 (rows,1024); PG_DTYPE_F32 -> fp32 (may alias x). */
+int pg_op_layernorm(const float* x, const float* gamma, const float* beta, void* y, int out_dtype,
+                    int64_t rows, float eps, void* stream);
+/* Multi-head attention over the fused QKV buffer (n_images*577, 3072) bf16 -> out (n_images*577,1024) bf16.
+ * Q must already carry the factor log2(e)/sqrt(64) (the GEMM epilogue applies it); softmax in fp32. */
+int pg_op_attention(const void* qkv, void* out, int n_images, void* stream);
+/* fp32/bf16 NCHW pixels -> bf16 patch matrix (n_images*576, 640), k = c*196+ky*14+kx, cols 588..639 zero. */
+int pg_op_im2col(const void* pixels, int pix_dtype, void* out, int n_images, void* stream);
+/* mean over the 577 tokens: x fp32 (n_images,577,1024) -> (n_images,1024). */
+int pg_op_token_mean(const float* x, float* out, int n_images, void* stream);
+/* fp32 -> bf16 (round to nearest even), n elements. */
+int pg_op_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIGEON_HIP_H */

@@ -1,0 +1,236 @@
+"""Generate tests/golden/*.npz by running the REAL reference (from /root/reference) on seeded synthetic
+inputs.  Authoring-container only (the GPU box has no /root/reference); the outputs are committed.
+
+    python oracle/make_golden.py [--only vit2|vit24|head|pipeline|refine]
+
+Every fixture stores only small tensors (inputs are regenerated from their seeds by
+``pigeon_amd.synthetic`` on both sides).  What runs for each fixture:
+
+  vit2      reference CLIPEmbedding.forward (models/clip_embedder.py:79-89 -> :42-66) around a HF
+            CLIPVisionModel (ViT-L/14-336 geometry, 2 layers, jittered bias/LN params), 4 images.
+  vit24     same, full 24-layer default-init model (seed 0), 4 images of the bench pixel stream.
+  head      reference SuperGuessr(None, panorama=True, num_candidates=50).forward(embedding=...)
+            (models/super_guessr.py:350-483) with C = 10000 geocells.
+  pipeline  reference SuperGuessr(vit2, panorama=True, freeze_base=True, num_candidates=50) on 2 panoramas
+            -> reference ProtoRefiner.forward (models/proto_refiner.py:121-231) over a 200-cell bank.
+  refine    reference ProtoRefiner.forward on 48 purpose-built queries (near-prototype embeddings, empty
+            candidate cells, singleton and multi-member clusters) at both parameter settings used by
+            the reference: class defaults (topk 5, T 1.6, 1000 km; proto_refiner.py:20-21) and
+            evaluate()'s (T 0.6, 100000 km; evaluation/evaluate.py:79-80; topk 20 of 50 candidates).
+"""
+import argparse
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import reference_loader  # noqa: E402
+from pigeon_amd import synthetic  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def hf_vit(sd, layers):
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    cfg = CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=layers,
+                           num_attention_heads=16, image_size=336, patch_size=14, projection_dim=768)
+    m = CLIPVisionModel(cfg)
+    missing, unexpected = m.load_state_dict(sd, strict=True), None
+    m.eval()
+    return m
+
+
+def refine_queries(bank, B, k, seed):
+    """Queries that make refinement meaningful + exercise every branch."""
+    rng = np.random.default_rng(seed)
+    C = bank.num_cells
+    nonempty = np.nonzero(np.diff(bank.cell_off) > 0)[0]
+    empty = np.nonzero(np.diff(bank.cell_off) == 0)[0]
+    emb = np.empty((B, 1024), dtype=np.float32)
+    cands = np.empty((B, k), dtype=np.int64)
+    for i in range(B):
+        cells = rng.permutation(C)[:k]
+        if len(empty) and i % 3 == 0:
+            cells[rng.integers(0, min(k, 5))] = empty[rng.integers(0, len(empty))]   # an empty candidate up front
+        if i % 7 == 0 and len(empty):
+            cells[0] = empty[0]
+        cands[i] = cells
+        # query close to a random prototype of one of the first 5 candidate cells
+        pick = [c for c in cells[:5] if bank.cell_off[c + 1] > bank.cell_off[c]]
+        c = pick[rng.integers(0, len(pick))] if pick else nonempty[0]
+        p = rng.integers(bank.cell_off[c], bank.cell_off[c + 1])
+        emb[i] = bank.proto_emb[p] + 0.5 * rng.standard_normal(1024).astype(np.float32)
+    probs = np.sort(rng.dirichlet(np.ones(k) * 0.3, size=B).astype(np.float32), axis=1)[:, ::-1].copy()
+    init = np.stack([rng.uniform(-180, 180, B), rng.uniform(-90, 90, B)], axis=1)   # float64
+    # make some initial predictions sit right next to a candidate cell's data so the km veto is mixed
+    for i in range(0, B, 2):
+        c = cands[i, 0]
+        if bank.cell_off[c + 1] > bank.cell_off[c]:
+            init[i] = bank.proto_lnglat[bank.cell_off[c]].astype(np.float64) + rng.normal(0, 2.0, 2)
+    init[:, 1] = np.clip(init[:, 1], -89.5, 89.5)
+    return torch.from_numpy(emb), torch.from_numpy(cands), torch.from_numpy(probs), torch.from_numpy(init)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    tmp = tempfile.mkdtemp(prefix="pigeon_golden_")
+
+    # bank + geocells for the refiner fixtures (200 cells x 12 protos)
+    C_small = 200
+    bank = synthetic.make_bank(C_small, 12, seed=2, empty_frac=0.05)
+    proto_csv = os.path.join(tmp, "protos.csv")
+    ds_dir = os.path.join(tmp, "hf_train")
+    geo_small = synthetic.make_geocells(C_small, seed=0)
+    geo_small_csv = os.path.join(tmp, "geocells_small.csv")
+    synthetic.write_geocell_csv(geo_small_csv, geo_small)
+    synthetic.write_bank_reference_files(bank, proto_csv, ds_dir)
+
+    def want(name):
+        return args.only is None or args.only == name
+
+    if want("vit2"):
+        ns = reference_loader.load(geo_small_csv, proto_csv, ds_dir)
+        sd = synthetic.make_vit_weights(seed=11, layers=2, affine_jitter=True)
+        vit = hf_vit(sd, 2)
+        emb_ref = reference_loader.make_reference_embedder(ns, vit)
+        px = synthetic.make_pixels(4, seed=77)
+        with torch.no_grad():
+            e = emb_ref(px)
+            lhs = vit(pixel_values=px).last_hidden_state
+        np.savez(os.path.join(GOLD, "vit2.npz"), embedding=e.numpy(),
+                 lhs_rows=lhs[:, [0, 1, 2, 288, 575, 576]].numpy(),
+                 meta=np.array([11, 2, 1, 4, 77]))   # weight seed, layers, jitter, n images, pixel seed
+        print("vit2", e.shape, float(e.abs().mean()))
+
+    if want("vit24"):
+        ns = reference_loader.load(geo_small_csv, proto_csv, ds_dir)
+        sd = synthetic.make_vit_weights(seed=0, layers=24)
+        vit = hf_vit(sd, 24)
+        emb_ref = reference_loader.make_reference_embedder(ns, vit)
+        px = synthetic.make_pixels(4, seed=1234)
+        with torch.no_grad():
+            e = emb_ref(px)
+        np.savez(os.path.join(GOLD, "vit24.npz"), embedding=e.numpy(), meta=np.array([0, 24, 0, 4, 1234]))
+        print("vit24", e.shape, float(e.abs().mean()))
+        # stress variant: jittered affine + 3x projection scale -> far less benign numerics
+        sd = synthetic.make_vit_weights(seed=5, layers=24, affine_jitter=True, scale=2.0)
+        vit = hf_vit(sd, 24)
+        emb_ref = reference_loader.make_reference_embedder(ns, vit)
+        px = synthetic.make_pixels(2, seed=99)
+        with torch.no_grad():
+            e = emb_ref(px)
+        np.savez(os.path.join(GOLD, "vit24_stress.npz"), embedding=e.numpy(), meta=np.array([5, 24, 1, 2, 99]))
+        print("vit24_stress", e.shape, float(e.abs().mean()))
+
+    if want("head"):
+        C = 10000
+        geo = synthetic.make_geocells(C, seed=0)
+        geo_csv = os.path.join(tmp, "geocells.csv")
+        synthetic.write_geocell_csv(geo_csv, geo)
+        ns = reference_loader.load(geo_csv, proto_csv, ds_dir)
+        model = ns.SuperGuessr(None, panorama=True, num_candidates=50)
+        W, b = synthetic.make_head_weights(C, seed=0)
+        with torch.no_grad():
+            model.cell_layer.weight.copy_(W)
+            model.cell_layer.bias.copy_(b)
+        model.eval()
+        g = torch.Generator().manual_seed(321)
+        emb = torch.randn((32, 4, 1024), generator=g) * 0.7 + 0.1
+        with torch.no_grad():
+            out = model(embedding=emb, labels=torch.zeros(32, 2, dtype=torch.float64),
+                        labels_clf=torch.zeros(32, dtype=torch.long))
+        logits = model.cell_layer(emb.mean(dim=1))
+        np.savez(os.path.join(GOLD, "head.npz"),
+                 preds_LLH=out.preds_LLH.numpy(), preds_geocell=out.preds_geocell.numpy(),
+                 topk_values=out.top5_geocells.values.numpy(), topk_indices=out.top5_geocells.indices.numpy(),
+                 logits_first8=logits[:, :8].detach().numpy(), loss_clf=float(out.loss_clf),
+                 meta=np.array([C, 0, 32, 321, 50]))
+        print("head", out.preds_geocell[:8].tolist())
+
+    if want("pipeline"):
+        ns = reference_loader.load(geo_small_csv, proto_csv, ds_dir)
+        sd = synthetic.make_vit_weights(seed=11, layers=2, affine_jitter=True)
+        vit = hf_vit(sd, 2)
+        model = ns.SuperGuessr(vit, panorama=True, hierarchical=False, multi_task=False, heading=False,
+                               freeze_base=True, num_candidates=50)
+        W, b = synthetic.make_head_weights(C_small, seed=3)
+        with torch.no_grad():
+            model.cell_layer.weight.copy_(W * 8)      # sharper softmax -> non-degenerate candidate probs
+            model.cell_layer.bias.copy_(b)
+        model.eval()
+        px = synthetic.make_pixels(8, seed=55, panorama=True)       # (2,12,336,336)
+        with torch.no_grad():
+            out = model(pixel_values=px, labels=torch.zeros(2, 2, dtype=torch.float64),
+                        labels_clf=torch.zeros(2, dtype=torch.long))
+        refiner = ns.ProtoRefiner(topk=5, max_refinement=1000, temperature=1.6,
+                                  proto_path=proto_csv, dataset_path=ds_dir)
+        refiner.eval()
+        with torch.no_grad():
+            _, r_llh, r_cell = refiner(out.embedding, initial_preds=out.preds_LLH,
+                                       candidate_cells=out.top5_geocells.indices,
+                                       candidate_probs=out.top5_geocells.values)
+        np.savez(os.path.join(GOLD, "pipeline.npz"),
+                 embedding=out.embedding.numpy(), preds_LLH=out.preds_LLH.numpy(),
+                 preds_geocell=out.preds_geocell.numpy(), topk_values=out.top5_geocells.values.numpy(),
+                 topk_indices=out.top5_geocells.indices.numpy(),
+                 refined_LLH=r_llh.numpy(), refined_cell=r_cell.numpy(),
+                 meta=np.array([11, 2, 1, 8, 55, C_small, 12, 2, 3]))
+        print("pipeline", out.preds_geocell.tolist(), r_llh.tolist())
+
+    if want("refine"):
+        ns = reference_loader.load(geo_small_csv, proto_csv, ds_dir)
+        B, k = 48, 50
+        emb, cands, probs, init = refine_queries(bank, B, k, seed=9)
+        save = dict(embedding=emb.numpy(), candidate_cells=cands.numpy(), candidate_probs=probs.numpy(),
+                    initial_preds=init.numpy(), meta=np.array([C_small, 12, 2]))
+        base = ns.ProtoRefiner(topk=5, max_refinement=1000, temperature=1.6,
+                               proto_path=proto_csv, dataset_path=ds_dir)
+        base.eval()
+        # sanity: the prototypes the reference built == the bank's (same mean-of-members arithmetic)
+        worst = 0.0
+        for c in range(C_small):
+            pr = base.protos[c]
+            s, e = int(bank.cell_off[c]), int(bank.cell_off[c + 1])
+            if pr is None:
+                assert s == e
+                continue
+            ref_e = pr["embedding"][:].numpy()
+            worst = max(worst, float(np.abs(ref_e - bank.proto_emb[s:e]).max()))
+        print("max |reference proto - bank proto| =", worst)
+        save["proto_build_max_abs_diff"] = np.array(worst)
+        for tag, (topk, T, mr) in dict(default=(5, 1.6, 1000), evaluate=(20, 0.6, 100000),
+                                       tight=(5, 1.0, 50)).items():
+            ref = ns.ProtoRefiner(topk=topk, max_refinement=mr, temperature=T, proto_path=proto_csv,
+                                  dataset_path=ds_dir, protos=base.protos)
+            ref.eval()
+            with torch.no_grad():
+                _, llh, cell = ref(emb, initial_preds=init, candidate_cells=cands, candidate_probs=probs)
+            # 3-D embedding input + no candidate_probs variants (proto_refiner.py:139-145)
+            save[f"{tag}_LLH"] = llh.numpy()
+            save[f"{tag}_cell"] = cell.numpy()
+            save[f"{tag}_params"] = np.array([topk, T, mr], dtype=np.float64)
+            print("refine", tag, cell[:10].tolist())
+        ref = ns.ProtoRefiner(topk=5, max_refinement=1000, temperature=1.6, proto_path=proto_csv,
+                              dataset_path=ds_dir, protos=base.protos)
+        ref.eval()
+        emb3 = emb[:, None, :] + torch.tensor([0.1, -0.1, 0.2, -0.2])[None, :, None]
+        with torch.no_grad():
+            _, llh, cell = ref(emb3, initial_preds=init, candidate_cells=cands, candidate_probs=None)
+        save["noprobs3d_LLH"] = llh.numpy()
+        save["noprobs3d_cell"] = cell.numpy()
+        np.savez(os.path.join(GOLD, "refine.npz"), **save)
+
+    print("golden fixtures written to", GOLD)
+
+
+if __name__ == "__main__":
+    main()

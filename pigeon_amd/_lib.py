@@ -1,0 +1,93 @@
+"""ctypes binding of libpigeon_hip.so (include/pigeon_hip.h).  The product path has NO fallback: if the HIP
+library is missing or there is no GPU, importing/using the ops raises -- loudly (see `require_gpu`)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpigeon_hip.so")
+
+PG_DTYPE_F32, PG_DTYPE_BF16 = 0, 1
+EPI_QKV, EPI_GELU, EPI_RESID, EPI_PATCH, EPI_F32 = 0, 1, 2, 3, 4
+PROF_CLASSES = ["gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2", "gemm_patch", "attention", "layernorm",
+                "im2col", "token_mean"]
+
+
+class PigeonHipError(RuntimeError):
+    pass
+
+
+class VitCfg(C.Structure):
+    _fields_ = [("layers", C.c_int32), ("image_size", C.c_int32), ("patch", C.c_int32), ("hidden", C.c_int32),
+                ("heads", C.c_int32), ("mlp", C.c_int32), ("ln_eps", C.c_float), ("max_chunk", C.c_int32)]
+
+
+class Bank(C.Structure):
+    _fields_ = [("proto_emb", C.c_void_p), ("cell_off", C.c_void_p), ("proto_lnglat", C.c_void_p),
+                ("proto_count", C.c_void_p), ("member_off", C.c_void_p), ("member_idx", C.c_void_p),
+                ("train_emb", C.c_void_p), ("train_lnglat", C.c_void_p),
+                ("num_cells", C.c_int64), ("num_protos", C.c_int64), ("num_train", C.c_int64)]
+
+
+# name -> (restype, argtypes); must list EVERY symbol declared in include/pigeon_hip.h (tests check this)
+_P, _I, _I64, _F, _D, _SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
+SIGNATURES = {
+    "pg_last_error": (C.c_char_p, []),
+    "pg_abi_version": (_I, []),
+    "pg_device_count": (_I, []),
+    "pg_vit_create": (_I, [C.POINTER(_P), _I, C.POINTER(VitCfg)]),
+    "pg_vit_load_weight": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_I64), _I]),
+    "pg_vit_finalize": (_I, [_P]),
+    "pg_vit_workspace_bytes": (_I, [_P, _I, C.POINTER(_SZ)]),
+    "pg_vit_forward": (_I, [_P, _P, _I, _I, _P, _P, _SZ, _P]),
+    "pg_vit_forward_hidden": (_I, [_P, _P, _I, _I, _P, _P, _P, _SZ, _P]),
+    "pg_vit_destroy": (_I, [_P]),
+    "pg_vit_profile_enable": (_I, [_P, _I]),
+    "pg_vit_profile_read": (_I, [_P, C.POINTER(_I64), C.POINTER(_D)]),
+    "pg_vit_profile_reset": (_I, [_P]),
+    "pg_head_forward": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "pg_refine_forward": (_I, [C.POINTER(Bank), _P, _I, _I, _P, _P, _P, _I, _I, _F, _D, _P, _P, _P, _P, _P]),
+    "pg_op_gemm_bf16": (_I, [_P, _I64, _P, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _P, _I, _P]),
+    "pg_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I64, _F, _P]),
+    "pg_op_attention": (_I, [_P, _P, _I, _P]),
+    "pg_op_im2col": (_I, [_P, _I, _P, _I, _P]),
+    "pg_op_token_mean": (_I, [_P, _P, _I, _P]),
+    "pg_op_f32_to_bf16": (_I, [_P, _P, _I64, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (no GPU needed for loading / symbol checks)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PigeonHipError(
+            f"{LIB_PATH} not found: build it with `python -m pigeon_amd.build` (hipcc, gfx950). "
+            "pigeon_amd has no CPU/PyTorch fallback for its hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().pg_last_error()
+        raise PigeonHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def require_gpu():
+    """Fail loudly when the HIP path cannot run (missing library or no device)."""
+    lib = load()
+    n = lib.pg_device_count()
+    if n <= 0:
+        raise PigeonHipError("pigeon_amd needs an AMD GPU (gfx950) visible to HIP; found none. "
+                             "There is no CPU fallback for the hot path.")
+    return n

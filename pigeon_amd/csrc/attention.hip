@@ -1,0 +1,217 @@
+// attention.hip -- multi-head self-attention of the ViT (16 heads x 64, 577 tokens, no mask), flash style.
+//
+// Replaces: transformers CLIPAttention.forward + eager_attention_forward (modeling_clip.py:259-335): per
+// (image, head) softmax(Q K^T / 8) V with the softmax in fp32 -- SURVEY.md section 2c row K5.
+//
+// Input is the fused QKV activation (n_img*577, 3072) bf16 exactly as the QKV GEMM writes it (token-major;
+// a head's Q/K/V rows are 128-byte contiguous segments), with Q pre-multiplied by log2(e)/8 so the kernel
+// can use v_exp_f32 (2^x) directly.  Output (n_img*577, 1024) bf16, column = head*64 + d.
+//
+// Structure (gfx950, wave64):
+//   * block = 4 waves = 128 query rows of one (image, head); 5 blocks cover the 577 queries.  The 5 blocks of
+//     a pair are mapped to the SAME XCD (block b runs on XCD b%8) so K/V are fetched into one L2 once.
+//   * K/V are walked in 64-key tiles, register-staged (loads for tile t+1 are issued before tile t is
+//     multiplied, written to LDS after) into a double-buffered LDS image, one barrier per tile.
+//   * S^T = K Q^T: mfma_32x32x16(A = K rows, B = Q rows) leaves each LANE owning one query and 16 keys per
+//     32-key block, so the row max / row sum are in-lane reductions plus one lane^32 exchange.
+//   * P feeds the PV MFMA straight from those registers as the B operand (O^T = V^T P^T).  The key order a
+//     lane holds (keys 4h+{0..3}, 8+4h+{0..3} per 16-wide k-step) is simply used as the contraction order
+//     on BOTH operands: V is stored transposed in LDS (VT[d][key], built with packed ds_write_b32 from the
+//     register-staged rows) and the A operand gathers the same keys with two ds_read_b64.
+//   * O^T accumulators keep lane == query, so the online-softmax rescale is a per-lane scalar multiply.
+//   * key padding: 577 = 9*64 + 1; the last tile masks keys >= 577 to -1e30 before the max.
+#include "common.h"
+#include "pigeon_internal.h"
+
+#define ATT_KT 64
+#define ATT_QB 128                       // query rows per block
+#define ATT_NQB 5                        // ceil(577 / 128)
+#define ATT_NT 10                        // ceil(577 / 64)
+#define K_ROWB 128
+#define VT_STRIDE 136                    // bytes per VT row: 64 keys * 2 B + 8 B pad (conflict-free b64 reads)
+#define K_TILE_BYTES (ATT_KT * K_ROWB)   // 8192
+#define VT_TILE_BYTES (64 * VT_STRIDE)   // 8704
+#define QKV_LD 3072
+
+struct StageRegs { u32x4 k[2]; u32x4 v[2]; };
+
+__device__ __forceinline__ void att_load_tile(StageRegs& st, const uint16_t* __restrict__ qkv, int64_t base,
+                                              int head, int t, int tid) {
+    const int key0 = t * ATT_KT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int cid = tid + i * 256, row = cid >> 3, c = cid & 7;
+        int key = key0 + row; key = key < VIT_TOKENS ? key : VIT_TOKENS - 1;
+        st.k[i] = *(const u32x4*)(qkv + (base + key) * QKV_LD + 1024 + head * 64 + c * 8);
+    }
+    const int j = tid & 31, c = tid >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int key = key0 + 2 * j + i; key = key < VIT_TOKENS ? key : VIT_TOKENS - 1;
+        st.v[i] = *(const u32x4*)(qkv + (base + key) * QKV_LD + 2048 + head * 64 + c * 8);
+    }
+}
+
+__device__ __forceinline__ void att_store_tile(const StageRegs& st, char* ks, char* vt, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int cid = tid + i * 256, row = cid >> 3, c = cid & 7;
+        *(u32x4*)(ks + row * K_ROWB + ((c ^ ((row >> 1) & 7)) << 4)) = st.k[i];
+    }
+    const int j = tid & 31, c = tid >> 5;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t w0 = st.v[0][e >> 1], w1 = st.v[1][e >> 1];
+        const uint32_t lo = (e & 1) ? (w0 >> 16) : (w0 & 0xffffu);
+        const uint32_t hi = (e & 1) ? (w1 >> 16) : (w1 & 0xffffu);
+        *(uint32_t*)(vt + (c * 8 + e) * VT_STRIDE + j * 4) = lo | (hi << 16);   // keys 2j (low), 2j+1 (high)
+    }
+}
+
+__global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * K_TILE_BYTES + 2 * VT_TILE_BYTES];
+    char* ks0 = smem;
+    char* vt0 = smem + 2 * K_TILE_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, g = lane >> 5;
+
+    // XCD-aware decode: the ATT_NQB query blocks of one (image, head) pair share an XCD
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int qb = slot % ATT_NQB;
+    const int pair = (slot / ATT_NQB) * 8 + xcd;
+    const int img = pair >> 4, head = pair & 15;
+    const int64_t base = (int64_t)img * VIT_TOKENS;
+
+    const int q_first = qb * ATT_QB + wave * 32;            // wave-uniform
+    const bool wave_active = q_first < VIT_TOKENS;
+    const int qrow = q_first + lq;
+    const int qr = qrow < VIT_TOKENS ? qrow : VIT_TOKENS - 1;
+
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ksi = 0; ksi < 4; ++ksi)
+        qf[ksi] = *(const bf16x8*)(qkv + (base + qr) * QKV_LD + head * 64 + ksi * 16 + g * 8);
+
+    f32x16 o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m = -1e30f, l = 0.f;
+
+    int kxoff[4];
+#pragma unroll
+    for (int ksi = 0; ksi < 4; ++ksi) kxoff[ksi] = ((ksi * 2 + g) ^ ((lq >> 1) & 7)) << 4;
+
+    StageRegs st;
+    att_load_tile(st, qkv, base, head, 0, tid);
+    att_store_tile(st, ks0, vt0, tid);
+    __syncthreads();
+
+    for (int t = 0; t < ATT_NT; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ATT_NT) att_load_tile(st, qkv, base, head, t + 1, tid);   // in flight during the math
+        const char* ks = ks0 + cur * K_TILE_BYTES;
+        const char* vt = vt0 + cur * VT_TILE_BYTES;
+
+        if (wave_active) {
+            // ---- S^T = K Q^T : lane owns query lq, keys (r&3)+8*(r>>2)+4g of each 32-key block ----
+            f32x16 s[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+                for (int ksi = 0; ksi < 4; ++ksi) {
+                    const bf16x8 kf = *(const bf16x8*)(ks + (kb * 32 + lq) * K_ROWB + kxoff[ksi]);
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ksi], s[kb], 0, 0, 0);
+                }
+            }
+            if (t == ATT_NT - 1) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = t * ATT_KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                        if (key >= VIT_TOKENS) s[kb][r] = -1e30f;
+                    }
+            }
+            // ---- online softmax (base 2; Q carries log2(e)/8) ----
+            float tmax = s[0][0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb][r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m, tmax);
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            m = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+                    s[kb][r] = p;
+                    psum += p;
+                }
+            l = l * alpha + psum;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+
+            // ---- O^T += V^T P^T : B operand = this lane's own P registers, 8 per 16-wide k-step ----
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    u32x4 pw;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) pw[w] = pack_bf16x2(s[kb][8 * s2 + 2 * w], s[kb][8 * s2 + 2 * w + 1]);
+                    const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const char* vrow = vt + (db * 32 + lq) * VT_STRIDE + (kb * 32 + 16 * s2 + 4 * g) * 2;
+                        const u32x2 lo = *(const u32x2*)(vrow);        // keys +0..3
+                        const u32x2 hi = *(const u32x2*)(vrow + 16);   // keys +8..11
+                        u32x4 vw; vw[0] = lo[0]; vw[1] = lo[1]; vw[2] = hi[0]; vw[3] = hi[1];
+                        const bf16x8 vf = __builtin_bit_cast(bf16x8, vw);
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        if (t + 1 < ATT_NT) att_store_tile(st, ks0 + (cur ^ 1) * K_TILE_BYTES, vt0 + (cur ^ 1) * VT_TILE_BYTES, tid);
+        __syncthreads();
+    }
+
+    if (wave_active) {
+        const float ltot = l + __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / ltot;
+        if (qrow < VIT_TOKENS) {
+            uint16_t* orow = out + (base + qrow) * VIT_HIDDEN + head * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    u32x2 pk;
+                    pk[0] = pack_bf16x2(o[db][4 * q4] * inv, o[db][4 * q4 + 1] * inv);
+                    pk[1] = pack_bf16x2(o[db][4 * q4 + 2] * inv, o[db][4 * q4 + 3] * inv);
+                    *(u32x2*)(orow + db * 32 + 8 * q4 + 4 * g) = pk;
+                }
+        }
+    }
+}
+
+int pg_attention_launch(const void* qkv, void* out, int n_images, hipStream_t s) {
+    if (n_images <= 0) return PG_OK;
+    const int pairs = n_images * VIT_HEADS;                  // always a multiple of 8
+    hipLaunchKernelGGL(attention_kernel, dim3(pairs * ATT_NQB), dim3(256), 0, s,
+                       (const uint16_t*)qkv, (uint16_t*)out);
+    return pg_check_launch("attention");
+}

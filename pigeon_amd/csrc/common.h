@@ -1,0 +1,59 @@
+// common.h -- shared device helpers for the gfx950 (CDNA4, wave64) kernels of libpigeon_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;   // one MFMA A/B fragment: 8 bf16 = 4 VGPRs
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;   // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define PG_WAVE 64
+
+// geometry of the ViT-L/14-336 vision tower (reference config.py:6-7)
+#define VIT_TOKENS 577
+#define VIT_PATCHES 576
+#define VIT_HIDDEN 1024
+#define VIT_HEADS 16
+#define VIT_HEAD_DIM 64
+#define VIT_MLP 4096
+#define VIT_PATCH_K 588
+#define VIT_PATCH_KPAD 640
+#define VIT_IMG 336
+
+// fp32 -> bf16 bits, round to nearest even (matches torch's .to(bfloat16)); NaN stays NaN
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
+    return __builtin_bit_cast(float, (uint32_t)b << 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Bijective XCD-aware remap of a 1-D block id (cdna guide T1): hardware places block b on XCD b%8; give each
+// XCD a contiguous chunk of logical ids so that neighbouring tiles (which share operand panels) share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int NX = 8;
+    int xcd = bid % NX, idx = bid / NX;
+    int q = nwg / NX, r = nwg % NX;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

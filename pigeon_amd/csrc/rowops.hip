@@ -1,0 +1,195 @@
+// rowops.hip -- the HBM-bound row kernels of the ViT: LayerNorm (fp32 stats, bf16 or fp32 out), the
+// CLS/position/pre-LayerNorm fix-up, the patch im2col, the token mean and a dtype cast.
+//
+// Replaces: nn.LayerNorm (modeling_clip.py CLIPEncoderLayer.layer_norm1/2, CLIPVisionTransformer.pre_layrnorm),
+// the class-token concat + position add of CLIPVisionEmbeddings.forward (:202-218), the unfold half of the
+// patch Conv2d, and torch.mean(last_hidden_state, dim=1) (reference models/clip_embedder.py:65,
+// models/super_guessr.py:398).
+//
+// All of these are pure streaming kernels: one wave owns one 1024-float row (16 floats per lane as four
+// 16-byte loads), statistics are reduced with cross-lane shuffles, no LDS.
+#include "common.h"
+#include "pigeon_internal.h"
+
+// ---- LayerNorm over 1024 columns; one wave per row, 4 rows per 256-thread block ----------------------
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, void* __restrict__ y,
+                                                        int64_t rows, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * VIT_HIDDEN;
+    f32x4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *(const f32x4*)(xr + i * 256 + lane * 4);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) * (1.0f / VIT_HIDDEN);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    const float var = wave_sum(q) * (1.0f / VIT_HIDDEN);      // biased variance, as torch
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * 256 + lane * 4;
+        const f32x4 g4 = *(const f32x4*)(gamma + c);
+        const f32x4 b4 = *(const f32x4*)(beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
+        if (OUT_BF16) {
+            u32x2 pk;
+            pk[0] = pack_bf16x2(o[0], o[1]);
+            pk[1] = pack_bf16x2(o[2], o[3]);
+            *(u32x2*)((uint16_t*)y + row * VIT_HIDDEN + c) = pk;
+        } else {
+            *(f32x4*)((float*)y + row * VIT_HIDDEN + c) = o;
+        }
+    }
+}
+
+int pg_layernorm_launch(const float* x, const float* gamma, const float* beta, void* y, int out_bf16,
+                        int64_t rows, float eps, hipStream_t s) {
+    if (rows <= 0) return PG_OK;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (out_bf16) hipLaunchKernelGGL(layernorm_kernel<true>, grid, block, 0, s, x, gamma, beta, y, rows, eps);
+    else hipLaunchKernelGGL(layernorm_kernel<false>, grid, block, 0, s, x, gamma, beta, y, rows, eps);
+    return pg_check_launch("layernorm");
+}
+
+// ---- class token + position + pre_layrnorm, in place on the fp32 residual stream ----------------------
+// Row r of x is token t = r % 577 of image r / 577.  Patch rows already hold conv + position (written by the
+// patch GEMM epilogue); row t == 0 is synthesised here as class_embedding + position_embedding[0]
+// (modeling_clip.py:212-217), then every row gets pre_layrnorm.
+__global__ __launch_bounds__(256) void preln_kernel(float* __restrict__ x, const float* __restrict__ cls,
+                                                    const float* __restrict__ pos0, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, int64_t rows, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bool is_cls = (row % VIT_TOKENS) == 0;
+    float* xr = x + row * VIT_HIDDEN;
+    f32x4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (is_cls) v[i] = *(const f32x4*)(cls + c) + *(const f32x4*)(pos0 + c);
+        else v[i] = *(const f32x4*)(xr + c);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) * (1.0f / VIT_HIDDEN);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / VIT_HIDDEN) + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * 256 + lane * 4;
+        const f32x4 g4 = *(const f32x4*)(gamma + c);
+        const f32x4 b4 = *(const f32x4*)(beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
+        *(f32x4*)(xr + c) = o;
+    }
+}
+
+int pg_preln_launch(float* x, const float* cls, const float* pos0, const float* gamma, const float* beta,
+                    int64_t rows, float eps, hipStream_t s) {
+    if (rows <= 0) return PG_OK;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipLaunchKernelGGL(preln_kernel, grid, block, 0, s, x, cls, pos0, gamma, beta, rows, eps);
+    return pg_check_launch("pre_layernorm");
+}
+
+// ---- im2col of the 14x14 stride-14 patch stream -------------------------------------------------------
+// One block per (image, patch-row py).  The 42 source rows (3 channels x 14 ky) of that patch row are each
+// 336 contiguous pixels: reads are fully coalesced; every pixel lands at
+//   out[(img*576 + py*24 + px)*640 + c*196 + ky*14 + kx]   (k order == Conv2d weight [1024,3,14,14] flattened)
+// Columns 588..639 are zero so the GEMM can run K = 640 = 10 x 64.
+template <typename PIX>
+__global__ __launch_bounds__(256) void im2col_kernel(const PIX* __restrict__ pix, uint16_t* __restrict__ out) {
+    const int img = blockIdx.x / 24, py = blockIdx.x % 24;
+    const PIX* src = pix + (int64_t)img * 3 * VIT_IMG * VIT_IMG;
+    uint16_t* dst = out + ((int64_t)img * VIT_PATCHES + py * 24) * VIT_PATCH_KPAD;
+    for (int idx = threadIdx.x; idx < 42 * VIT_IMG; idx += 256) {
+        const int line = idx / VIT_IMG, xcol = idx - line * VIT_IMG;   // line = c*14 + ky
+        const int c = line / 14, ky = line - c * 14;
+        const int px = xcol / 14, kx = xcol - px * 14;
+        float v;
+        if (sizeof(PIX) == 4) v = (float)src[((int64_t)c * VIT_IMG + py * 14 + ky) * VIT_IMG + xcol];
+        else v = bf16_bits_to_f32((uint16_t)src[((int64_t)c * VIT_IMG + py * 14 + ky) * VIT_IMG + xcol]);
+        dst[px * VIT_PATCH_KPAD + c * 196 + ky * 14 + kx] = f32_to_bf16_bits(v);
+    }
+    for (int idx = threadIdx.x; idx < 24 * (VIT_PATCH_KPAD - VIT_PATCH_K); idx += 256) {
+        const int px = idx / (VIT_PATCH_KPAD - VIT_PATCH_K), k = idx % (VIT_PATCH_KPAD - VIT_PATCH_K);
+        dst[px * VIT_PATCH_KPAD + VIT_PATCH_K + k] = 0;
+    }
+}
+
+int pg_im2col_launch(const void* pixels, int pix_dtype, void* out, int n_images, hipStream_t s) {
+    if (n_images <= 0) return PG_OK;
+    dim3 grid(n_images * 24), block(256);
+    if (pix_dtype == PG_DTYPE_F32)
+        hipLaunchKernelGGL(im2col_kernel<float>, grid, block, 0, s, (const float*)pixels, (uint16_t*)out);
+    else if (pix_dtype == PG_DTYPE_BF16)
+        hipLaunchKernelGGL(im2col_kernel<uint16_t>, grid, block, 0, s, (const uint16_t*)pixels, (uint16_t*)out);
+    else { pg_set_error("im2col: unsupported pixel dtype %d", pix_dtype); return PG_EINVAL; }
+    return pg_check_launch("im2col");
+}
+
+// ---- token mean: (n,577,1024) fp32 -> (n,1024) ---------------------------------------------------------
+// Block = (image, 256-column slab); a thread owns one column and walks the 577 rows (coalesced across threads).
+// 4 independent partial sums keep 4 loads in flight.
+__global__ __launch_bounds__(256) void token_mean_kernel(const float* __restrict__ x, float* __restrict__ out) {
+    const int img = blockIdx.x >> 2, col = (blockIdx.x & 3) * 256 + threadIdx.x;
+    const float* p = x + (int64_t)img * VIT_TOKENS * VIT_HIDDEN + col;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int t = 0;
+    for (; t + 4 <= VIT_TOKENS; t += 4) {
+        s0 += p[(int64_t)(t + 0) * VIT_HIDDEN];
+        s1 += p[(int64_t)(t + 1) * VIT_HIDDEN];
+        s2 += p[(int64_t)(t + 2) * VIT_HIDDEN];
+        s3 += p[(int64_t)(t + 3) * VIT_HIDDEN];
+    }
+    for (; t < VIT_TOKENS; ++t) s0 += p[(int64_t)t * VIT_HIDDEN];
+    out[(int64_t)img * VIT_HIDDEN + col] = ((s0 + s1) + (s2 + s3)) / (float)VIT_TOKENS;
+}
+
+int pg_token_mean_launch(const float* x, float* out, int n_images, hipStream_t s) {
+    if (n_images <= 0) return PG_OK;
+    hipLaunchKernelGGL(token_mean_kernel, dim3(n_images * 4), dim3(256), 0, s, x, out);
+    return pg_check_launch("token_mean");
+}
+
+// ---- fp32 -> bf16 cast ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    for (; i + 3 < n; i += stride) {
+        const f32x4 v = *(const f32x4*)(x + i);
+        u32x2 pk;
+        pk[0] = pack_bf16x2(v[0], v[1]);
+        pk[1] = pack_bf16x2(v[2], v[3]);
+        *(u32x2*)(y + i) = pk;
+    }
+    if (i < n) for (int64_t j = i; j < n; ++j) y[j] = f32_to_bf16_bits(x[j]);   // ragged tail (at most one thread)
+}
+
+int pg_f32_to_bf16_launch(const float* x, void* y, int64_t n, hipStream_t s) {
+    if (n <= 0) return PG_OK;
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, (uint16_t*)y, n);
+    return pg_check_launch("f32_to_bf16");
+}

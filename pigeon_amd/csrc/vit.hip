@@ -1,0 +1,361 @@
+// vit.hip -- the pg_vit handle (packed bf16 weights in HBM), the forward-pass orchestration of the ViT-L/14-336
+// encoder, and the exported C ABI (include/pigeon_hip.h) for everything except head/refine.
+//
+// Forward pass for a chunk of n images (M = 577 n rows), all launches asynchronous on the caller's stream:
+//   im2col            pixels (n,3,336,336) -> P (576 n, 640) bf16
+//   gemm<PATCH>       P x Wpatch^T (+ position)            -> X rows 1..576 of every image (fp32 residual stream)
+//   pre_layernorm     class token + position[0], LN in place on X
+//   24 x { LN1 -> Xn bf16 ; gemm<QKV> -> QKV bf16 ; attention -> O bf16 (aliases Xn) ; gemm<RESID>(O, Wo) -> X
+//          LN2 -> Xn bf16 ; gemm<GELU> -> H bf16 (aliases QKV) ; gemm<RESID>(H, W2) -> X }
+//   token_mean        X -> emb (n,1024) fp32
+// HBM layout per chunk: X 4 KB/row fp32, Xn/O 2 KB/row bf16, QKV/H/P 8 KB/row bf16  => 14 KB per token row,
+// 8.1 MB per image; weights 0.61 GB bf16 stay resident.  The residual stream and all LayerNorm / softmax
+// statistics are fp32; only GEMM operands are bf16 (SURVEY "accuracy budget").
+#include "common.h"
+#include "pigeon_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+void pg_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int pg_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { pg_set_error("launch of %s failed: %s", what, hipGetErrorString(e)); return PG_EHIP; }
+    return PG_OK;
+}
+int pg_default_gemm_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("PIGEON_GEMM_VARIANT");
+        v = e ? atoi(e) : 1;
+        if (v <= 0) v = 1;
+    }
+    return v;
+}
+
+extern "C" const char* pg_last_error(void) { return g_err; }
+extern "C" int pg_abi_version(void) { return PG_ABI_VERSION; }
+extern "C" int pg_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { pg_set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return PG_EHIP; }
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------ handle
+struct LayerW {
+    uint16_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;     // bf16 [N][K]
+    float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+    float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+};
+
+struct pg_vit {
+    pg_vit_cfg cfg;
+    int device = 0;
+    bool finalized = false;
+    std::map<std::string, std::vector<float>> host;      // staged fp32 parameters until finalize
+    std::vector<void*> allocs;
+    uint16_t* wpatch = nullptr;                           // [1024][640] bf16 (K zero padded)
+    float *cls = nullptr, *pos = nullptr, *preg = nullptr, *preb = nullptr;
+    std::vector<LayerW> layers;
+    // profiling
+    bool prof = false;
+    struct Ev { hipEvent_t a, b; int cls; };
+    std::vector<Ev> evs;
+    int64_t prof_launches[PG_PROF_CLASSES] = {0};
+    double prof_ms[PG_PROF_CLASSES] = {0};
+};
+
+static const float kQScale = 0.125f * 1.4426950408889634f;    // head_dim^-0.5 * log2(e)
+
+static std::string canon(const char* name) {
+    std::string s(name);
+    const std::string pre = "vision_model.";
+    if (s.compare(0, pre.size(), pre) == 0) s = s.substr(pre.size());
+    return s;
+}
+
+extern "C" int pg_vit_create(pg_vit** out, int device, const pg_vit_cfg* cfg) {
+    if (!out || !cfg) { pg_set_error("vit_create: null argument"); return PG_EINVAL; }
+    if (cfg->image_size != 336 || cfg->patch != 14 || cfg->hidden != 1024 || cfg->heads != 16 || cfg->mlp != 4096 ||
+        cfg->layers < 1) {
+        pg_set_error("vit_create: only the ViT-L/14-336 geometry is supported (336/14/1024/16/4096, layers>=1)");
+        return PG_EINVAL;
+    }
+    int n = 0;
+    PG_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) { pg_set_error("vit_create: device %d of %d", device, n); return PG_EINVAL; }
+    pg_vit* h = new pg_vit();
+    h->cfg = *cfg;
+    if (h->cfg.ln_eps <= 0) h->cfg.ln_eps = 1e-5f;
+    if (h->cfg.max_chunk <= 0) h->cfg.max_chunk = 256;
+    h->device = device;
+    h->layers.resize(cfg->layers);
+    *out = h;
+    return PG_OK;
+}
+
+extern "C" int pg_vit_load_weight(pg_vit* h, const char* name, const void* data, int dtype, const int64_t* shape, int ndim) {
+    if (!h || !name || !data || !shape) { pg_set_error("vit_load_weight: null argument"); return PG_EINVAL; }
+    if (dtype != PG_DTYPE_F32) { pg_set_error("vit_load_weight: only fp32 host data is accepted"); return PG_EINVAL; }
+    if (h->finalized) { pg_set_error("vit_load_weight: handle already finalized"); return PG_ESTATE; }
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    std::string key = canon(name);
+    const float* f = (const float*)data;
+    h->host[key] = std::vector<float>(f, f + n);
+    return PG_OK;
+}
+
+static uint16_t host_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+static int need(pg_vit* h, const std::string& k, size_t n, const std::vector<float>** out) {
+    auto it = h->host.find(k);
+    if (it == h->host.end()) { pg_set_error("vit_finalize: missing parameter %s", k.c_str()); return PG_ESTATE; }
+    if (it->second.size() != n) {
+        pg_set_error("vit_finalize: parameter %s has %zu elements, expected %zu", k.c_str(), it->second.size(), n);
+        return PG_EINVAL;
+    }
+    *out = &it->second;
+    return PG_OK;
+}
+
+static int upload_f32(pg_vit* h, const float* src, size_t n, float** dst) {
+    PG_HIP(hipMalloc((void**)dst, n * sizeof(float)));
+    h->allocs.push_back(*dst);
+    PG_HIP(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+    return PG_OK;
+}
+static int upload_bf16(pg_vit* h, const std::vector<uint16_t>& src, uint16_t** dst) {
+    PG_HIP(hipMalloc((void**)dst, src.size() * 2));
+    h->allocs.push_back(*dst);
+    PG_HIP(hipMemcpy(*dst, src.data(), src.size() * 2, hipMemcpyHostToDevice));
+    return PG_OK;
+}
+
+#define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+extern "C" int pg_vit_finalize(pg_vit* h) {
+    if (!h) { pg_set_error("vit_finalize: null handle"); return PG_EINVAL; }
+    if (h->finalized) return PG_OK;
+    PG_HIP(hipSetDevice(h->device));
+    const size_t D = VIT_HIDDEN, F = VIT_MLP;
+    const std::vector<float>* p;
+    // patch embedding [1024,3,14,14] -> bf16 [1024][640], zero padded along K
+    RC(need(h, "embeddings.patch_embedding.weight", D * VIT_PATCH_K, &p));
+    {
+        std::vector<uint16_t> w(D * VIT_PATCH_KPAD, 0);
+        for (size_t n = 0; n < D; ++n)
+            for (size_t k = 0; k < VIT_PATCH_K; ++k) w[n * VIT_PATCH_KPAD + k] = host_bf16((*p)[n * VIT_PATCH_K + k]);
+        RC(upload_bf16(h, w, &h->wpatch));
+    }
+    RC(need(h, "embeddings.class_embedding", D, &p));                 RC(upload_f32(h, p->data(), D, &h->cls));
+    RC(need(h, "embeddings.position_embedding.weight", VIT_TOKENS * D, &p)); RC(upload_f32(h, p->data(), VIT_TOKENS * D, &h->pos));
+    RC(need(h, "pre_layrnorm.weight", D, &p));                        RC(upload_f32(h, p->data(), D, &h->preg));
+    RC(need(h, "pre_layrnorm.bias", D, &p));                          RC(upload_f32(h, p->data(), D, &h->preb));
+    for (int l = 0; l < h->cfg.layers; ++l) {
+        LayerW& L = h->layers[l];
+        const std::string pre = "encoder.layers." + std::to_string(l) + ".";
+        const std::vector<float>*wq, *wk, *wv, *bq, *bk, *bv;
+        RC(need(h, pre + "self_attn.q_proj.weight", D * D, &wq)); RC(need(h, pre + "self_attn.k_proj.weight", D * D, &wk));
+        RC(need(h, pre + "self_attn.v_proj.weight", D * D, &wv)); RC(need(h, pre + "self_attn.q_proj.bias", D, &bq));
+        RC(need(h, pre + "self_attn.k_proj.bias", D, &bk));       RC(need(h, pre + "self_attn.v_proj.bias", D, &bv));
+        {
+            std::vector<uint16_t> w(3 * D * D);
+            for (size_t i = 0; i < D * D; ++i) { w[i] = host_bf16((*wq)[i]); w[D * D + i] = host_bf16((*wk)[i]); w[2 * D * D + i] = host_bf16((*wv)[i]); }
+            RC(upload_bf16(h, w, &L.wqkv));
+            std::vector<float> b(3 * D);
+            for (size_t i = 0; i < D; ++i) { b[i] = (*bq)[i]; b[D + i] = (*bk)[i]; b[2 * D + i] = (*bv)[i]; }
+            RC(upload_f32(h, b.data(), 3 * D, &L.bqkv));
+        }
+        auto up_w = [&](const std::string& k, size_t n, uint16_t** dst) -> int {
+            const std::vector<float>* q;
+            RC(need(h, k, n, &q));
+            std::vector<uint16_t> w(n);
+            for (size_t i = 0; i < n; ++i) w[i] = host_bf16((*q)[i]);
+            return upload_bf16(h, w, dst);
+        };
+        auto up_f = [&](const std::string& k, size_t n, float** dst) -> int {
+            const std::vector<float>* q;
+            RC(need(h, k, n, &q));
+            return upload_f32(h, q->data(), n, dst);
+        };
+        RC(up_w(pre + "self_attn.out_proj.weight", D * D, &L.wo)); RC(up_f(pre + "self_attn.out_proj.bias", D, &L.bo));
+        RC(up_w(pre + "mlp.fc1.weight", F * D, &L.w1));            RC(up_f(pre + "mlp.fc1.bias", F, &L.b1));
+        RC(up_w(pre + "mlp.fc2.weight", D * F, &L.w2));            RC(up_f(pre + "mlp.fc2.bias", D, &L.b2));
+        RC(up_f(pre + "layer_norm1.weight", D, &L.ln1g));          RC(up_f(pre + "layer_norm1.bias", D, &L.ln1b));
+        RC(up_f(pre + "layer_norm2.weight", D, &L.ln2g));          RC(up_f(pre + "layer_norm2.bias", D, &L.ln2b));
+    }
+    h->host.clear();
+    h->finalized = true;
+    return PG_OK;
+}
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static size_t ws_bytes_for(int chunk) {
+    const size_t M = (size_t)chunk * VIT_TOKENS;
+    return align_up(M * VIT_HIDDEN * 4, 256) + align_up(M * VIT_HIDDEN * 2, 256) + align_up(M * VIT_MLP * 2, 256) + 256;
+}
+
+extern "C" int pg_vit_workspace_bytes(const pg_vit* h, int n_images, size_t* bytes) {
+    if (!h || !bytes || n_images < 0) { pg_set_error("vit_workspace_bytes: bad argument"); return PG_EINVAL; }
+    const int chunk = n_images < h->cfg.max_chunk ? n_images : h->cfg.max_chunk;
+    *bytes = ws_bytes_for(chunk > 0 ? chunk : 1);
+    return PG_OK;
+}
+
+struct ProfScope {
+    pg_vit* h; hipStream_t s; int cls; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(pg_vit* h_, hipStream_t s_, int c) : h(h_), s(s_), cls(c) {
+        if (h->prof) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
+    }
+    ~ProfScope() {
+        if (h->prof) { hipEventRecord(b, s); h->evs.push_back({a, b, cls}); }
+    }
+};
+
+static int vit_forward_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n, float* emb_out, float* hidden_out,
+                             char* ws, hipStream_t s) {
+    const int64_t M = (int64_t)n * VIT_TOKENS;
+    float* X = (float*)ws;
+    uint16_t* Xn = (uint16_t*)(ws + align_up((size_t)M * VIT_HIDDEN * 4, 256));
+    uint16_t* big = (uint16_t*)((char*)Xn + align_up((size_t)M * VIT_HIDDEN * 2, 256));
+    const float eps = h->cfg.ln_eps;
+    { ProfScope p(h, s, 7); RC(pg_im2col_launch(pixels, pix_dtype, big, n, s)); }
+    { ProfScope p(h, s, 4);
+      RC(pg_gemm_launch(big, VIT_PATCH_KPAD, h->wpatch, nullptr, X, VIT_HIDDEN, n * VIT_PATCHES, VIT_HIDDEN, VIT_PATCH_KPAD,
+                        EPI_PATCH, 1.f, 0, h->pos, 0, s)); }
+    { ProfScope p(h, s, 6); RC(pg_preln_launch(X, h->cls, h->pos, h->preg, h->preb, M, eps, s)); }
+    for (int l = 0; l < h->cfg.layers; ++l) {
+        const LayerW& L = h->layers[l];
+        { ProfScope p(h, s, 6); RC(pg_layernorm_launch(X, L.ln1g, L.ln1b, Xn, 1, M, eps, s)); }
+        { ProfScope p(h, s, 0);
+          RC(pg_gemm_launch(Xn, VIT_HIDDEN, L.wqkv, L.bqkv, big, 3 * VIT_HIDDEN, (int)M, 3 * VIT_HIDDEN, VIT_HIDDEN, EPI_QKV,
+                            kQScale, VIT_HIDDEN, nullptr, 0, s)); }
+        { ProfScope p(h, s, 5); RC(pg_attention_launch(big, Xn, n, s)); }
+        { ProfScope p(h, s, 1);
+          RC(pg_gemm_launch(Xn, VIT_HIDDEN, L.wo, L.bo, X, VIT_HIDDEN, (int)M, VIT_HIDDEN, VIT_HIDDEN, EPI_RESID, 1.f, 0, nullptr, 0, s)); }
+        { ProfScope p(h, s, 6); RC(pg_layernorm_launch(X, L.ln2g, L.ln2b, Xn, 1, M, eps, s)); }
+        { ProfScope p(h, s, 2);
+          RC(pg_gemm_launch(Xn, VIT_HIDDEN, L.w1, L.b1, big, VIT_MLP, (int)M, VIT_MLP, VIT_HIDDEN, EPI_GELU, 1.f, 0, nullptr, 0, s)); }
+        { ProfScope p(h, s, 3);
+          RC(pg_gemm_launch(big, VIT_MLP, L.w2, L.b2, X, VIT_HIDDEN, (int)M, VIT_HIDDEN, VIT_MLP, EPI_RESID, 1.f, 0, nullptr, 0, s)); }
+    }
+    { ProfScope p(h, s, 8); RC(pg_token_mean_launch(X, emb_out, n, s)); }
+    if (hidden_out) PG_HIP(hipMemcpyAsync(hidden_out, X, (size_t)M * VIT_HIDDEN * 4, hipMemcpyDeviceToDevice, s));
+    return PG_OK;
+}
+
+extern "C" int pg_vit_forward_hidden(pg_vit* h, const void* pixels, int pix_dtype, int n_images, float* emb_out,
+                                     float* hidden_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !pixels || !emb_out || !workspace) { pg_set_error("vit_forward: null argument"); return PG_EINVAL; }
+    if (!h->finalized) { pg_set_error("vit_forward: handle not finalized"); return PG_ESTATE; }
+    if (n_images <= 0) return PG_OK;
+    if (pix_dtype != PG_DTYPE_F32 && pix_dtype != PG_DTYPE_BF16) { pg_set_error("vit_forward: bad pixel dtype"); return PG_EINVAL; }
+    size_t needb = 0;
+    pg_vit_workspace_bytes(h, n_images, &needb);
+    if (workspace_bytes < needb) { pg_set_error("vit_forward: workspace %zu < required %zu bytes", workspace_bytes, needb); return PG_ENOMEM; }
+    if (((uintptr_t)workspace & 255) != 0) { pg_set_error("vit_forward: workspace must be 256-byte aligned"); return PG_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t esz = pix_dtype == PG_DTYPE_F32 ? 4 : 2;
+    const size_t img_elems = (size_t)3 * VIT_IMG * VIT_IMG;
+    for (int s0 = 0; s0 < n_images; s0 += h->cfg.max_chunk) {
+        const int n = (n_images - s0) < h->cfg.max_chunk ? (n_images - s0) : h->cfg.max_chunk;
+        RC(vit_forward_chunk(h, (const char*)pixels + (size_t)s0 * img_elems * esz, pix_dtype, n,
+                             emb_out + (size_t)s0 * VIT_HIDDEN,
+                             hidden_out ? hidden_out + (size_t)s0 * VIT_TOKENS * VIT_HIDDEN : nullptr, (char*)workspace, s));
+    }
+    return PG_OK;
+}
+
+extern "C" int pg_vit_forward(pg_vit* h, const void* pixels, int pix_dtype, int n_images, float* emb_out, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    return pg_vit_forward_hidden(h, pixels, pix_dtype, n_images, emb_out, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pg_vit_destroy(pg_vit* h) {
+    if (!h) return PG_OK;
+    for (void* p : h->allocs) hipFree(p);
+    for (auto& e : h->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    delete h;
+    return PG_OK;
+}
+
+extern "C" int pg_vit_profile_enable(pg_vit* h, int on) {
+    if (!h) { pg_set_error("profile_enable: null handle"); return PG_EINVAL; }
+    h->prof = on != 0;
+    return PG_OK;
+}
+static int prof_drain(pg_vit* h) {
+    for (auto& e : h->evs) {
+        PG_HIP(hipEventSynchronize(e.b));
+        float ms = 0.f;
+        PG_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+        h->prof_ms[e.cls] += ms;
+        h->prof_launches[e.cls] += 1;
+        hipEventDestroy(e.a); hipEventDestroy(e.b);
+    }
+    h->evs.clear();
+    return PG_OK;
+}
+extern "C" int pg_vit_profile_read(pg_vit* h, int64_t* launches, double* ms) {
+    if (!h || !launches || !ms) { pg_set_error("profile_read: null argument"); return PG_EINVAL; }
+    RC(prof_drain(h));
+    for (int i = 0; i < PG_PROF_CLASSES; ++i) { launches[i] = h->prof_launches[i]; ms[i] = h->prof_ms[i]; }
+    return PG_OK;
+}
+extern "C" int pg_vit_profile_reset(pg_vit* h) {
+    if (!h) { pg_set_error("profile_reset: null handle"); return PG_EINVAL; }
+    RC(prof_drain(h));
+    for (int i = 0; i < PG_PROF_CLASSES; ++i) { h->prof_launches[i] = 0; h->prof_ms[i] = 0; }
+    return PG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ op-level ABI
+extern "C" int pg_op_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
+                               int M, int N, int K, int epi, float qscale, int qcols, const float* aux, int variant,
+                               void* stream) {
+    if (!A || !W || !out) { pg_set_error("op_gemm: null argument"); return PG_EINVAL; }
+    return pg_gemm_launch(A, lda, W, bias, out, ldc, M, N, K, epi, qscale, qcols, aux, variant, (hipStream_t)stream);
+}
+extern "C" int pg_op_layernorm(const float* x, const float* gamma, const float* beta, void* y, int out_dtype,
+                               int64_t rows, float eps, void* stream) {
+    if (!x || !gamma || !beta || !y) { pg_set_error("op_layernorm: null argument"); return PG_EINVAL; }
+    return pg_layernorm_launch(x, gamma, beta, y, out_dtype == PG_DTYPE_BF16, rows, eps, (hipStream_t)stream);
+}
+extern "C" int pg_op_attention(const void* qkv, void* out, int n_images, void* stream) {
+    if (!qkv || !out) { pg_set_error("op_attention: null argument"); return PG_EINVAL; }
+    return pg_attention_launch(qkv, out, n_images, (hipStream_t)stream);
+}
+extern "C" int pg_op_im2col(const void* pixels, int pix_dtype, void* out, int n_images, void* stream) {
+    if (!pixels || !out) { pg_set_error("op_im2col: null argument"); return PG_EINVAL; }
+    return pg_im2col_launch(pixels, pix_dtype, out, n_images, (hipStream_t)stream);
+}
+extern "C" int pg_op_token_mean(const float* x, float* out, int n_images, void* stream) {
+    if (!x || !out) { pg_set_error("op_token_mean: null argument"); return PG_EINVAL; }
+    return pg_token_mean_launch(x, out, n_images, (hipStream_t)stream);
+}
+extern "C" int pg_op_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
+    if (!x || !y) { pg_set_error("op_f32_to_bf16: null argument"); return PG_EINVAL; }
+    return pg_f32_to_bf16_launch(x, y, n, (hipStream_t)stream);
+}

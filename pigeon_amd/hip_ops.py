@@ -1,0 +1,238 @@
+"""Torch-tensor front end of the C ABI: tensors are only containers (device memory + current stream);
+every FLOP of the hot path happens inside libpigeon_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Bank, VitCfg, check, load
+
+TOKENS, HIDDEN, MLP, PATCHES, KPAD = 577, 1024, 4096, 576, 640
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t: torch.Tensor, dtype=None) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.PigeonHipError("expected a device tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.PigeonHipError(f"expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.PigeonHipError("expected a contiguous tensor")
+    return t
+
+
+# ----------------------------------------------------------------------------------------- building blocks
+def gemm_bf16(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epi: int,
+              qscale: float = 1.0, qcols: int = 0, aux: Optional[torch.Tensor] = None, variant: int = 0,
+              M: Optional[int] = None):
+    """out (epilogue-dependent) <- A[M,K] bf16 x W[N,K]^T bf16; see pg_op_gemm_bf16."""
+    _dev(A, torch.bfloat16); _dev(W, torch.bfloat16)
+    M = A.shape[0] if M is None else M
+    K = A.shape[1]
+    N = W.shape[0]
+    check(load().pg_op_gemm_bf16(_p(A), A.stride(0), _p(W), _p(bias), _p(out), out.stride(0), M, N, K, epi,
+                                 float(qscale), int(qcols), _p(aux), variant, _stream()), "pg_op_gemm_bf16")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, out_bf16: bool = True,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev(x, torch.float32)
+    rows = x.numel() // HIDDEN
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    check(load().pg_op_layernorm(_p(x), _p(gamma), _p(beta), _p(out),
+                                 _lib.PG_DTYPE_BF16 if out.dtype == torch.bfloat16 else _lib.PG_DTYPE_F32,
+                                 rows, float(eps), _stream()), "pg_op_layernorm")
+    return out
+
+
+def attention(qkv: torch.Tensor, n_images: int) -> torch.Tensor:
+    _dev(qkv, torch.bfloat16)
+    out = torch.empty((n_images * TOKENS, HIDDEN), dtype=torch.bfloat16, device=qkv.device)
+    check(load().pg_op_attention(_p(qkv), _p(out), n_images, _stream()), "pg_op_attention")
+    return out
+
+
+def im2col(pixels: torch.Tensor) -> torch.Tensor:
+    _dev(pixels)
+    n = pixels.shape[0]
+    dt = _lib.PG_DTYPE_F32 if pixels.dtype == torch.float32 else _lib.PG_DTYPE_BF16
+    out = torch.empty((n * PATCHES, KPAD), dtype=torch.bfloat16, device=pixels.device)
+    check(load().pg_op_im2col(_p(pixels), dt, _p(out), n, _stream()), "pg_op_im2col")
+    return out
+
+
+def token_mean(x: torch.Tensor) -> torch.Tensor:
+    _dev(x, torch.float32)
+    n = x.shape[0]
+    out = torch.empty((n, HIDDEN), dtype=torch.float32, device=x.device)
+    check(load().pg_op_token_mean(_p(x), _p(out), n, _stream()), "pg_op_token_mean")
+    return out
+
+
+def f32_to_bf16(x: torch.Tensor) -> torch.Tensor:
+    _dev(x, torch.float32)
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(load().pg_op_f32_to_bf16(_p(x), _p(y), x.numel(), _stream()), "pg_op_f32_to_bf16")
+    return y
+
+
+# ----------------------------------------------------------------------------------------- ViT encoder handle
+class VitEncoder:
+    """Owns a pg_vit handle: bf16-packed weights resident in HBM, forward = ViT-L/14-336 + token mean.
+
+    state_dict keys may be in either transformers layout (vision_model.* or flat); values are CPU or device
+    tensors of any float dtype (converted to fp32 on the host, then packed by the library).
+    """
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device: int = 0, max_chunk: int = 0, layers: Optional[int] = None):
+        _lib.require_gpu()
+        lib = load()
+        keys = [k[len("vision_model."):] if k.startswith("vision_model.") else k for k in state_dict]
+        if layers is None:
+            layers = 0
+            while f"encoder.layers.{layers}.layer_norm1.weight" in keys:
+                layers += 1
+        if layers < 1:
+            raise _lib.PigeonHipError("state dict holds no encoder layers")
+        self.layers = layers
+        self.device = device
+        cfg = VitCfg(layers, 336, 14, 1024, 16, 4096, 1e-5, max_chunk)
+        h = C.c_void_p()
+        torch.cuda.set_device(device)
+        check(lib.pg_vit_create(C.byref(h), device, C.byref(cfg)), "pg_vit_create")
+        self._h = h
+        for name, t in state_dict.items():
+            if not torch.is_tensor(t) or not t.is_floating_point():
+                continue                                   # e.g. embeddings.position_ids (int64 buffer)
+            a = t.detach().to("cpu", torch.float32).contiguous()
+            shape = (C.c_int64 * max(a.dim(), 1))(*(list(a.shape) or [1]))
+            check(lib.pg_vit_load_weight(h, name.encode(), C.c_void_p(a.data_ptr()), _lib.PG_DTYPE_F32, shape,
+                                         max(a.dim(), 1)), f"pg_vit_load_weight({name})")
+        check(lib.pg_vit_finalize(h), "pg_vit_finalize")
+        self._ws = None
+        self.max_chunk = max_chunk if max_chunk > 0 else 256
+
+    def _workspace(self, n: int) -> torch.Tensor:
+        need = C.c_size_t()
+        check(load().pg_vit_workspace_bytes(self._h, n, C.byref(need)), "pg_vit_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need.value:
+            self._ws = None
+            self._ws = torch.empty(need.value + 256, dtype=torch.uint8, device=f"cuda:{self.device}")
+        return self._ws
+
+    def forward(self, pixels: torch.Tensor, return_hidden: bool = False):
+        """pixels (N,3,336,336) fp32/bf16 on the device -> (N,1024) fp32 [, (N,577,1024) fp32]."""
+        _dev(pixels)
+        if pixels.dim() != 4 or tuple(pixels.shape[1:]) != (3, 336, 336):
+            raise _lib.PigeonHipError(f"pixels must be (N,3,336,336), got {tuple(pixels.shape)}")
+        if pixels.dtype not in (torch.float32, torch.bfloat16):
+            raise _lib.PigeonHipError("pixels must be fp32 or bf16")
+        n = pixels.shape[0]
+        ws = self._workspace(n)
+        off = (-ws.data_ptr()) % 256
+        emb = torch.empty((n, HIDDEN), dtype=torch.float32, device=pixels.device)
+        hid = torch.empty((n, TOKENS, HIDDEN), dtype=torch.float32, device=pixels.device) if return_hidden else None
+        dt = _lib.PG_DTYPE_F32 if pixels.dtype == torch.float32 else _lib.PG_DTYPE_BF16
+        check(load().pg_vit_forward_hidden(self._h, _p(pixels), dt, n, _p(emb), _p(hid),
+                                           C.c_void_p(ws.data_ptr() + off), ws.numel() - off, _stream()),
+              "pg_vit_forward")
+        return (emb, hid) if return_hidden else emb
+
+    __call__ = forward
+
+    # ---- per-kernel-class timing for bench.py ----
+    def profile_enable(self, on: bool = True):
+        check(load().pg_vit_profile_enable(self._h, 1 if on else 0), "pg_vit_profile_enable")
+
+    def profile_reset(self):
+        check(load().pg_vit_profile_reset(self._h), "pg_vit_profile_reset")
+
+    def profile_read(self):
+        n = len(_lib.PROF_CLASSES)
+        launches = (C.c_int64 * n)()
+        ms = (C.c_double * n)()
+        check(load().pg_vit_profile_read(self._h, launches, ms), "pg_vit_profile_read")
+        return {name: (int(launches[i]), float(ms[i])) for i, name in enumerate(_lib.PROF_CLASSES)}
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            load().pg_vit_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ----------------------------------------------------------------------------------------- head
+def head_forward(emb: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, centroids: torch.Tensor, k: int):
+    """emb (B,P,1024) or (B,1024) fp32; returns dict(logits, topk_values, topk_indices, preds_geocell, preds_LLH)."""
+    _dev(emb, torch.float32); _dev(W, torch.float32); _dev(bias, torch.float32); _dev(centroids, torch.float64)
+    B = emb.shape[0]
+    P = emb.shape[1] if emb.dim() == 3 else 1
+    Cn = W.shape[0]
+    dev = emb.device
+    logits = torch.empty((B, Cn), dtype=torch.float32, device=dev)
+    tv = torch.empty((B, k), dtype=torch.float32, device=dev)
+    ti = torch.empty((B, k), dtype=torch.int64, device=dev)
+    am = torch.empty((B,), dtype=torch.int64, device=dev)
+    llh = torch.empty((B, 2), dtype=torch.float64, device=dev)
+    check(load().pg_head_forward(_p(emb), B, P, _p(W), _p(bias), _p(centroids), Cn, k, _p(logits), _p(tv), _p(ti),
+                                 _p(am), _p(llh), _stream()), "pg_head_forward")
+    return dict(logits=logits, topk_values=tv, topk_indices=ti, preds_geocell=am, preds_LLH=llh)
+
+
+# ----------------------------------------------------------------------------------------- refiner
+class DeviceBank:
+    """CSR prototype bank resident in HBM (see include/pigeon_hip.h pg_bank)."""
+
+    FIELDS = [("proto_emb", torch.float32), ("cell_off", torch.int64), ("proto_lnglat", torch.float32),
+              ("proto_count", torch.int32), ("member_off", torch.int64), ("member_idx", torch.int64),
+              ("train_emb", torch.float32), ("train_lnglat", torch.float32)]
+
+    def __init__(self, arrays, device="cuda"):
+        self.t = {}
+        for name, dt in self.FIELDS:
+            a = getattr(arrays, name) if not isinstance(arrays, dict) else arrays[name]
+            t = torch.as_tensor(a) if not torch.is_tensor(a) else a
+            self.t[name] = t.to(device=device, dtype=dt).contiguous()
+        self.num_cells = self.t["cell_off"].numel() - 1
+        self.num_protos = self.t["proto_emb"].shape[0]
+        self.num_train = self.t["train_emb"].shape[0]
+        self.struct = Bank(*[C.c_void_p(self.t[n].data_ptr()) for n, _ in self.FIELDS],
+                           self.num_cells, self.num_protos, self.num_train)
+
+
+def refine_forward(bank: DeviceBank, q: torch.Tensor, init_llh: torch.Tensor, cand: torch.Tensor,
+                   cand_prob: Optional[torch.Tensor], topk: int, temperature: float, max_refine_km: float):
+    """Returns (preds_LLH (B,2) f32, preds_geocell (B,) i64, choice (B,) i32)."""
+    _dev(q, torch.float32); _dev(init_llh, torch.float64); _dev(cand, torch.int64)
+    if cand_prob is not None:
+        _dev(cand_prob, torch.float32)
+    B = q.shape[0]
+    P = q.shape[1] if q.dim() == 3 else 1
+    k = cand.shape[1]
+    dev = q.device
+    scratch = torch.empty((B, topk, 4), dtype=torch.float32, device=dev)
+    out_llh = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    out_cell = torch.empty((B,), dtype=torch.int64, device=dev)
+    out_choice = torch.empty((B,), dtype=torch.int32, device=dev)
+    check(load().pg_refine_forward(C.byref(bank.struct), _p(q), B, P, _p(init_llh), _p(cand), _p(cand_prob), k, topk,
+                                   float(temperature), float(max_refine_km), _p(scratch), _p(out_llh), _p(out_cell),
+                                   _p(out_choice), _stream()), "pg_refine_forward")
+    return out_llh, out_cell, out_choice

@@ -1,0 +1,228 @@
+"""Seeded synthetic weights / inputs / geocells / prototype banks for the PIGEON hot path.
+
+The reference ships no weights, geocells, prototypes or data (reference README.md:11), so every
+parity test and the benchmark run on synthetic fixtures built here.
+
+All generators are pure functions of their seed; they run identically in the authoring container and on
+the GPU box, which is what lets small golden OUTPUT vectors (tests/golden/) stand in for the 1.2 GB of
+ViT-L weights that cannot be committed.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+# ViT-L/14-336 geometry (reference config.py:6-7, `openai/clip-vit-large-patch14-336`)
+IMAGE_SIZE = 336
+PATCH = 14
+GRID = IMAGE_SIZE // PATCH            # 24
+TOKENS = GRID * GRID + 1              # 577
+HIDDEN = 1024
+HEADS = 16
+HEAD_DIM = 64
+MLP = 4096
+LAYERS = 24
+PATCH_K = 3 * PATCH * PATCH           # 588
+
+
+def make_vit_weights(seed: int = 0, layers: int = LAYERS, affine_jitter: bool = False,
+                     scale: float = 1.0, std_layers: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    """State dict (transformers>=5 flat key layout) of a random-init CLIP ViT-L/14-336 vision tower.
+
+    Distributions follow transformers' ``CLIPPreTrainedModel._init_weights`` (modeling_clip.py:404-428):
+    class_embedding ~ N(0, D^-1/2), patch/position embedding ~ N(0, 0.02), q/k/v and fc2 ~
+    N(0, D^-1/2 (2L)^-1/2), out_proj ~ N(0, D^-1/2), fc1 ~ N(0, (2D)^-1/2); biases 0, LayerNorm (1, 0).
+
+    affine_jitter=True additionally randomises every bias and LayerNorm gamma/beta so that the bias /
+    gamma / beta code paths of the kernels are actually exercised by parity tests (HF's default init
+    leaves them at 0 / 1 / 0, which would hide a dropped bias).  ``scale`` multiplies the projection
+    weights to push the network into a less benign numeric regime for stress tests.
+    """
+    g = torch.Generator().manual_seed(seed)
+    D, F = HIDDEN, MLP
+    L_std = layers if std_layers is None else std_layers
+
+    def normal(shape, std):
+        return torch.empty(shape, dtype=torch.float32).normal_(0.0, std, generator=g)
+
+    in_std = D ** -0.5 * (2 * L_std) ** -0.5 * scale
+    out_std = D ** -0.5 * scale
+    fc_std = (2 * D) ** -0.5 * scale
+    sd: Dict[str, torch.Tensor] = {}
+    sd["embeddings.class_embedding"] = normal((D,), D ** -0.5)
+    sd["embeddings.patch_embedding.weight"] = normal((D, 3, PATCH, PATCH), 0.02)
+    sd["embeddings.position_embedding.weight"] = normal((TOKENS, D), 0.02)
+
+    def ln(prefix):
+        if affine_jitter:
+            sd[prefix + ".weight"] = 1.0 + normal((D,), 0.1)
+            sd[prefix + ".bias"] = normal((D,), 0.05)
+        else:
+            sd[prefix + ".weight"] = torch.ones(D)
+            sd[prefix + ".bias"] = torch.zeros(D)
+
+    def bias(n):
+        return normal((n,), 0.02) if affine_jitter else torch.zeros(n)
+
+    ln("pre_layrnorm")
+    for i in range(layers):
+        p = f"encoder.layers.{i}."
+        sd[p + "self_attn.k_proj.weight"] = normal((D, D), in_std)
+        sd[p + "self_attn.k_proj.bias"] = bias(D)
+        sd[p + "self_attn.v_proj.weight"] = normal((D, D), in_std)
+        sd[p + "self_attn.v_proj.bias"] = bias(D)
+        sd[p + "self_attn.q_proj.weight"] = normal((D, D), in_std)
+        sd[p + "self_attn.q_proj.bias"] = bias(D)
+        sd[p + "self_attn.out_proj.weight"] = normal((D, D), out_std)
+        sd[p + "self_attn.out_proj.bias"] = bias(D)
+        ln(p + "layer_norm1")
+        sd[p + "mlp.fc1.weight"] = normal((F, D), fc_std)
+        sd[p + "mlp.fc1.bias"] = bias(F)
+        sd[p + "mlp.fc2.weight"] = normal((D, F), in_std)
+        sd[p + "mlp.fc2.bias"] = bias(D)
+        ln(p + "layer_norm2")
+    ln("post_layernorm")   # dead weight on this path but part of the state dict
+    return sd
+
+
+def make_pixels(n_images: int, seed: int = 1234, panorama: bool = False) -> torch.Tensor:
+    """Seeded N(0,1) pixels, the statistics of CLIP-normalised images.
+
+    panorama=False -> (N,3,336,336); panorama=True -> (N/4, 12, 336, 336), the 4 panels concatenated on
+    the channel axis exactly as reference preprocessing/dataset_preprocessing.py:199-200 does.
+    """
+    g = torch.Generator().manual_seed(seed)
+    if panorama:
+        assert n_images % 4 == 0
+        return torch.randn((n_images // 4, 12, IMAGE_SIZE, IMAGE_SIZE), generator=g)
+    return torch.randn((n_images, 3, IMAGE_SIZE, IMAGE_SIZE), generator=g)
+
+
+def make_geocells(num_cells: int = 10000, seed: int = 0) -> np.ndarray:
+    """(C,2) float64 [lng,lat] centroids, lng~U(-180,180), lat~U(-90,90)."""
+    rng = np.random.default_rng(seed)
+    lng = rng.uniform(-180.0, 180.0, size=num_cells)
+    lat = rng.uniform(-90.0, 90.0, size=num_cells)
+    return np.stack([lng, lat], axis=1)
+
+
+def write_geocell_csv(path: str, centroids: np.ndarray) -> None:
+    """CSV with the two columns the reference reads (models/super_guessr.py:171-172)."""
+    import pandas as pd
+    pd.DataFrame({"lng": centroids[:, 0], "lat": centroids[:, 1]}).to_csv(path, index=False)
+
+
+def make_head_weights(num_cells: int, seed: int = 0, embed_dim: int = HIDDEN):
+    """nn.Linear(embed_dim, C) default init: U(-1/sqrt(in), 1/sqrt(in)) for weight and bias."""
+    g = torch.Generator().manual_seed(seed + 7)
+    bound = 1.0 / math.sqrt(embed_dim)
+    W = (torch.rand((num_cells, embed_dim), generator=g) * 2 - 1) * bound
+    b = (torch.rand((num_cells,), generator=g) * 2 - 1) * bound
+    return W, b
+
+
+class SyntheticBank:
+    """A CSR prototype bank + its training-embedding bank, in the arrays the kernels consume.
+
+    proto_emb   (P,1024) f32   prototype embedding = mean of member embeddings (proto_refiner.py:359-378)
+    cell_off    (C+1,)  i64    CSR offsets of each geocell's prototypes (empty cell -> zero-length)
+    proto_lnglat(P,2)   f32    cluster centroid (`lng`,`lat` columns; float32 under torch format)
+    proto_count (P,)    i32    `count` column
+    member_off  (P+1,)  i64    CSR offsets into member_idx
+    member_idx  (Nm,)   i64    `indices` column (rows of the training bank)
+    train_emb   (Ntr,1024) f32 training embeddings (panel-averaged)
+    train_lnglat(Ntr,2) f32    training `labels` [lng,lat]
+    """
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    @property
+    def num_cells(self):
+        return self.cell_off.shape[0] - 1
+
+
+def make_bank(num_cells: int, protos_per_cell: int, seed: int = 2, dim: int = HIDDEN,
+              empty_frac: float = 0.01, max_members: int = 8, exact_means: bool = True,
+              jitter_protos: bool = True) -> SyntheticBank:
+    """Synthetic prototype bank per SURVEY 8d: ~1% empty cells; 50% singleton clusters, 50% with 2..8
+    members.  Training rows are laid out cluster by cluster so member lists are contiguous ranges (the
+    kernels do not rely on that; member_idx is still an explicit index list).
+
+    exact_means=True computes each prototype as the fp32 mean of its members exactly as the reference
+    does (needed for parity against the reference's own prototype builder).  For the 1M-row perf bank
+    exact_means=False draws prototypes directly (mean-of-members is irrelevant to kernel speed).
+    """
+    rng = np.random.default_rng(seed)
+    empty = rng.random(num_cells) < empty_frac
+    empty[-1] = False   # the reference sizes its proto list by max(geocell_idx)+1 (proto_refiner.py:75)
+    n_per_cell = np.where(empty, 0, protos_per_cell).astype(np.int64)
+    cell_off = np.zeros(num_cells + 1, dtype=np.int64)
+    np.cumsum(n_per_cell, out=cell_off[1:])
+    P = int(cell_off[-1])
+    multi = rng.random(P) < 0.5
+    count = np.where(multi, rng.integers(2, max_members + 1, size=P), 1).astype(np.int32)
+    member_off = np.zeros(P + 1, dtype=np.int64)
+    np.cumsum(count.astype(np.int64), out=member_off[1:])
+    Ntr = int(member_off[-1])
+    member_idx = rng.permutation(Ntr).astype(np.int64)   # scattered rows: exercises the gather
+    train_lnglat = np.stack([rng.uniform(-180, 180, Ntr), rng.uniform(-90, 90, Ntr)], axis=1).astype(np.float32)
+    if exact_means:
+        train_emb = rng.standard_normal((Ntr, dim), dtype=np.float32)
+        if jitter_protos:
+            # members of one cluster share a centre so that "nearest prototype" is meaningful
+            centres = rng.standard_normal((P, dim), dtype=np.float32)
+            rows = np.repeat(np.arange(P), count)
+            train_emb[member_idx] = centres[rows] + 0.3 * train_emb[member_idx]
+        te = torch.from_numpy(train_emb)
+        proto_emb = np.empty((P, dim), dtype=np.float32)
+        for p in range(P):
+            idx = torch.from_numpy(member_idx[member_off[p]:member_off[p + 1]])
+            proto_emb[p] = te[idx].mean(dim=0).numpy()      # torch mean, as proto_refiner.py:378
+    else:
+        proto_emb = rng.standard_normal((P, dim), dtype=np.float32)
+        train_emb = rng.standard_normal((Ntr, dim), dtype=np.float32)
+    # cluster centroid = mean of member labels in float64 then stored float32 (torch format)
+    proto_lnglat = np.empty((P, 2), dtype=np.float32)
+    lab = train_lnglat.astype(np.float64)
+    sums = np.add.reduceat(lab[member_idx], member_off[:-1], axis=0) if P > 0 else np.zeros((0, 2))
+    proto_lnglat[:] = (sums / count[:, None]).astype(np.float32)
+    return SyntheticBank(proto_emb=proto_emb, cell_off=cell_off, proto_lnglat=proto_lnglat,
+                         proto_count=count, member_off=member_off, member_idx=member_idx,
+                         train_emb=train_emb, train_lnglat=train_lnglat)
+
+
+def write_bank_reference_files(bank: SyntheticBank, proto_csv: str, dataset_dir: str) -> None:
+    """Write the bank in the two on-disk formats the REFERENCE consumes:
+    the prototype CSV (columns geocell_idx,cluster,lng,lat,count,indices with `indices` a JSON list;
+    dataset_creation/prototype/prototype.py:87-95, models/proto_refiner.py:70-76) and a HF DatasetDict
+    with split `train`, columns `embedding` (1024,) f32 and `labels` (2,) [lng,lat]
+    (models/proto_refiner.py:67,247-255,370-376)."""
+    import pandas as pd
+    import datasets
+    rows = []
+    C = bank.num_cells
+    for c in range(C):
+        for j, p in enumerate(range(int(bank.cell_off[c]), int(bank.cell_off[c + 1]))):
+            idx = bank.member_idx[bank.member_off[p]:bank.member_off[p + 1]].tolist()
+            rows.append(dict(geocell_idx=c, cluster=j, lng=float(bank.proto_lnglat[p, 0]),
+                             lat=float(bank.proto_lnglat[p, 1]), count=int(bank.proto_count[p]),
+                             indices=json.dumps(idx)))
+    # the reference sizes its table by max(geocell_idx)+1 (proto_refiner.py:75): make sure the last cell exists
+    pd.DataFrame(rows).to_csv(proto_csv, index=False)
+    ds = datasets.Dataset.from_dict({
+        "embedding": bank.train_emb,
+        "labels": bank.train_lnglat,
+    })
+    ds.set_format("torch")
+    datasets.DatasetDict(train=ds).save_to_disk(dataset_dir)
+
+
+def env_cores() -> int:
+    return os.cpu_count() or 1
