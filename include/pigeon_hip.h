@@ -34,6 +34,7 @@ extern "C" {
 
 #define PG_DTYPE_F32     0
 #define PG_DTYPE_BF16    1
+#define PG_DTYPE_F16     2
 
 #define PG_ABI_VERSION   1
 
@@ -60,6 +61,9 @@ typedef struct pg_vit_cfg {
     int32_t mlp;          /* must be 4096 */
     float   ln_eps;       /* 1e-5 */
     int32_t max_chunk;    /* images processed per internal pass (0 = default 256) */
+    int32_t mma_dtype;    /* 16-bit MFMA operand format for weights and activations: PG_DTYPE_F16, PG_DTYPE_BF16, or
+                             0 = default (fp16, unless env PIGEON_MMA_DTYPE=bf16).  Same MFMA rate on gfx950; fp16
+                             keeps embeddings within 1e-3 of the fp32 reference, bf16 measures 2e-3. */
 } pg_vit_cfg;
 
 int pg_vit_create(pg_vit** out, int device, const pg_vit_cfg* cfg);
@@ -83,6 +87,8 @@ int pg_vit_forward(pg_vit* h, const void* pixels, int pix_dtype, int n_images, f
 int pg_vit_forward_hidden(pg_vit* h, const void* pixels, int pix_dtype, int n_images, float* emb_out,
                           float* hidden_out, void* workspace, size_t workspace_bytes, void* stream);
 int pg_vit_destroy(pg_vit* h);
+/* The operand format the handle resolved to (PG_DTYPE_F16 or PG_DTYPE_BF16). */
+int pg_vit_mma_dtype(const pg_vit* h);
 
 /* Per-kernel-class timing (HIP events on `stream`), for bench.py's roofline object.
  * pg_vit_profile_enable(h,1) makes subsequent forwards bracket every launch with events;
@@ -149,29 +155,30 @@ int pg_refine_forward(const pg_bank* bank, const float* q, int B, int P, const d
 /* ------------------------------------------------------------------------------------------------
  * Building-block ops (exported so the parity tests can check every kernel in isolation through the ABI).
  * ------------------------------------------------------------------------------------------------ */
-/* C = A (M,K bf16, row stride lda) x W^T (N,K bf16) with fp32 accumulation and a fused epilogue:
- *   epi 0: out bf16 (M,ldc) = acc + bias; columns < qcols additionally scaled by qscale      (QKV)
- *   epi 1: out bf16 = quick_gelu(acc + bias) = x*sigmoid(1.702x)                              (fc1)
+/* `dtype` below is the 16-bit operand/activation format: PG_DTYPE_F16 or PG_DTYPE_BF16.
+ * C = A (M,K 16-bit, row stride lda) x W^T (N,K 16-bit) with fp32 accumulation and a fused epilogue:
+ *   epi 0: out 16-bit (M,ldc) = acc + bias; columns < qcols additionally scaled by qscale     (QKV)
+ *   epi 1: out 16-bit = quick_gelu(acc + bias) = x*sigmoid(1.702x)                            (fc1)
  *   epi 2: out fp32 (M,ldc) += acc + bias  (in-place residual add)                            (out_proj, fc2)
  *   epi 3: patch embed: row = img*576+p -> out fp32 row (img*577+1+p) = acc + aux[(1+p)*N + col] (aux = pos emb)
  *   epi 4: out fp32 = acc + bias (bias may be NULL)                                           (tests)
  * N must be a multiple of 256, K a multiple of 64.  variant selects the tile configuration (0 = default). */
-int pg_op_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
-                    int M, int N, int K, int epi, float qscale, int qcols, const float* aux,
-                    int variant, void* stream);
+int pg_op_gemm16(int dtype, const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
+                 int M, int N, int K, int epi, float qscale, int qcols, const float* aux,
+                 int variant, void* stream);
 /* y = LayerNorm(x) over the last dim (1024), eps, gamma/beta fp32.  x fp32 (rows,1024).
- * out_dtype PG_DTYPE_BF16 -> y bf16 (rows,1024); PG_DTYPE_F32 -> fp32 (may alias x). */
+ * out_dtype PG_DTYPE_F16/BF16 -> y 16-bit (rows,1024); PG_DTYPE_F32 -> fp32 (may alias x). */
 int pg_op_layernorm(const float* x, const float* gamma, const float* beta, void* y, int out_dtype,
                     int64_t rows, float eps, void* stream);
-/* Multi-head attention over the fused QKV buffer (n_images*577, 3072) bf16 -> out (n_images*577,1024) bf16.
+/* Multi-head attention over the fused QKV buffer (n_images*577, 3072) 16-bit -> out (n_images*577,1024) 16-bit.
  * Q must already carry the factor log2(e)/sqrt(64) (the GEMM epilogue applies it); softmax in fp32. */
-int pg_op_attention(const void* qkv, void* out, int n_images, void* stream);
-/* fp32/bf16 NCHW pixels -> bf16 patch matrix (n_images*576, 640), k = c*196+ky*14+kx, cols 588..639 zero. */
-int pg_op_im2col(const void* pixels, int pix_dtype, void* out, int n_images, void* stream);
+int pg_op_attention(int dtype, const void* qkv, void* out, int n_images, void* stream);
+/* fp32/bf16 NCHW pixels -> 16-bit patch matrix (n_images*576, 640), k = c*196+ky*14+kx, cols 588..639 zero. */
+int pg_op_im2col(const void* pixels, int pix_dtype, void* out, int out_dtype, int n_images, void* stream);
 /* mean over the 577 tokens: x fp32 (n_images,577,1024) -> (n_images,1024). */
 int pg_op_token_mean(const float* x, float* out, int n_images, void* stream);
-/* fp32 -> bf16 (round to nearest even), n elements. */
-int pg_op_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+/* fp32 -> fp16/bf16 (round to nearest even; fp16 saturates), n elements. */
+int pg_op_cast_f32(const float* x, void* y, int out_dtype, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpigeon_hip.so")
 
-PG_DTYPE_F32, PG_DTYPE_BF16 = 0, 1
+PG_DTYPE_F32, PG_DTYPE_BF16, PG_DTYPE_F16 = 0, 1, 2
 EPI_QKV, EPI_GELU, EPI_RESID, EPI_PATCH, EPI_F32 = 0, 1, 2, 3, 4
 PROF_CLASSES = ["gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2", "gemm_patch", "attention", "layernorm",
                 "im2col", "token_mean"]
@@ -20,7 +20,8 @@ class PigeonHipError(RuntimeError):
 
 class VitCfg(C.Structure):
     _fields_ = [("layers", C.c_int32), ("image_size", C.c_int32), ("patch", C.c_int32), ("hidden", C.c_int32),
-                ("heads", C.c_int32), ("mlp", C.c_int32), ("ln_eps", C.c_float), ("max_chunk", C.c_int32)]
+                ("heads", C.c_int32), ("mlp", C.c_int32), ("ln_eps", C.c_float), ("max_chunk", C.c_int32),
+                ("mma_dtype", C.c_int32)]
 
 
 class Bank(C.Structure):
@@ -43,17 +44,18 @@ SIGNATURES = {
     "pg_vit_forward": (_I, [_P, _P, _I, _I, _P, _P, _SZ, _P]),
     "pg_vit_forward_hidden": (_I, [_P, _P, _I, _I, _P, _P, _P, _SZ, _P]),
     "pg_vit_destroy": (_I, [_P]),
+    "pg_vit_mma_dtype": (_I, [_P]),
     "pg_vit_profile_enable": (_I, [_P, _I]),
     "pg_vit_profile_read": (_I, [_P, C.POINTER(_I64), C.POINTER(_D)]),
     "pg_vit_profile_reset": (_I, [_P]),
     "pg_head_forward": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "pg_refine_forward": (_I, [C.POINTER(Bank), _P, _I, _I, _P, _P, _P, _I, _I, _F, _D, _P, _P, _P, _P, _P]),
-    "pg_op_gemm_bf16": (_I, [_P, _I64, _P, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _P, _I, _P]),
+    "pg_op_gemm16": (_I, [_I, _P, _I64, _P, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _P, _I, _P]),
     "pg_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I64, _F, _P]),
-    "pg_op_attention": (_I, [_P, _P, _I, _P]),
-    "pg_op_im2col": (_I, [_P, _I, _P, _I, _P]),
+    "pg_op_attention": (_I, [_I, _P, _P, _I, _P]),
+    "pg_op_im2col": (_I, [_P, _I, _P, _I, _I, _P]),
     "pg_op_token_mean": (_I, [_P, _P, _I, _P]),
-    "pg_op_f32_to_bf16": (_I, [_P, _P, _I64, _P]),
+    "pg_op_cast_f32": (_I, [_P, _P, _I, _I64, _P]),
 }
 
 _lib = None

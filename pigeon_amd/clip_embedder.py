@@ -1,0 +1,189 @@
+"""CLIP ViT-L/14-336 image embedder on the HIP kernels, behind the reference's call surface.
+
+Mirrors reference models/clip_embedder.py (class CLIPEmbedding: same constructor arguments, `forward(image)`
+accepts PIL image(s) or an (N,3,336,336) tensor and returns the (N,1024) mean-over-577-tokens embedding on
+the device), with `transformers.CLIPVisionModel` replaced by `HipCLIPVisionModel`, a module whose forward
+runs entirely inside libpigeon_hip.so.
+"""
+from __future__ import annotations
+
+import os
+from types import SimpleNamespace
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import hip_ops, synthetic
+from .config import CLIP_MODEL, OPENAI_CLIP_MEAN, OPENAI_CLIP_STD
+from .utils import load_state_dict
+
+
+class HipCLIPVisionModel(torch.nn.Module):
+    """Stand-in for transformers.CLIPVisionModel on this path.
+
+    * holds the fp32 parameters under the SAME state-dict names as transformers (flat 5.x layout; the 4.23.1
+      `vision_model.` prefix is accepted on load), so the reference's name-wise checkpoint loading
+      (models/utils.py:24-45, models/super_guessr.py:222-238) keeps working;
+    * `forward(pixel_values=...)` returns an object with `.last_hidden_state` (N,577,1024), taken before
+      post_layernorm exactly like the HF module the reference calls (models/clip_embedder.py:63);
+    * `embed(pixel_values)` returns the token mean directly (what both reference call sites compute next,
+      clip_embedder.py:64-65 / super_guessr.py:397-398) without materialising the hidden states.
+    The packed bf16 device copy (hip_ops.VitEncoder) is built lazily and rebuilt after any weight load.
+    """
+
+    def __init__(self, state_dict: Optional[Dict[str, Tensor]] = None, layers: int = synthetic.LAYERS,
+                 seed: Optional[int] = None, max_chunk: int = 0):
+        super().__init__()
+        if state_dict is None:
+            if seed is None:
+                raise ValueError("HipCLIPVisionModel needs a state_dict or an explicit seed for random init")
+            state_dict = synthetic.make_vit_weights(seed=seed, layers=layers)
+        sd = {}
+        for k, v in state_dict.items():
+            if not torch.is_tensor(v) or not v.is_floating_point():
+                continue
+            k = k[len("vision_model."):] if k.startswith("vision_model.") else k
+            sd[k] = v.detach().to("cpu", torch.float32).clone()
+        self._sd = sd
+        self.config = SimpleNamespace(hidden_size=1024, _name_or_path=CLIP_MODEL, num_hidden_layers=layers)
+        self._enc: Optional[hip_ops.VitEncoder] = None
+        self._enc_device = None
+        self._max_chunk = max_chunk
+        self._dummy = torch.nn.Parameter(torch.zeros(1), requires_grad=False)   # lets .to()/is_cuda work
+
+    # ---- nn.Module protocol over the plain weight dict ----
+    def state_dict(self, *args, prefix: str = "", **kwargs):
+        return {prefix + k: v for k, v in self._sd.items()}
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        load_state_dict(self, state_dict)
+        return SimpleNamespace(missing_keys=[], unexpected_keys=[])
+
+    def parameters(self, recurse: bool = True):
+        yield self._dummy
+
+    def _weights_changed(self):
+        if self._enc is not None:
+            self._enc.close()
+        self._enc = None
+
+    @property
+    def base_model(self):
+        return self                                      # HF: model.base_model is model for CLIPVisionModel
+
+    def _encoder(self, device: torch.device) -> hip_ops.VitEncoder:
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if self._enc is None or self._enc_device != idx:
+            if self._enc is not None:
+                self._enc.close()
+            self._enc = hip_ops.VitEncoder(self._sd, device=idx, max_chunk=self._max_chunk)
+            self._enc_device = idx
+        return self._enc
+
+    def embed(self, pixel_values: Tensor) -> Tensor:
+        pixel_values = _to_device_pixels(pixel_values, self._dummy.device)
+        return self._encoder(pixel_values.device).forward(pixel_values)
+
+    def forward(self, pixel_values: Tensor = None, **kwargs):
+        pixel_values = _to_device_pixels(pixel_values, self._dummy.device)
+        emb, hid = self._encoder(pixel_values.device).forward(pixel_values, return_hidden=True)
+        return SimpleNamespace(last_hidden_state=hid, pooler_output=None, token_mean=emb)
+
+
+def _to_device_pixels(pixel_values: Tensor, device) -> Tensor:
+    if not pixel_values.is_cuda:
+        dev = device if (isinstance(device, torch.device) and device.type == "cuda") else torch.device("cuda")
+        pixel_values = pixel_values.to(dev)
+    if pixel_values.dtype not in (torch.float32, torch.bfloat16):
+        pixel_values = pixel_values.float()
+    return pixel_values.contiguous()
+
+
+def clip_preprocess(images) -> Tensor:
+    """CLIPImageProcessor restated for PIL inputs (what `self.processor(images=...)` does at reference
+    models/clip_embedder.py:52): resize shortest edge to 336 (bicubic), centre crop 336x336, scale 1/255,
+    normalise with OPENAI_CLIP_MEAN/STD -> (N,3,336,336) fp32."""
+    from PIL import Image
+    if not isinstance(images, (list, tuple)):
+        images = [images]
+    out = []
+    mean = np.asarray(OPENAI_CLIP_MEAN, dtype=np.float32)[:, None, None]
+    std = np.asarray(OPENAI_CLIP_STD, dtype=np.float32)[:, None, None]
+    for im in images:
+        im = im.convert("RGB")
+        w, h = im.size
+        s = 336 / min(w, h)
+        nw, nh = max(336, int(round(w * s))), max(336, int(round(h * s)))
+        im = im.resize((nw, nh), resample=Image.BICUBIC)
+        left, top = (nw - 336) // 2, (nh - 336) // 2
+        im = im.crop((left, top, left + 336, top + 336))
+        a = np.asarray(im, dtype=np.float32).transpose(2, 0, 1) * (1.0 / 255.0)
+        out.append((a - mean) / std)
+    return torch.from_numpy(np.stack(out))
+
+
+class CLIPEmbedding(torch.nn.Module):
+    def __init__(self, model_name: str, device: str = 'cuda', load_checkpoint: bool = False,
+                 panorama: bool = False, state_dict: Optional[Dict[str, Tensor]] = None,
+                 clip_model: Optional[HipCLIPVisionModel] = None):
+        """CLIP embedding model (not trainable) -- reference models/clip_embedder.py:11-40.
+
+        Args follow the reference.  The reference pulls the base weights from the HuggingFace hub
+        (`CLIPVisionModel.from_pretrained(CLIP_MODEL)`, :26), which is impossible offline; the two extra keyword
+        arguments supply them instead: `state_dict` (transformers CLIPVisionModel names) or a ready
+        `clip_model`.  With `load_checkpoint=True`, `model_name` is a torch checkpoint copied over the weights by
+        name with the leading `base_model.` component stripped, exactly as :30-32 does.
+        """
+        super().__init__()
+        self.device = device
+        self.processor = clip_preprocess
+        if clip_model is not None:
+            self.clip_model = clip_model
+        elif state_dict is not None:
+            self.clip_model = HipCLIPVisionModel(state_dict)
+        elif load_checkpoint and os.path.exists(model_name):
+            ckpt = torch.load(model_name, map_location='cpu')
+            ckpt = {('.'.join(k.split('.')[1:]) if 'base_model' in k else k): v for k, v in ckpt.items()}
+            self.clip_model = HipCLIPVisionModel(ckpt)
+            load_checkpoint = False
+        else:
+            raise RuntimeError(
+                "CLIPEmbedding: no weights. The reference downloads openai/clip-vit-large-patch14-336 from the hub; "
+                "offline, pass state_dict=... / clip_model=... or a checkpoint path with load_checkpoint=True.")
+        self.panorama = panorama
+
+        if load_checkpoint:
+            sd = torch.load(model_name, map_location='cpu')
+            load_state_dict(self.clip_model.base_model, sd, embedder=True)
+            print('Loaded embedder from checkpoint:', model_name)
+
+        if type(device) == str:
+            self.clip_model = self.clip_model.to(self.device)
+        else:
+            self.clip_model = self.clip_model.cuda(self.device)
+        self.eval()
+
+    def _get_embedding(self, image) -> Tensor:
+        """reference models/clip_embedder.py:42-66"""
+        with torch.no_grad():
+            if isinstance(image, Tensor) == False:
+                pixel_values = self.processor(image)
+            else:
+                pixel_values = image
+            if type(self.device) == str:
+                pixel_values = pixel_values.to(self.device)
+            else:
+                pixel_values = pixel_values.cuda(self.device)
+            # last_hidden_state.mean(dim=1), fused in the library (token_mean kernel)
+            return self.clip_model.base_model.embed(pixel_values)
+
+    def _pre_embed_hook(self) -> Callable:
+        def hook(model, input, output):
+            self.pre_embed_outputs = output[0]
+        return hook
+
+    def forward(self, image) -> Tensor:
+        """reference models/clip_embedder.py:79-89"""
+        return self._get_embedding(image)

@@ -3,9 +3,9 @@
 // Replaces: transformers CLIPAttention.forward + eager_attention_forward (modeling_clip.py:259-335): per
 // (image, head) softmax(Q K^T / 8) V with the softmax in fp32 -- SURVEY.md section 2c row K5.
 //
-// Input is the fused QKV activation (n_img*577, 3072) bf16 exactly as the QKV GEMM writes it (token-major;
+// Input is the fused QKV activation (n_img*577, 3072) fp16/bf16 exactly as the QKV GEMM writes it (token-major;
 // a head's Q/K/V rows are 128-byte contiguous segments), with Q pre-multiplied by log2(e)/8 so the kernel
-// can use v_exp_f32 (2^x) directly.  Output (n_img*577, 1024) bf16, column = head*64 + d.
+// can use v_exp_f32 (2^x) directly.  Output (n_img*577, 1024) in the same 16-bit type, column = head*64 + d.
 //
 // Structure (gfx950, wave64):
 //   * block = 4 waves = 128 query rows of one (image, head); 5 blocks cover the 577 queries.  The 5 blocks of
@@ -68,6 +68,7 @@ __device__ __forceinline__ void att_store_tile(const StageRegs& st, char* ks, ch
     }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) char smem[2 * K_TILE_BYTES + 2 * VT_TILE_BYTES];
     char* ks0 = smem;
@@ -90,10 +91,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     const int qrow = q_first + lq;
     const int qr = qrow < VIT_TOKENS ? qrow : VIT_TOKENS - 1;
 
-    bf16x8 qf[4];
+    typename T::v8 qf[4];
 #pragma unroll
     for (int ksi = 0; ksi < 4; ++ksi)
-        qf[ksi] = *(const bf16x8*)(qkv + (base + qr) * QKV_LD + head * 64 + ksi * 16 + g * 8);
+        qf[ksi] = *(const typename T::v8*)(qkv + (base + qr) * QKV_LD + head * 64 + ksi * 16 + g * 8);
 
     f32x16 o[2];
 #pragma unroll
@@ -126,8 +127,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
                 for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
                 for (int ksi = 0; ksi < 4; ++ksi) {
-                    const bf16x8 kf = *(const bf16x8*)(ks + (kb * 32 + lq) * K_ROWB + kxoff[ksi]);
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ksi], s[kb], 0, 0, 0);
+                    const typename T::v8 kf = *(const typename T::v8*)(ks + (kb * 32 + lq) * K_ROWB + kxoff[ksi]);
+                    s[kb] = T::mfma(kf, qf[ksi], s[kb]);
                 }
             }
             if (t == ATT_NT - 1) {
@@ -171,16 +172,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
                 for (int s2 = 0; s2 < 2; ++s2) {
                     u32x4 pw;
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) pw[w] = pack_bf16x2(s[kb][8 * s2 + 2 * w], s[kb][8 * s2 + 2 * w + 1]);
-                    const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+                    for (int w = 0; w < 4; ++w) pw[w] = pack16x2<T>(s[kb][8 * s2 + 2 * w], s[kb][8 * s2 + 2 * w + 1]);
+                    const typename T::v8 pf = __builtin_bit_cast(typename T::v8, pw);
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
                         const char* vrow = vt + (db * 32 + lq) * VT_STRIDE + (kb * 32 + 16 * s2 + 4 * g) * 2;
                         const u32x2 lo = *(const u32x2*)(vrow);        // keys +0..3
                         const u32x2 hi = *(const u32x2*)(vrow + 16);   // keys +8..11
                         u32x4 vw; vw[0] = lo[0]; vw[1] = lo[1]; vw[2] = hi[0]; vw[3] = hi[1];
-                        const bf16x8 vf = __builtin_bit_cast(bf16x8, vw);
-                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+                        const typename T::v8 vf = __builtin_bit_cast(typename T::v8, vw);
+                        o[db] = T::mfma(vf, pf, o[db]);
                     }
                 }
             }
@@ -200,18 +201,21 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     u32x2 pk;
-                    pk[0] = pack_bf16x2(o[db][4 * q4] * inv, o[db][4 * q4 + 1] * inv);
-                    pk[1] = pack_bf16x2(o[db][4 * q4 + 2] * inv, o[db][4 * q4 + 3] * inv);
+                    pk[0] = pack16x2<T>(o[db][4 * q4] * inv, o[db][4 * q4 + 1] * inv);
+                    pk[1] = pack16x2<T>(o[db][4 * q4 + 2] * inv, o[db][4 * q4 + 3] * inv);
                     *(u32x2*)(orow + db * 32 + 8 * q4 + 4 * g) = pk;
                 }
         }
     }
 }
 
-int pg_attention_launch(const void* qkv, void* out, int n_images, hipStream_t s) {
+int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hipStream_t s) {
     if (n_images <= 0) return PG_OK;
     const int pairs = n_images * VIT_HEADS;                  // always a multiple of 8
-    hipLaunchKernelGGL(attention_kernel, dim3(pairs * ATT_NQB), dim3(256), 0, s,
-                       (const uint16_t*)qkv, (uint16_t*)out);
+    if (dtype == PG_DTYPE_F16)
+        hipLaunchKernelGGL(attention_kernel<T_F16>, dim3(pairs * ATT_NQB), dim3(256), 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+    else if (dtype == PG_DTYPE_BF16)
+        hipLaunchKernelGGL(attention_kernel<T_BF16>, dim3(pairs * ATT_NQB), dim3(256), 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+    else { pg_set_error("attention: dtype must be PG_DTYPE_F16 or PG_DTYPE_BF16"); return PG_EINVAL; }
     return pg_check_launch("attention");
 }

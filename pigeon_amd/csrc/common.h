@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;   // one MFMA A/B fragment: 8 bf16 = 4 VGPRs
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;   // same, fp16
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;   // 32x32 MFMA accumulator
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -35,6 +36,38 @@ __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
 }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
+    f = fminf(fmaxf(f, -65504.f), 65504.f);              // saturate instead of overflowing to inf
+    return __builtin_bit_cast(uint16_t, (_Float16)f);     // v_cvt_f16_f32, round to nearest even
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+
+// The two 16-bit operand formats the MFMA path can run in (same MFMA rate on gfx950).  fp16 is the default:
+// its 11-bit significand keeps the embedding within 1e-3 of the fp32 reference; bf16 (8 bits) measures 2e-3,
+// dominated by WEIGHT rounding, which is coherent across tokens and survives the token mean.
+struct T_BF16 {
+    typedef bf16x8 v8;
+    static constexpr int id = 1;
+    static __device__ __forceinline__ uint16_t bits(float f) { return f32_to_bf16_bits(f); }
+    static __device__ __forceinline__ float val(uint16_t b) { return bf16_bits_to_f32(b); }
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+struct T_F16 {
+    typedef f16x8 v8;
+    static constexpr int id = 2;
+    static __device__ __forceinline__ uint16_t bits(float f) { return f32_to_f16_bits(f); }
+    static __device__ __forceinline__ float val(uint16_t b) { return f16_bits_to_f32(b); }
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <typename T>
+__device__ __forceinline__ uint32_t pack16x2(float lo, float hi) {
+    return (uint32_t)T::bits(lo) | ((uint32_t)T::bits(hi) << 16);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

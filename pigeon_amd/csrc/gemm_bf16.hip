@@ -1,11 +1,12 @@
-// gemm_bf16.hip -- C[M,N] = A[M,K] * W[N,K]^T, bf16 operands, fp32 accumulation on MFMA, fused epilogues.
+// gemm_bf16.hip -- C[M,N] = A[M,K] * W[N,K]^T, 16-bit (fp16 or bf16) operands, fp32 accumulation on MFMA,
+// fused epilogues.
 //
 // Replaces the nn.Linear / Conv2d library GEMMs the reference reaches through transformers
 // (modeling_clip.py CLIPAttention.q/k/v/out_proj, CLIPMLP.fc1/fc2, CLIPVisionEmbeddings.patch_embedding),
 // SURVEY.md section 2c rows K1,K4,K6,K7,K8 = 91% of the path's FLOPs.
 //
 // Design (gfx950 / CDNA4, wave64):
-//   * v_mfma_f32_32x32x16_bf16; both operands are K-contiguous in memory ([M,K] activations, [N,K] weights as
+//   * v_mfma_f32_32x32x16_{f16,bf16}; both operands are K-contiguous in memory ([M,K] activations, [N,K] weights as
 //     nn.Linear stores them) so a lane's fragment is one 16-byte ds_read_b128.
 //   * K tile BK = 64 (128-byte rows in LDS).  Tiles are staged global->LDS with the direct-to-LDS DMA
 //     (global_load_lds_dwordx4: 64 lanes x 16 B = 8 rows per wave instruction), no VGPR round trip.
@@ -33,7 +34,8 @@ struct GemmArgs {
     int M, N, K;
     float qscale; int qcols;
     const float* aux;             // epi 3: position embedding [577][N]
-    int tilesN, ntiles;
+    int tilesM, tilesN, ntiles;
+    int gn;                       // N tiles per raster group (see tile_coords)
 };
 
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_base_uniform) {
@@ -61,8 +63,8 @@ __device__ __forceinline__ void epi_store_f32x4(const GemmArgs& g, int row, int 
     }
 }
 
-// bf16-out epilogues on 8 consecutive columns.
-template <int EPI>
+// 16-bit-out epilogues on 8 consecutive columns.
+template <typename T, int EPI>
 __device__ __forceinline__ void epi_store_bf16x8(const GemmArgs& g, int row, int col, f32x4 lo, f32x4 hi,
                                                  const f32x4& b_lo, const f32x4& b_hi) {
     lo += b_lo; hi += b_hi;
@@ -73,20 +75,20 @@ __device__ __forceinline__ void epi_store_bf16x8(const GemmArgs& g, int row, int
         for (int e = 0; e < 4; ++e) { lo[e] = quick_gelu(lo[e]); hi[e] = quick_gelu(hi[e]); }
     }
     u32x4 pk;
-    pk[0] = pack_bf16x2(lo[0], lo[1]); pk[1] = pack_bf16x2(lo[2], lo[3]);
-    pk[2] = pack_bf16x2(hi[0], hi[1]); pk[3] = pack_bf16x2(hi[2], hi[3]);
+    pk[0] = pack16x2<T>(lo[0], lo[1]); pk[1] = pack16x2<T>(lo[2], lo[3]);
+    pk[2] = pack16x2<T>(hi[0], hi[1]); pk[3] = pack16x2<T>(hi[2], hi[3]);
     *(u32x4*)((uint16_t*)g.out + (int64_t)row * g.ldc + col) = pk;
 }
 
-template <int EPI>
+template <typename T, int EPI>
 __device__ __forceinline__ void epi_store_scalar(const GemmArgs& g, int row, int col, float v) {
     if (EPI == EPI_QKV) {
         if (g.bias) v += g.bias[col];
         if (col < g.qcols) v *= g.qscale;
-        ((uint16_t*)g.out)[(int64_t)row * g.ldc + col] = f32_to_bf16_bits(v);
+        ((uint16_t*)g.out)[(int64_t)row * g.ldc + col] = T::bits(v);
     } else if (EPI == EPI_GELU) {
         v = quick_gelu(v + g.bias[col]);
-        ((uint16_t*)g.out)[(int64_t)row * g.ldc + col] = f32_to_bf16_bits(v);
+        ((uint16_t*)g.out)[(int64_t)row * g.ldc + col] = T::bits(v);
     } else if (EPI == EPI_RESID) {
         float* p = (float*)g.out + (int64_t)row * g.ldc + col;
         *p = *p + (v + g.bias[col]);
@@ -100,8 +102,139 @@ __device__ __forceinline__ void epi_store_scalar(const GemmArgs& g, int row, int
     }
 }
 
-// BM x BN block tile, WM x WN waves, each wave owns (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 32x32.
-template <int BM, int BN, int WM, int WN, int EPI, bool DIRECT>
+// Tile rasterisation.  Blocks are first remapped so every XCD owns a contiguous chunk of logical ids (hardware
+// places block b on XCD b % 8), then logical ids walk the tile grid in groups of `gn` N-tiles: inside a group
+// the N index runs fastest, then M, then the next group.  The gn weight panels of a group (gn x 256 x K) stay
+// resident in the XCD's 4 MB L2 while the XCD walks down its rows; an A row-panel is fetched from HBM/MALL once
+// per group and shared by the gn blocks that run side by side.
+__device__ __forceinline__ void tile_coords(const GemmArgs& g, int& tm, int& tn) {
+    const int wg = xcd_remap(blockIdx.x, g.ntiles);
+    const int gsz = g.tilesM * g.gn;
+    const int grp = wg / gsz, rem = wg - grp * gsz;
+    const int gn_here = min(g.gn, g.tilesN - grp * g.gn);
+    tm = rem / gn_here;
+    tn = grp * g.gn + (rem - tm * gn_here);
+}
+
+// ---- LDS-staged epilogue: per wave, one 32 x WTN fp32 slab at a time -------------------------------------------
+// The accumulators hold D[n][m] (operands swapped), i.e. lane owns row m = lane&31 and 4-column quads.  Each wave
+// parks a 32-row slab in its private LDS region, then re-reads it row-major so that a lane stores 16 contiguous
+// bytes (8 x 16-bit or 4 x fp32) and a wave instruction covers whole 128/256-byte row segments.
+template <typename T, int EPI, int TM, int TN, int WTM, int WTN>
+__device__ __forceinline__ void staged_epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& g, char* smem, int wave, int lane,
+                                                int row0 /* first row of this wave's tile */, int col0) {
+    constexpr bool OUT16 = (EPI == EPI_QKV || EPI == EPI_GELU);
+    constexpr int ROWPF = WTN + 4;                           // padded slab row, floats (272 B for WTN=64)
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    float* slab = (float*)(smem + wave * (32 * ROWPF * 4));
+    __syncthreads();                                         // every wave is done with the K-loop buffers
+    constexpr int CPL = OUT16 ? 8 : 4;                       // columns per lane on the row-major side
+    constexpr int LPR = WTN / CPL, RPI = 64 / LPR, ITS = 32 / RPI;
+    const int rr = lane / LPR, cc = (lane % LPR) * CPL;
+    const int col = col0 + cc;
+    f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) {
+        b_lo = *(const f32x4*)(g.bias + col);
+        if (OUT16) b_hi = *(const f32x4*)(g.bias + col + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                *(f32x4*)(slab + lrow * ROWPF + j * 32 + q * 8 + 4 * lhalf) = v;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+            const int r = it * RPI + rr;
+            const int row = row0 + i * 32 + r;
+            const f32x4 lo = *(const f32x4*)(slab + r * ROWPF + cc);
+            if (OUT16) {
+                const f32x4 hi = *(const f32x4*)(slab + r * ROWPF + cc + 4);
+                if (row < g.M) epi_store_bf16x8<T, EPI>(g, row, col, lo, hi, b_lo, b_hi);
+            } else {
+                if (row < g.M) epi_store_f32x4<EPI>(g, row, col, lo, b_lo);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// One K tile (BK = 64 = 4 k-steps of 16) of MFMAs for a wave's TM x TN tiles, fragments software-pipelined:
+// the ds_reads of k-step kk+1 are issued before the MFMAs of kk.  a_ptr / b_ptr already include the lane's row.
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void mma_ktile(f32x16 (&acc)[TM][TN], const char* a_ptr, const char* b_ptr, const int (&xoff)[4]) {
+    typename T::v8 af[2][TM], bfr[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = *(const typename T::v8*)(a_ptr + i * 32 * ROWB + xoff[0]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bfr[0][j] = *(const typename T::v8*)(b_ptr + j * 32 * ROWB + xoff[0]);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[(kk + 1) & 1][i] = *(const typename T::v8*)(a_ptr + i * 32 * ROWB + xoff[kk < 3 ? kk + 1 : 3]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[(kk + 1) & 1][j] = *(const typename T::v8*)(b_ptr + j * 32 * ROWB + xoff[kk < 3 ? kk + 1 : 3]);
+        }
+        __builtin_amdgcn_s_setprio(1);
+        // swapped operands: D[n][m] -> lane owns row m = lane&31, columns n = (r&3)+8*(r>>2)+4*(lane>>5)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = T::mfma(bfr[kk & 1][j], af[kk & 1][i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// Same K tile, but the next tile's direct-to-LDS DMAs are issued in NDMA/4-sized slices between the k-steps
+// instead of all at once after the barrier: a DMA issue can stall its wave for 100+ cycles when the vector-memory
+// queue is backed up, and spreading them lets the other wave of the SIMD keep the matrix pipe busy meanwhile.
+template <typename T, int TM, int TN, int NDMA>
+__device__ __forceinline__ void mma_ktile_dma(f32x16 (&acc)[TM][TN], const char* a_ptr, const char* b_ptr, const int (&xoff)[4],
+                                              const uint16_t* const (&src)[NDMA], const int (&ldsoff)[NDMA], char* nxt,
+                                              int64_t koff, bool do_dma) {
+    static_assert(NDMA % 4 == 0, "DMA count must split over the 4 k-steps");
+    constexpr int PER = NDMA / 4;
+    typename T::v8 af[2][TM], bfr[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = *(const typename T::v8*)(a_ptr + i * 32 * ROWB + xoff[0]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bfr[0][j] = *(const typename T::v8*)(b_ptr + j * 32 * ROWB + xoff[0]);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[(kk + 1) & 1][i] = *(const typename T::v8*)(a_ptr + i * 32 * ROWB + xoff[kk < 3 ? kk + 1 : 3]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[(kk + 1) & 1][j] = *(const typename T::v8*)(b_ptr + j * 32 * ROWB + xoff[kk < 3 ? kk + 1 : 3]);
+        }
+        if (do_dma) {
+#pragma unroll
+            for (int d = 0; d < PER; ++d) glds16(src[kk * PER + d] + koff, nxt + ldsoff[kk * PER + d]);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = T::mfma(bfr[kk & 1][j], af[kk & 1][i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// ================================================================================================================
+// Kernel A: BM x BN block tile, WM x WN waves, 2 LDS stages of (A|W), one __syncthreads per K tile.
+// ================================================================================================================
+template <typename T, int BM, int BN, int WM, int WN, int EPI, bool DIRECT, bool PIPE, int DBG = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmArgs g) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -111,7 +244,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmArgs g) {
     constexpr int LPW = GROUPS / NW;             // DMA instructions per wave per stage
     static_assert(GROUPS % NW == 0, "stage must split evenly over waves");
     static_assert(BM % 16 == 0 && BN % 16 == 0, "tile alignment");
-    constexpr bool BF16_OUT = (EPI == EPI_QKV || EPI == EPI_GELU);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -120,8 +252,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    const int wg = xcd_remap(blockIdx.x, g.ntiles);
-    const int tm = wg / g.tilesN, tn = wg - tm * g.tilesN;
+    int tm, tn;
+    tile_coords(g, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- per-lane DMA source pointers (advance by BK elements per K tile) ----
@@ -173,27 +305,46 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmArgs g) {
         // and every wave is done reading the buffer tile t+1 is about to overwrite.
         __syncthreads();
         const int cur = t & 1;
-        if (t + 1 < nt) {
+        if constexpr ((DBG & 4) != 0) {                 // DMA of tile t+1 interleaved with the k-steps of tile t
+            mma_ktile_dma<T, TM, TN, LPW>(acc, smem + cur * STAGE + a_base, smem + cur * STAGE + b_base, xoff, src, ldsoff,
+                                          smem + (cur ^ 1) * STAGE, (int64_t)(t + 1) * BK, t + 1 < nt);
+            continue;
+        }
+        if (t + 1 < nt && !(DBG & 1)) {                 // DBG&1: ablation -- no DMA inside the loop (results are garbage)
             char* nxt = smem + (cur ^ 1) * STAGE;
 #pragma unroll
             for (int i = 0; i < LPW; ++i) glds16(src[i] + (int64_t)(t + 1) * BK, nxt + ldsoff[i]);
         }
         const char* sb = smem + cur * STAGE;
+        if (DBG & 2) {                                   // DBG&2: ablation -- MFMAs only, no ds_reads in the loop
+            typename T::v8 f = *(const typename T::v8*)(smem + a_base);
+            asm volatile("" : "+v"(f));
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = T::mfma(f, f, acc[i][j]);
+            continue;
+        }
+        if (PIPE) {
+            mma_ktile<T, TM, TN>(acc, sb + a_base, sb + b_base, xoff);
+            continue;
+        }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 af[TM], bfr[TN];
+            typename T::v8 af[TM], bfr[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i] = *(const bf16x8*)(sb + a_base + i * 32 * ROWB + xoff[kk]);
+                af[i] = *(const typename T::v8*)(sb + a_base + i * 32 * ROWB + xoff[kk]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bfr[j] = *(const bf16x8*)(sb + b_base + j * 32 * ROWB + xoff[kk]);
-            // swapped operands: D[n][m] -> lane owns row m = lane&31, columns n = (r&3)+8*(r>>2)+4*(lane>>5)
+                bfr[j] = *(const typename T::v8*)(sb + b_base + j * 32 * ROWB + xoff[kk]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = T::mfma(bfr[j], af[i], acc[i][j]);
         }
     }
 
@@ -207,119 +358,195 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int col = n0 + wn * WTN + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                    if (row < g.M) epi_store_scalar<EPI>(g, row, col, acc[i][j][r]);
+                    if (row < g.M) epi_store_scalar<T, EPI>(g, row, col, acc[i][j][r]);
                 }
         }
         return;
     }
-
-    // ---- LDS-staged epilogue: per wave, one 32 x WTN fp32 slab at a time ----
-    constexpr int ROWPF = WTN + 4;                           // padded slab row, floats (272 B for WTN=64)
-    float* slab = (float*)(smem + wave * (32 * ROWPF * 4));
-    __syncthreads();                                         // every wave is done with the K-loop buffers
-    if (BF16_OUT) {
-        constexpr int LPR = WTN / 8, RPI = 64 / LPR, ITS = 32 / RPI;
-        const int rr = lane / LPR, cc = (lane % LPR) * 8;
-        const int col = n0 + wn * WTN + cc;
-        f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = {0.f, 0.f, 0.f, 0.f};
-        if (g.bias) { b_lo = *(const f32x4*)(g.bias + col); b_hi = *(const f32x4*)(g.bias + col + 4); }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                    *(f32x4*)(slab + lrow * ROWPF + j * 32 + q * 8 + 4 * lhalf) = v;
-                }
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < ITS; ++it) {
-                const int r = it * RPI + rr;
-                const f32x4 lo = *(const f32x4*)(slab + r * ROWPF + cc);
-                const f32x4 hi = *(const f32x4*)(slab + r * ROWPF + cc + 4);
-                const int row = m0 + wm * WTM + i * 32 + r;
-                if (row < g.M) epi_store_bf16x8<EPI>(g, row, col, lo, hi, b_lo, b_hi);
-            }
-            __syncthreads();
-        }
-    } else {
-        constexpr int LPR = WTN / 4, RPI = 64 / LPR, ITS = 32 / RPI;
-        const int rr = lane / LPR, cc = (lane % LPR) * 4;
-        const int col = n0 + wn * WTN + cc;
-        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-        if (g.bias) b4 = *(const f32x4*)(g.bias + col);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                    *(f32x4*)(slab + lrow * ROWPF + j * 32 + q * 8 + 4 * lhalf) = v;
-                }
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < ITS; ++it) {
-                const int r = it * RPI + rr;
-                const f32x4 v = *(const f32x4*)(slab + r * ROWPF + cc);
-                const int row = m0 + wm * WTM + i * 32 + r;
-                if (row < g.M) epi_store_f32x4<EPI>(g, row, col, v, b4);
-            }
-            __syncthreads();
-        }
-    }
+    staged_epilogue<T, EPI, TM, TN, WTM, WTN>(acc, g, smem, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
 }
 
-template <int BM, int BN, int WM, int WN, bool DIRECT>
+// ================================================================================================================
+// Kernel B ("a3w2"): 256 x 256 tile, 8 waves (2 x 4), the whole 160 KB of LDS:
+//     A ring  3 x 32 KB  -- activations stream from HBM/MALL (every A line is a compulsory miss for the first of
+//                           the gn blocks that share it), so A is prefetched TWO K tiles ahead;
+//     W ring  2 x 32 KB  -- weights hit the XCD's L2 (see tile_coords), one tile of lookahead is enough.
+// vmcnt retires in issue order, so each iteration issues W(t+1) BEFORE A(t+2): at the top of iteration t the
+// queue is [A(t) W(t) | A(t+1)] and `s_waitcnt vmcnt(4)` (this wave's 4 newest DMAs may stay in flight) is exactly
+// "A(t) and W(t) have landed".  Raw s_barrier + counted waits: a __syncthreads() would drain vmcnt to 0.
+// ================================================================================================================
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm16_a3w2_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, WN = 4, NW = 8, WTM = 128, WTN = 64, TM = 4, TN = 2;
+    constexpr int ASTG = BM * ROWB, WSTG = BN * ROWB;                 // 32 KB each
+    constexpr int W_OFF = 3 * ASTG;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int tm, tn;
+    tile_coords(g, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const uint16_t* srcA[4];
+    const uint16_t* srcW[4];
+    int ldsoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int grp = wave + i * NW;                                // 8-row group 0..31 inside a 256-row stage
+        const int r = grp * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int row = m0 + r;
+        row = row < g.M ? row : g.M - 1;
+        srcA[i] = g.A + (int64_t)row * g.lda + c * 8;
+        srcW[i] = g.W + (int64_t)(n0 + r) * g.K + c * 8;
+        ldsoff[i] = grp * 8 * ROWB;
+    }
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int sw = (lane >> 1) & 7;
+    int xoff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) xoff[kk] = ((kk * 2 + lhalf) ^ sw) << 4;
+    const int a_base = (wm * WTM + lrow) * ROWB;
+    const int b_base = W_OFF + (wn * WTN + lrow) * ROWB;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nt = g.K / BK;
+    // prologue: A(0), W(0), A(1)  (same relative order as the steady state)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(srcA[i], smem + ldsoff[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(srcW[i], smem + W_OFF + ldsoff[i]);
+    if (nt > 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(srcA[i] + BK, smem + ASTG + ldsoff[i]);
+    }
+
+    int a_slot = 0;                                                   // t % 3
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                 // tile t visible to all; slots of t-1 are free
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < nt) {
+            char* wn_ = smem + W_OFF + ((t + 1) & 1) * WSTG;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16(srcW[i] + (int64_t)(t + 1) * BK, wn_ + ldsoff[i]);
+        }
+        if (t + 2 < nt) {
+            const int s2 = a_slot == 0 ? 2 : a_slot - 1;              // (t + 2) % 3
+            char* an_ = smem + s2 * ASTG;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16(srcA[i] + (int64_t)(t + 2) * BK, an_ + ldsoff[i]);
+        }
+        mma_ktile<T, TM, TN>(acc, smem + a_slot * ASTG + a_base, smem + (t & 1) * WSTG + b_base, xoff);
+        a_slot = a_slot == 2 ? 0 : a_slot + 1;
+    }
+    staged_epilogue<T, EPI, TM, TN, WTM, WTN>(acc, g, smem, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
+}
+
+template <typename KFN>
+static int launch_kernel(KFN kfn, bool& attr_set, size_t lds, dim3 grid, dim3 block, const GemmArgs& g, hipStream_t s) {
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { pg_set_error("gemm: set LDS attr (%zu B): %s", lds, hipGetErrorString(e)); return PG_EHIP; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, grid, block, lds, s, g);
+    return pg_check_launch("gemm16");
+}
+
+static int finish_args(GemmArgs& g, int BM, int BN) {
+    if (g.N % BN != 0 || g.K % BK != 0) { pg_set_error("gemm: N %% %d or K %% 64 != 0 (N=%d K=%d)", BN, g.N, g.K); return PG_EINVAL; }
+    g.tilesM = (g.M + BM - 1) / BM;
+    g.tilesN = g.N / BN;
+    g.ntiles = g.tilesM * g.tilesN;
+    if (g.gn <= 0) g.gn = 4;
+    if (g.gn > g.tilesN) g.gn = g.tilesN;
+    return PG_OK;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool DIRECT, bool PIPE, int DBG = 0>
 static int launch_cfg(const GemmArgs& g0, int epi, hipStream_t s) {
     GemmArgs g = g0;
-    if (g.N % BN != 0 || g.K % BK != 0) { pg_set_error("gemm: N %% %d or K %% 64 != 0 (N=%d K=%d)", BN, g.N, g.K); return PG_EINVAL; }
-    const int tilesM = (g.M + BM - 1) / BM;
-    g.tilesN = g.N / BN;
-    g.ntiles = tilesM * g.tilesN;
+    int rc = finish_args(g, BM, BN);
+    if (rc) return rc;
     const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
     dim3 grid(g.ntiles), block(WM * WN * 64);
-#define PG_LAUNCH(E)                                                                                    \
-    {                                                                                                   \
-        auto kfn = gemm_bf16_kernel<BM, BN, WM, WN, E, DIRECT>;                                         \
-        static bool attr_set = false;                                                                   \
-        if (!attr_set) {                                                                                \
-            hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) { pg_set_error("gemm: set LDS attr: %s", hipGetErrorString(e)); return PG_EHIP; } \
-            attr_set = true;                                                                            \
-        }                                                                                               \
-        hipLaunchKernelGGL(kfn, grid, block, lds, s, g);                                                \
-    }
+#define PG_LAUNCH(E) { static bool a = false; return launch_kernel(gemm_bf16_kernel<T, BM, BN, WM, WN, E, DIRECT, PIPE, DBG>, a, lds, grid, block, g, s); }
     switch (epi) {
-        case EPI_QKV: PG_LAUNCH(EPI_QKV) break;
-        case EPI_GELU: PG_LAUNCH(EPI_GELU) break;
-        case EPI_RESID: PG_LAUNCH(EPI_RESID) break;
-        case EPI_PATCH: PG_LAUNCH(EPI_PATCH) break;
-        case EPI_F32: PG_LAUNCH(EPI_F32) break;
+        case EPI_QKV: PG_LAUNCH(EPI_QKV)
+        case EPI_GELU: PG_LAUNCH(EPI_GELU)
+        case EPI_RESID: PG_LAUNCH(EPI_RESID)
+        case EPI_PATCH: PG_LAUNCH(EPI_PATCH)
+        case EPI_F32: PG_LAUNCH(EPI_F32)
         default: pg_set_error("gemm: bad epilogue %d", epi); return PG_EINVAL;
     }
 #undef PG_LAUNCH
-    return pg_check_launch("gemm_bf16");
 }
 
-int pg_gemm_launch(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
+template <typename T>
+static int launch_a3w2(const GemmArgs& g0, int epi, hipStream_t s) {
+    GemmArgs g = g0;
+    int rc = finish_args(g, 256, 256);
+    if (rc) return rc;
+    const size_t lds = 5 * 256 * ROWB;                               // 160 KB: the whole LDS of a CU
+    dim3 grid(g.ntiles), block(512);
+#define PG_LAUNCH(E) { static bool a = false; return launch_kernel(gemm16_a3w2_kernel<T, E>, a, lds, grid, block, g, s); }
+    switch (epi) {
+        case EPI_QKV: PG_LAUNCH(EPI_QKV)
+        case EPI_GELU: PG_LAUNCH(EPI_GELU)
+        case EPI_RESID: PG_LAUNCH(EPI_RESID)
+        case EPI_PATCH: PG_LAUNCH(EPI_PATCH)
+        case EPI_F32: PG_LAUNCH(EPI_F32)
+        default: pg_set_error("gemm: bad epilogue %d", epi); return PG_EINVAL;
+    }
+#undef PG_LAUNCH
+}
+
+template <typename T>
+static int gemm_dispatch(GemmArgs& g, int epi, int variant, hipStream_t s) {
+    switch (variant) {
+        case 1: return launch_cfg<T, 256, 256, 2, 4, false, false>(g, epi, s);
+        case 2: return launch_cfg<T, 128, 128, 2, 2, false, true>(g, epi, s);
+        case 3: return launch_cfg<T, 256, 128, 4, 2, false, true>(g, epi, s);
+        case 4: return launch_cfg<T, 256, 256, 2, 4, false, true>(g, epi, s);
+        case 5: return launch_a3w2<T>(g, epi, s);
+        case 6: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true>(g, epi, s);   // variant 4, N-fastest raster
+        case 7: g.gn = 1 << 20; return launch_a3w2<T>(g, epi, s);                                  // variant 5, N-fastest raster
+        case 11: return launch_cfg<T, 256, 256, 2, 4, true, false>(g, epi, s);
+        // ablations of variant 6 (timing only, wrong results): 21 no in-loop DMA, 22 no ds_reads, 23 neither
+        case 8: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true, 4>(g, epi, s);   // variant 6 + interleaved DMA
+        case 21: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true, 1>(g, epi, s);
+        case 22: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true, 2>(g, epi, s);
+        case 23: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true, 3>(g, epi, s);
+        default: pg_set_error("gemm: unknown variant %d", variant); return PG_EINVAL;
+    }
+}
+
+int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
                    int M, int N, int K, int epi, float qscale, int qcols, const float* aux, int variant,
                    hipStream_t s) {
     if (M <= 0) return PG_OK;
     GemmArgs g;
     g.A = (const uint16_t*)A; g.lda = lda; g.W = (const uint16_t*)W; g.bias = bias; g.out = out; g.ldc = ldc;
-    g.M = M; g.N = N; g.K = K; g.qscale = qscale; g.qcols = qcols; g.aux = aux; g.tilesN = 0; g.ntiles = 0;
+    g.M = M; g.N = N; g.K = K; g.qscale = qscale; g.qcols = qcols; g.aux = aux;
+    g.tilesM = 0; g.tilesN = 0; g.ntiles = 0; g.gn = 0;
     if ((epi == EPI_GELU || epi == EPI_RESID) && !bias) { pg_set_error("gemm: epilogue %d needs a bias", epi); return PG_EINVAL; }
     if (epi == EPI_PATCH && !aux) { pg_set_error("gemm: patch epilogue needs aux"); return PG_EINVAL; }
     if ((lda % 8) || (ldc % 8) || (qcols % 8)) { pg_set_error("gemm: lda/ldc/qcols must be multiples of 8"); return PG_EINVAL; }
     if (variant == 0) variant = pg_default_gemm_variant();
-    switch (variant) {
-        case 1: return launch_cfg<256, 256, 2, 4, false>(g, epi, s);
-        case 2: return launch_cfg<128, 128, 2, 2, false>(g, epi, s);
-        case 3: return launch_cfg<256, 128, 4, 2, false>(g, epi, s);
-        case 11: return launch_cfg<256, 256, 2, 4, true>(g, epi, s);
-        case 12: return launch_cfg<128, 128, 2, 2, true>(g, epi, s);
-        default: pg_set_error("gemm: unknown variant %d", variant); return PG_EINVAL;
-    }
+    if (dtype == PG_DTYPE_F16) return gemm_dispatch<T_F16>(g, epi, variant, s);
+    if (dtype == PG_DTYPE_BF16) return gemm_dispatch<T_BF16>(g, epi, variant, s);
+    pg_set_error("gemm: operand dtype must be PG_DTYPE_F16 or PG_DTYPE_BF16 (got %d)", dtype);
+    return PG_EINVAL;
 }

@@ -20,16 +20,16 @@ int pg_default_gemm_variant();                   // env PIGEON_GEMM_VARIANT or t
     } while (0)
 
 // gemm_bf16.hip
-int pg_gemm_launch(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
+int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
                    int M, int N, int K, int epi, float qscale, int qcols, const float* aux, int variant,
                    hipStream_t s);
 // rowops.hip
-int pg_layernorm_launch(const float* x, const float* gamma, const float* beta, void* y, int out_bf16,
+int pg_layernorm_launch(const float* x, const float* gamma, const float* beta, void* y, int out_dtype,
                         int64_t rows, float eps, hipStream_t s);
 int pg_preln_launch(float* x, const float* cls, const float* pos0, const float* gamma, const float* beta,
                     int64_t rows, float eps, hipStream_t s);
-int pg_im2col_launch(const void* pixels, int pix_dtype, void* out, int n_images, hipStream_t s);
+int pg_im2col_launch(const void* pixels, int pix_dtype, void* out, int out_dtype, int n_images, hipStream_t s);
 int pg_token_mean_launch(const float* x, float* out, int n_images, hipStream_t s);
-int pg_f32_to_bf16_launch(const float* x, void* y, int64_t n, hipStream_t s);
+int pg_cast_f32_launch(const float* x, void* y, int out_dtype, int64_t n, hipStream_t s);
 // attention.hip
-int pg_attention_launch(const void* qkv, void* out, int n_images, hipStream_t s);
+int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hipStream_t s);

@@ -12,7 +12,7 @@
 #include "pigeon_internal.h"
 
 // ---- LayerNorm over 1024 columns; one wave per row, 4 rows per 256-thread block ----------------------
-template <bool OUT_BF16>
+template <int OUT>   // 0 fp32, else T id (1 bf16, 2 fp16)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, void* __restrict__ y,
                                                         int64_t rows, float eps) {
@@ -42,10 +42,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
-        if (OUT_BF16) {
+        if (OUT != 0) {
             u32x2 pk;
-            pk[0] = pack_bf16x2(o[0], o[1]);
-            pk[1] = pack_bf16x2(o[2], o[3]);
+            if (OUT == 1) { pk[0] = pack16x2<T_BF16>(o[0], o[1]); pk[1] = pack16x2<T_BF16>(o[2], o[3]); }
+            else { pk[0] = pack16x2<T_F16>(o[0], o[1]); pk[1] = pack16x2<T_F16>(o[2], o[3]); }
             *(u32x2*)((uint16_t*)y + row * VIT_HIDDEN + c) = pk;
         } else {
             *(f32x4*)((float*)y + row * VIT_HIDDEN + c) = o;
@@ -53,12 +53,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
-int pg_layernorm_launch(const float* x, const float* gamma, const float* beta, void* y, int out_bf16,
+int pg_layernorm_launch(const float* x, const float* gamma, const float* beta, void* y, int out_dtype,
                         int64_t rows, float eps, hipStream_t s) {
     if (rows <= 0) return PG_OK;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-    if (out_bf16) hipLaunchKernelGGL(layernorm_kernel<true>, grid, block, 0, s, x, gamma, beta, y, rows, eps);
-    else hipLaunchKernelGGL(layernorm_kernel<false>, grid, block, 0, s, x, gamma, beta, y, rows, eps);
+    if (out_dtype == PG_DTYPE_BF16) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y, rows, eps);
+    else if (out_dtype == PG_DTYPE_F16) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, gamma, beta, y, rows, eps);
+    else if (out_dtype == PG_DTYPE_F32) hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, s, x, gamma, beta, y, rows, eps);
+    else { pg_set_error("layernorm: bad output dtype %d", out_dtype); return PG_EINVAL; }
     return pg_check_launch("layernorm");
 }
 
@@ -116,7 +118,7 @@ int pg_preln_launch(float* x, const float* cls, const float* pos0, const float* 
 // 336 contiguous pixels: reads are fully coalesced; every pixel lands at
 //   out[(img*576 + py*24 + px)*640 + c*196 + ky*14 + kx]   (k order == Conv2d weight [1024,3,14,14] flattened)
 // Columns 588..639 are zero so the GEMM can run K = 640 = 10 x 64.
-template <typename PIX>
+template <typename PIX, typename T>
 __global__ __launch_bounds__(256) void im2col_kernel(const PIX* __restrict__ pix, uint16_t* __restrict__ out) {
     const int img = blockIdx.x / 24, py = blockIdx.x % 24;
     const PIX* src = pix + (int64_t)img * 3 * VIT_IMG * VIT_IMG;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const PIX* __restrict__ pix
         float v;
         if (sizeof(PIX) == 4) v = (float)src[((int64_t)c * VIT_IMG + py * 14 + ky) * VIT_IMG + xcol];
         else v = bf16_bits_to_f32((uint16_t)src[((int64_t)c * VIT_IMG + py * 14 + ky) * VIT_IMG + xcol]);
-        dst[px * VIT_PATCH_KPAD + c * 196 + ky * 14 + kx] = f32_to_bf16_bits(v);
+        dst[px * VIT_PATCH_KPAD + c * 196 + ky * 14 + kx] = T::bits(v);
     }
     for (int idx = threadIdx.x; idx < 24 * (VIT_PATCH_KPAD - VIT_PATCH_K); idx += 256) {
         const int px = idx / (VIT_PATCH_KPAD - VIT_PATCH_K), k = idx % (VIT_PATCH_KPAD - VIT_PATCH_K);
@@ -136,14 +138,18 @@ __global__ __launch_bounds__(256) void im2col_kernel(const PIX* __restrict__ pix
     }
 }
 
-int pg_im2col_launch(const void* pixels, int pix_dtype, void* out, int n_images, hipStream_t s) {
+int pg_im2col_launch(const void* pixels, int pix_dtype, void* out, int out_dtype, int n_images, hipStream_t s) {
     if (n_images <= 0) return PG_OK;
     dim3 grid(n_images * 24), block(256);
-    if (pix_dtype == PG_DTYPE_F32)
-        hipLaunchKernelGGL(im2col_kernel<float>, grid, block, 0, s, (const float*)pixels, (uint16_t*)out);
-    else if (pix_dtype == PG_DTYPE_BF16)
-        hipLaunchKernelGGL(im2col_kernel<uint16_t>, grid, block, 0, s, (const uint16_t*)pixels, (uint16_t*)out);
-    else { pg_set_error("im2col: unsupported pixel dtype %d", pix_dtype); return PG_EINVAL; }
+    if (out_dtype != PG_DTYPE_F16 && out_dtype != PG_DTYPE_BF16) { pg_set_error("im2col: bad output dtype %d", out_dtype); return PG_EINVAL; }
+    const bool h = out_dtype == PG_DTYPE_F16;
+    if (pix_dtype == PG_DTYPE_F32) {
+        if (h) hipLaunchKernelGGL((im2col_kernel<float, T_F16>), grid, block, 0, s, (const float*)pixels, (uint16_t*)out);
+        else hipLaunchKernelGGL((im2col_kernel<float, T_BF16>), grid, block, 0, s, (const float*)pixels, (uint16_t*)out);
+    } else if (pix_dtype == PG_DTYPE_BF16) {
+        if (h) hipLaunchKernelGGL((im2col_kernel<uint16_t, T_F16>), grid, block, 0, s, (const uint16_t*)pixels, (uint16_t*)out);
+        else hipLaunchKernelGGL((im2col_kernel<uint16_t, T_BF16>), grid, block, 0, s, (const uint16_t*)pixels, (uint16_t*)out);
+    } else { pg_set_error("im2col: unsupported pixel dtype %d", pix_dtype); return PG_EINVAL; }
     return pg_check_launch("im2col");
 }
 
@@ -172,24 +178,27 @@ int pg_token_mean_launch(const float* x, float* out, int n_images, hipStream_t s
 }
 
 // ---- fp32 -> bf16 cast ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t n) {
+template <typename T>
+__global__ __launch_bounds__(256) void f32_to_16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t n) {
     int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     const int64_t stride = (int64_t)gridDim.x * 256 * 4;
     for (; i + 3 < n; i += stride) {
         const f32x4 v = *(const f32x4*)(x + i);
         u32x2 pk;
-        pk[0] = pack_bf16x2(v[0], v[1]);
-        pk[1] = pack_bf16x2(v[2], v[3]);
+        pk[0] = pack16x2<T>(v[0], v[1]);
+        pk[1] = pack16x2<T>(v[2], v[3]);
         *(u32x2*)(y + i) = pk;
     }
-    if (i < n) for (int64_t j = i; j < n; ++j) y[j] = f32_to_bf16_bits(x[j]);   // ragged tail (at most one thread)
+    if (i < n) for (int64_t j = i; j < n; ++j) y[j] = T::bits(x[j]);   // ragged tail (at most one thread)
 }
 
-int pg_f32_to_bf16_launch(const float* x, void* y, int64_t n, hipStream_t s) {
+int pg_cast_f32_launch(const float* x, void* y, int out_dtype, int64_t n, hipStream_t s) {
     if (n <= 0) return PG_OK;
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, (uint16_t*)y, n);
-    return pg_check_launch("f32_to_bf16");
+    if (out_dtype == PG_DTYPE_F16) hipLaunchKernelGGL(f32_to_16_kernel<T_F16>, dim3((unsigned)blocks), dim3(256), 0, s, x, (uint16_t*)y, n);
+    else if (out_dtype == PG_DTYPE_BF16) hipLaunchKernelGGL(f32_to_16_kernel<T_BF16>, dim3((unsigned)blocks), dim3(256), 0, s, x, (uint16_t*)y, n);
+    else { pg_set_error("cast: bad output dtype %d", out_dtype); return PG_EINVAL; }
+    return pg_check_launch("cast_f32");
 }

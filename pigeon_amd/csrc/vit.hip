@@ -9,8 +9,8 @@
 //          LN2 -> Xn bf16 ; gemm<GELU> -> H bf16 (aliases QKV) ; gemm<RESID>(H, W2) -> X }
 //   token_mean        X -> emb (n,1024) fp32
 // HBM layout per chunk: X 4 KB/row fp32, Xn/O 2 KB/row bf16, QKV/H/P 8 KB/row bf16  => 14 KB per token row,
-// 8.1 MB per image; weights 0.61 GB bf16 stay resident.  The residual stream and all LayerNorm / softmax
-// statistics are fp32; only GEMM operands are bf16 (SURVEY "accuracy budget").
+// 8.1 MB per image; weights 0.61 GB (16-bit) stay resident.  The residual stream and all LayerNorm / softmax
+// statistics are fp32; only MFMA operands are 16-bit: fp16 by default, bf16 with cfg.mma_dtype / PIGEON_MMA_DTYPE=bf16.
 #include "common.h"
 #include "pigeon_internal.h"
 
@@ -40,8 +40,8 @@ int pg_default_gemm_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("PIGEON_GEMM_VARIANT");
-        v = e ? atoi(e) : 1;
-        if (v <= 0) v = 1;
+        v = e ? atoi(e) : 8;
+        if (v <= 0) v = 8;
     }
     return v;
 }
@@ -102,6 +102,15 @@ extern "C" int pg_vit_create(pg_vit** out, int device, const pg_vit_cfg* cfg) {
     h->cfg = *cfg;
     if (h->cfg.ln_eps <= 0) h->cfg.ln_eps = 1e-5f;
     if (h->cfg.max_chunk <= 0) h->cfg.max_chunk = 256;
+    if (h->cfg.mma_dtype == 0) {
+        const char* e = getenv("PIGEON_MMA_DTYPE");
+        h->cfg.mma_dtype = (e && (!strcmp(e, "bf16") || !strcmp(e, "BF16"))) ? PG_DTYPE_BF16 : PG_DTYPE_F16;
+    }
+    if (h->cfg.mma_dtype != PG_DTYPE_F16 && h->cfg.mma_dtype != PG_DTYPE_BF16) {
+        delete h;
+        pg_set_error("vit_create: mma_dtype must be 0 (default), PG_DTYPE_F16 or PG_DTYPE_BF16");
+        return PG_EINVAL;
+    }
     h->device = device;
     h->layers.resize(cfg->layers);
     *out = h;
@@ -127,6 +136,15 @@ static uint16_t host_bf16(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
+static uint16_t host_f16(float f) {                       // round to nearest even, saturating
+    if (f > 65504.f) f = 65504.f;
+    if (f < -65504.f) f = -65504.f;
+    _Float16 h = (_Float16)f;
+    uint16_t b;
+    memcpy(&b, &h, 2);
+    return b;
+}
+static uint16_t host_cvt(int dtype, float f) { return dtype == PG_DTYPE_F16 ? host_f16(f) : host_bf16(f); }
 
 static int need(pg_vit* h, const std::string& k, size_t n, const std::vector<float>** out) {
     auto it = h->host.find(k);
@@ -159,13 +177,14 @@ extern "C" int pg_vit_finalize(pg_vit* h) {
     if (h->finalized) return PG_OK;
     PG_HIP(hipSetDevice(h->device));
     const size_t D = VIT_HIDDEN, F = VIT_MLP;
+    const int dt = h->cfg.mma_dtype;
     const std::vector<float>* p;
     // patch embedding [1024,3,14,14] -> bf16 [1024][640], zero padded along K
     RC(need(h, "embeddings.patch_embedding.weight", D * VIT_PATCH_K, &p));
     {
         std::vector<uint16_t> w(D * VIT_PATCH_KPAD, 0);
         for (size_t n = 0; n < D; ++n)
-            for (size_t k = 0; k < VIT_PATCH_K; ++k) w[n * VIT_PATCH_KPAD + k] = host_bf16((*p)[n * VIT_PATCH_K + k]);
+            for (size_t k = 0; k < VIT_PATCH_K; ++k) w[n * VIT_PATCH_KPAD + k] = host_cvt(dt, (*p)[n * VIT_PATCH_K + k]);
         RC(upload_bf16(h, w, &h->wpatch));
     }
     RC(need(h, "embeddings.class_embedding", D, &p));                 RC(upload_f32(h, p->data(), D, &h->cls));
@@ -181,7 +200,7 @@ extern "C" int pg_vit_finalize(pg_vit* h) {
         RC(need(h, pre + "self_attn.k_proj.bias", D, &bk));       RC(need(h, pre + "self_attn.v_proj.bias", D, &bv));
         {
             std::vector<uint16_t> w(3 * D * D);
-            for (size_t i = 0; i < D * D; ++i) { w[i] = host_bf16((*wq)[i]); w[D * D + i] = host_bf16((*wk)[i]); w[2 * D * D + i] = host_bf16((*wv)[i]); }
+            for (size_t i = 0; i < D * D; ++i) { w[i] = host_cvt(dt, (*wq)[i]); w[D * D + i] = host_cvt(dt, (*wk)[i]); w[2 * D * D + i] = host_cvt(dt, (*wv)[i]); }
             RC(upload_bf16(h, w, &L.wqkv));
             std::vector<float> b(3 * D);
             for (size_t i = 0; i < D; ++i) { b[i] = (*bq)[i]; b[D + i] = (*bk)[i]; b[2 * D + i] = (*bv)[i]; }
@@ -191,7 +210,7 @@ extern "C" int pg_vit_finalize(pg_vit* h) {
             const std::vector<float>* q;
             RC(need(h, k, n, &q));
             std::vector<uint16_t> w(n);
-            for (size_t i = 0; i < n; ++i) w[i] = host_bf16((*q)[i]);
+            for (size_t i = 0; i < n; ++i) w[i] = host_cvt(dt, (*q)[i]);
             return upload_bf16(h, w, dst);
         };
         auto up_f = [&](const std::string& k, size_t n, float** dst) -> int {
@@ -227,10 +246,10 @@ extern "C" int pg_vit_workspace_bytes(const pg_vit* h, int n_images, size_t* byt
 struct ProfScope {
     pg_vit* h; hipStream_t s; int cls; hipEvent_t a = nullptr, b = nullptr;
     ProfScope(pg_vit* h_, hipStream_t s_, int c) : h(h_), s(s_), cls(c) {
-        if (h->prof) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
+        if (h->prof) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
     }
     ~ProfScope() {
-        if (h->prof) { hipEventRecord(b, s); h->evs.push_back({a, b, cls}); }
+        if (h->prof) { (void)hipEventRecord(b, s); h->evs.push_back({a, b, cls}); }
     }
 };
 
@@ -241,25 +260,26 @@ static int vit_forward_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n
     uint16_t* Xn = (uint16_t*)(ws + align_up((size_t)M * VIT_HIDDEN * 4, 256));
     uint16_t* big = (uint16_t*)((char*)Xn + align_up((size_t)M * VIT_HIDDEN * 2, 256));
     const float eps = h->cfg.ln_eps;
-    { ProfScope p(h, s, 7); RC(pg_im2col_launch(pixels, pix_dtype, big, n, s)); }
+    const int dt = h->cfg.mma_dtype;
+    { ProfScope p(h, s, 7); RC(pg_im2col_launch(pixels, pix_dtype, big, dt, n, s)); }
     { ProfScope p(h, s, 4);
-      RC(pg_gemm_launch(big, VIT_PATCH_KPAD, h->wpatch, nullptr, X, VIT_HIDDEN, n * VIT_PATCHES, VIT_HIDDEN, VIT_PATCH_KPAD,
+      RC(pg_gemm_launch(dt, big, VIT_PATCH_KPAD, h->wpatch, nullptr, X, VIT_HIDDEN, n * VIT_PATCHES, VIT_HIDDEN, VIT_PATCH_KPAD,
                         EPI_PATCH, 1.f, 0, h->pos, 0, s)); }
     { ProfScope p(h, s, 6); RC(pg_preln_launch(X, h->cls, h->pos, h->preg, h->preb, M, eps, s)); }
     for (int l = 0; l < h->cfg.layers; ++l) {
         const LayerW& L = h->layers[l];
-        { ProfScope p(h, s, 6); RC(pg_layernorm_launch(X, L.ln1g, L.ln1b, Xn, 1, M, eps, s)); }
+        { ProfScope p(h, s, 6); RC(pg_layernorm_launch(X, L.ln1g, L.ln1b, Xn, dt, M, eps, s)); }
         { ProfScope p(h, s, 0);
-          RC(pg_gemm_launch(Xn, VIT_HIDDEN, L.wqkv, L.bqkv, big, 3 * VIT_HIDDEN, (int)M, 3 * VIT_HIDDEN, VIT_HIDDEN, EPI_QKV,
+          RC(pg_gemm_launch(dt, Xn, VIT_HIDDEN, L.wqkv, L.bqkv, big, 3 * VIT_HIDDEN, (int)M, 3 * VIT_HIDDEN, VIT_HIDDEN, EPI_QKV,
                             kQScale, VIT_HIDDEN, nullptr, 0, s)); }
-        { ProfScope p(h, s, 5); RC(pg_attention_launch(big, Xn, n, s)); }
+        { ProfScope p(h, s, 5); RC(pg_attention_launch(dt, big, Xn, n, s)); }
         { ProfScope p(h, s, 1);
-          RC(pg_gemm_launch(Xn, VIT_HIDDEN, L.wo, L.bo, X, VIT_HIDDEN, (int)M, VIT_HIDDEN, VIT_HIDDEN, EPI_RESID, 1.f, 0, nullptr, 0, s)); }
-        { ProfScope p(h, s, 6); RC(pg_layernorm_launch(X, L.ln2g, L.ln2b, Xn, 1, M, eps, s)); }
+          RC(pg_gemm_launch(dt, Xn, VIT_HIDDEN, L.wo, L.bo, X, VIT_HIDDEN, (int)M, VIT_HIDDEN, VIT_HIDDEN, EPI_RESID, 1.f, 0, nullptr, 0, s)); }
+        { ProfScope p(h, s, 6); RC(pg_layernorm_launch(X, L.ln2g, L.ln2b, Xn, dt, M, eps, s)); }
         { ProfScope p(h, s, 2);
-          RC(pg_gemm_launch(Xn, VIT_HIDDEN, L.w1, L.b1, big, VIT_MLP, (int)M, VIT_MLP, VIT_HIDDEN, EPI_GELU, 1.f, 0, nullptr, 0, s)); }
+          RC(pg_gemm_launch(dt, Xn, VIT_HIDDEN, L.w1, L.b1, big, VIT_MLP, (int)M, VIT_MLP, VIT_HIDDEN, EPI_GELU, 1.f, 0, nullptr, 0, s)); }
         { ProfScope p(h, s, 3);
-          RC(pg_gemm_launch(big, VIT_MLP, L.w2, L.b2, X, VIT_HIDDEN, (int)M, VIT_HIDDEN, VIT_MLP, EPI_RESID, 1.f, 0, nullptr, 0, s)); }
+          RC(pg_gemm_launch(dt, big, VIT_MLP, L.w2, L.b2, X, VIT_HIDDEN, (int)M, VIT_HIDDEN, VIT_MLP, EPI_RESID, 1.f, 0, nullptr, 0, s)); }
     }
     { ProfScope p(h, s, 8); RC(pg_token_mean_launch(X, emb_out, n, s)); }
     if (hidden_out) PG_HIP(hipMemcpyAsync(hidden_out, X, (size_t)M * VIT_HIDDEN * 4, hipMemcpyDeviceToDevice, s));
@@ -295,8 +315,8 @@ extern "C" int pg_vit_forward(pg_vit* h, const void* pixels, int pix_dtype, int 
 
 extern "C" int pg_vit_destroy(pg_vit* h) {
     if (!h) return PG_OK;
-    for (void* p : h->allocs) hipFree(p);
-    for (auto& e : h->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (void* p : h->allocs) (void)hipFree(p);
+    for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     delete h;
     return PG_OK;
 }
@@ -313,7 +333,7 @@ static int prof_drain(pg_vit* h) {
         PG_HIP(hipEventElapsedTime(&ms, e.a, e.b));
         h->prof_ms[e.cls] += ms;
         h->prof_launches[e.cls] += 1;
-        hipEventDestroy(e.a); hipEventDestroy(e.b);
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
     }
     h->evs.clear();
     return PG_OK;
@@ -332,30 +352,32 @@ extern "C" int pg_vit_profile_reset(pg_vit* h) {
 }
 
 // ------------------------------------------------------------------------------------------------ op-level ABI
-extern "C" int pg_op_gemm_bf16(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
-                               int M, int N, int K, int epi, float qscale, int qcols, const float* aux, int variant,
-                               void* stream) {
-    if (!A || !W || !out) { pg_set_error("op_gemm: null argument"); return PG_EINVAL; }
-    return pg_gemm_launch(A, lda, W, bias, out, ldc, M, N, K, epi, qscale, qcols, aux, variant, (hipStream_t)stream);
+extern "C" int pg_vit_mma_dtype(const pg_vit* h) { return h ? h->cfg.mma_dtype : PG_EINVAL; }
+
+extern "C" int pg_op_gemm16(int dtype, const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
+                            int M, int N, int K, int epi, float qscale, int qcols, const float* aux, int variant,
+                            void* stream) {
+    if (!A || !W || !out) { pg_set_error("op_gemm16: null argument"); return PG_EINVAL; }
+    return pg_gemm_launch(dtype, A, lda, W, bias, out, ldc, M, N, K, epi, qscale, qcols, aux, variant, (hipStream_t)stream);
 }
 extern "C" int pg_op_layernorm(const float* x, const float* gamma, const float* beta, void* y, int out_dtype,
                                int64_t rows, float eps, void* stream) {
     if (!x || !gamma || !beta || !y) { pg_set_error("op_layernorm: null argument"); return PG_EINVAL; }
-    return pg_layernorm_launch(x, gamma, beta, y, out_dtype == PG_DTYPE_BF16, rows, eps, (hipStream_t)stream);
+    return pg_layernorm_launch(x, gamma, beta, y, out_dtype, rows, eps, (hipStream_t)stream);
 }
-extern "C" int pg_op_attention(const void* qkv, void* out, int n_images, void* stream) {
+extern "C" int pg_op_attention(int dtype, const void* qkv, void* out, int n_images, void* stream) {
     if (!qkv || !out) { pg_set_error("op_attention: null argument"); return PG_EINVAL; }
-    return pg_attention_launch(qkv, out, n_images, (hipStream_t)stream);
+    return pg_attention_launch(dtype, qkv, out, n_images, (hipStream_t)stream);
 }
-extern "C" int pg_op_im2col(const void* pixels, int pix_dtype, void* out, int n_images, void* stream) {
+extern "C" int pg_op_im2col(const void* pixels, int pix_dtype, void* out, int out_dtype, int n_images, void* stream) {
     if (!pixels || !out) { pg_set_error("op_im2col: null argument"); return PG_EINVAL; }
-    return pg_im2col_launch(pixels, pix_dtype, out, n_images, (hipStream_t)stream);
+    return pg_im2col_launch(pixels, pix_dtype, out, out_dtype, n_images, (hipStream_t)stream);
 }
 extern "C" int pg_op_token_mean(const float* x, float* out, int n_images, void* stream) {
     if (!x || !out) { pg_set_error("op_token_mean: null argument"); return PG_EINVAL; }
     return pg_token_mean_launch(x, out, n_images, (hipStream_t)stream);
 }
-extern "C" int pg_op_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
-    if (!x || !y) { pg_set_error("op_f32_to_bf16: null argument"); return PG_EINVAL; }
-    return pg_f32_to_bf16_launch(x, y, n, (hipStream_t)stream);
+extern "C" int pg_op_cast_f32(const float* x, void* y, int out_dtype, int64_t n, void* stream) {
+    if (!x || !y) { pg_set_error("op_cast_f32: null argument"); return PG_EINVAL; }
+    return pg_cast_f32_launch(x, y, out_dtype, n, (hipStream_t)stream);
 }

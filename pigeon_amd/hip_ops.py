@@ -22,6 +22,16 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_T16 = {torch.float16: _lib.PG_DTYPE_F16, torch.bfloat16: _lib.PG_DTYPE_BF16}
+_PG2T = {_lib.PG_DTYPE_F16: torch.float16, _lib.PG_DTYPE_BF16: torch.bfloat16, _lib.PG_DTYPE_F32: torch.float32}
+
+
+def _dt16(t: torch.Tensor) -> int:
+    if t.dtype not in _T16:
+        raise _lib.PigeonHipError(f"expected a float16 or bfloat16 tensor, got {t.dtype}")
+    return _T16[t.dtype]
+
+
 def _dev(t: torch.Tensor, dtype=None) -> torch.Tensor:
     if not t.is_cuda:
         raise _lib.PigeonHipError("expected a device tensor")
@@ -33,44 +43,43 @@ def _dev(t: torch.Tensor, dtype=None) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------------------- building blocks
-def gemm_bf16(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epi: int,
-              qscale: float = 1.0, qcols: int = 0, aux: Optional[torch.Tensor] = None, variant: int = 0,
-              M: Optional[int] = None):
-    """out (epilogue-dependent) <- A[M,K] bf16 x W[N,K]^T bf16; see pg_op_gemm_bf16."""
-    _dev(A, torch.bfloat16); _dev(W, torch.bfloat16)
+def gemm16(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epi: int,
+           qscale: float = 1.0, qcols: int = 0, aux: Optional[torch.Tensor] = None, variant: int = 0,
+           M: Optional[int] = None):
+    """out (epilogue-dependent) <- A[M,K] x W[N,K]^T, both fp16 or both bf16; see pg_op_gemm16."""
+    _dev(A); _dev(W, A.dtype)
     M = A.shape[0] if M is None else M
     K = A.shape[1]
     N = W.shape[0]
-    check(load().pg_op_gemm_bf16(_p(A), A.stride(0), _p(W), _p(bias), _p(out), out.stride(0), M, N, K, epi,
-                                 float(qscale), int(qcols), _p(aux), variant, _stream()), "pg_op_gemm_bf16")
+    check(load().pg_op_gemm16(_dt16(A), _p(A), A.stride(0), _p(W), _p(bias), _p(out), out.stride(0), M, N, K, epi,
+                              float(qscale), int(qcols), _p(aux), variant, _stream()), "pg_op_gemm16")
     return out
 
 
-def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, out_bf16: bool = True,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+              out_dtype: torch.dtype = torch.float16, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _dev(x, torch.float32)
     rows = x.numel() // HIDDEN
     if out is None:
-        out = torch.empty(x.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
-    check(load().pg_op_layernorm(_p(x), _p(gamma), _p(beta), _p(out),
-                                 _lib.PG_DTYPE_BF16 if out.dtype == torch.bfloat16 else _lib.PG_DTYPE_F32,
-                                 rows, float(eps), _stream()), "pg_op_layernorm")
+        out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    pg = _lib.PG_DTYPE_F32 if out.dtype == torch.float32 else _dt16(out)
+    check(load().pg_op_layernorm(_p(x), _p(gamma), _p(beta), _p(out), pg, rows, float(eps), _stream()), "pg_op_layernorm")
     return out
 
 
 def attention(qkv: torch.Tensor, n_images: int) -> torch.Tensor:
-    _dev(qkv, torch.bfloat16)
-    out = torch.empty((n_images * TOKENS, HIDDEN), dtype=torch.bfloat16, device=qkv.device)
-    check(load().pg_op_attention(_p(qkv), _p(out), n_images, _stream()), "pg_op_attention")
+    _dev(qkv)
+    out = torch.empty((n_images * TOKENS, HIDDEN), dtype=qkv.dtype, device=qkv.device)
+    check(load().pg_op_attention(_dt16(qkv), _p(qkv), _p(out), n_images, _stream()), "pg_op_attention")
     return out
 
 
-def im2col(pixels: torch.Tensor) -> torch.Tensor:
+def im2col(pixels: torch.Tensor, out_dtype: torch.dtype = torch.float16) -> torch.Tensor:
     _dev(pixels)
     n = pixels.shape[0]
     dt = _lib.PG_DTYPE_F32 if pixels.dtype == torch.float32 else _lib.PG_DTYPE_BF16
-    out = torch.empty((n * PATCHES, KPAD), dtype=torch.bfloat16, device=pixels.device)
-    check(load().pg_op_im2col(_p(pixels), dt, _p(out), n, _stream()), "pg_op_im2col")
+    out = torch.empty((n * PATCHES, KPAD), dtype=out_dtype, device=pixels.device)
+    check(load().pg_op_im2col(_p(pixels), dt, _p(out), _dt16(out), n, _stream()), "pg_op_im2col")
     return out
 
 
@@ -82,10 +91,10 @@ def token_mean(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def f32_to_bf16(x: torch.Tensor) -> torch.Tensor:
+def cast_f32(x: torch.Tensor, out_dtype: torch.dtype = torch.float16) -> torch.Tensor:
     _dev(x, torch.float32)
-    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    check(load().pg_op_f32_to_bf16(_p(x), _p(y), x.numel(), _stream()), "pg_op_f32_to_bf16")
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    check(load().pg_op_cast_f32(_p(x), _p(y), _dt16(y), x.numel(), _stream()), "pg_op_cast_f32")
     return y
 
 
@@ -97,7 +106,9 @@ class VitEncoder:
     tensors of any float dtype (converted to fp32 on the host, then packed by the library).
     """
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], device: int = 0, max_chunk: int = 0, layers: Optional[int] = None):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device: int = 0, max_chunk: int = 0,
+                 layers: Optional[int] = None, mma_dtype: Optional[str] = None):
+        """mma_dtype: None (library default: fp16, or env PIGEON_MMA_DTYPE=bf16), 'f16' or 'bf16'."""
         _lib.require_gpu()
         lib = load()
         keys = [k[len("vision_model."):] if k.startswith("vision_model.") else k for k in state_dict]
@@ -109,7 +120,8 @@ class VitEncoder:
             raise _lib.PigeonHipError("state dict holds no encoder layers")
         self.layers = layers
         self.device = device
-        cfg = VitCfg(layers, 336, 14, 1024, 16, 4096, 1e-5, max_chunk)
+        pgdt = {None: 0, "f16": _lib.PG_DTYPE_F16, "fp16": _lib.PG_DTYPE_F16, "bf16": _lib.PG_DTYPE_BF16}[mma_dtype]
+        cfg = VitCfg(layers, 336, 14, 1024, 16, 4096, 1e-5, max_chunk, pgdt)
         h = C.c_void_p()
         torch.cuda.set_device(device)
         check(lib.pg_vit_create(C.byref(h), device, C.byref(cfg)), "pg_vit_create")
@@ -122,6 +134,7 @@ class VitEncoder:
             check(lib.pg_vit_load_weight(h, name.encode(), C.c_void_p(a.data_ptr()), _lib.PG_DTYPE_F32, shape,
                                          max(a.dim(), 1)), f"pg_vit_load_weight({name})")
         check(lib.pg_vit_finalize(h), "pg_vit_finalize")
+        self.mma_dtype = {_lib.PG_DTYPE_F16: "f16", _lib.PG_DTYPE_BF16: "bf16"}[lib.pg_vit_mma_dtype(h)]
         self._ws = None
         self.max_chunk = max_chunk if max_chunk > 0 else 256
 

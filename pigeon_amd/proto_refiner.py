@@ -1,0 +1,219 @@
+"""ProtoRefiner (prototype-distance guess refinement) on the HIP kernels, behind the reference's call surface.
+
+Mirrors reference models/proto_refiner.py: same constructor arguments, same `forward(embedding, geo_tensor,
+initial_preds, candidate_cells, candidate_probs, cluster) -> (loss, preds_LLH, preds_geocell)` and the same
+status print.  The per-sample / per-candidate Python loop (:154-222) is replaced by pg_refine_forward over a
+CSR prototype bank resident in HBM.  `hedge=True` is out of scope (disabled in the reference's final model,
+models/README.md:11) and raises.
+"""
+from __future__ import annotations
+
+import json
+from typing import List, Optional
+
+import numpy as np
+import torch
+from torch import nn, Tensor
+from torch.nn.parameter import Parameter
+
+from . import hip_ops
+from .config import DATASET_PATH, PROTO_PATH
+
+
+class HostBank:
+    """CSR prototype bank on the host (numpy), the layout include/pigeon_hip.h `pg_bank` documents."""
+    FIELDS = ("proto_emb", "cell_off", "proto_lnglat", "proto_count", "member_off", "member_idx",
+              "train_emb", "train_lnglat")
+
+    def __init__(self, **kw):
+        for f in self.FIELDS:
+            setattr(self, f, kw[f])
+
+    @property
+    def num_cells(self):
+        return self.cell_off.shape[0] - 1
+
+    def save(self, path: str):
+        """Packed binary bank (one .npz): loads in seconds where the reference's 64-process Arrow build
+        (proto_refiner.py:257-313) takes minutes."""
+        np.savez(path, **{f: getattr(self, f) for f in self.FIELDS})
+
+    @classmethod
+    def load(cls, path: str) -> "HostBank":
+        z = np.load(path)
+        return cls(**{f: z[f] for f in cls.FIELDS})
+
+
+def _load_indices(index_json, verbose=False):
+    """reference models/proto_refiner.py:92-108"""
+    try:
+        return json.loads(index_json)
+    except TypeError:
+        if verbose:
+            print('Couldn\'t load a geocell.')
+        return []
+
+
+def _training_arrays(dataset_path):
+    """`DatasetDict.load_from_disk(dataset_path)['train']` -> (Ntr,1024) f32 panel-averaged embeddings and
+    (Ntr,2) f32 [lng,lat] labels (reference :48-67, :247-255, :370-376)."""
+    import datasets
+    if type(dataset_path) == list:
+        if len(dataset_path) > 2:
+            raise NotImplementedError('Can\'t concatentate more than 2 datasets.')
+        parts = [datasets.DatasetDict.load_from_disk(p)['train'] for p in dataset_path]
+        train = datasets.concatenate_datasets([p.remove_columns([c for c in ('labels_climate',) if c in p.column_names])
+                                               for p in parts])
+    else:
+        train = datasets.DatasetDict.load_from_disk(dataset_path)['train']
+    train = train.with_format('numpy')
+    emb = np.asarray(train['embedding'][:], dtype=np.float32)
+    if emb.ndim == 3:                                             # (N,4,1024): mean over panels (:252-253,:374-375)
+        emb = torch.from_numpy(emb).mean(dim=1).numpy()
+    lab = np.asarray(train['labels'][:], dtype=np.float32)
+    return np.ascontiguousarray(emb), np.ascontiguousarray(lab[:, :2])
+
+
+def build_bank(proto_path: str, dataset_path, verbose: bool = False) -> HostBank:
+    """CSV + training embeddings -> CSR bank, reproducing the reference's prototype construction:
+    rows of one geocell in CSV order (`proto_df.loc[cell]`, :299), a cell whose FIRST row has no indices is
+    empty (:307-308), prototype embedding = fp32 mean of the member embeddings (:359-378), lng/lat/count
+    columns become float32/int under the torch format (:312)."""
+    import pandas as pd
+    train_emb, train_lnglat = _training_arrays(dataset_path)
+    df = pd.read_csv(proto_path)
+    df['indices'] = df['indices'].apply(lambda s: _load_indices(s, verbose))
+    df['geocell_idx'] = df['geocell_idx'].astype(int)
+    num_cells = int(df['geocell_idx'].max()) + 1                  # :75
+    order = np.argsort(df['geocell_idx'].values, kind='stable')   # keeps CSV order inside a cell
+    cells = df['geocell_idx'].values[order]
+    idx_lists = [df['indices'].values[i] for i in order]
+    lng = df['lng'].values[order].astype(np.float32)
+    lat = df['lat'].values[order].astype(np.float32)
+    cnt = df['count'].values[order].astype(np.int32)
+    keep = np.ones(len(order), dtype=bool)
+    start = 0
+    while start < len(order):                                     # drop cells whose first row is empty (:307-308)
+        end = start
+        while end < len(order) and cells[end] == cells[start]:
+            end += 1
+        if len(idx_lists[start]) == 0:
+            keep[start:end] = False
+        start = end
+    cells, lng, lat, cnt = cells[keep], lng[keep], lat[keep], cnt[keep]
+    idx_lists = [l for l, k in zip(idx_lists, keep) if k]
+    P = len(idx_lists)
+    cell_off = np.zeros(num_cells + 1, dtype=np.int64)
+    np.add.at(cell_off, cells + 1, 1)
+    cell_off = np.cumsum(cell_off)
+    lens = np.array([len(l) for l in idx_lists], dtype=np.int64)
+    member_off = np.zeros(P + 1, dtype=np.int64)
+    np.cumsum(lens, out=member_off[1:])
+    member_idx = np.fromiter((i for l in idx_lists for i in l), dtype=np.int64, count=int(member_off[-1]))
+    # segmented fp32 mean, rows added in member order then divided by the count == torch .mean(dim=0)
+    # (np.add.reduceat sums pairwise and differs in the last ulp; the member-by-member sweep below is exact)
+    proto_emb = np.zeros((P, train_emb.shape[1]), dtype=np.float32)
+    for j in range(int(lens.max()) if P else 0):
+        sel = np.nonzero(lens > j)[0]
+        proto_emb[sel] += train_emb[member_idx[member_off[sel] + j]]
+    nz = lens > 0
+    proto_emb[nz] /= lens[nz].astype(np.float32)[:, None]
+    return HostBank(proto_emb=proto_emb, cell_off=cell_off, proto_lnglat=np.stack([lng, lat], axis=1),
+                    proto_count=cnt, member_off=member_off, member_idx=member_idx,
+                    train_emb=train_emb, train_lnglat=train_lnglat)
+
+
+def bank_from_protos(protos: List, dataset_path) -> HostBank:
+    """Convert the reference's own `refiner.protos` (list of per-cell HF Datasets or None, the object
+    evaluation/evaluate.py:66-75 pickles and reloads) into the CSR bank."""
+    train_emb, train_lnglat = _training_arrays(dataset_path)
+    embs, lnglat, cnt, idxs, cell_off = [], [], [], [], [0]
+    for cell in protos:
+        if cell is not None:
+            c = cell.with_format('numpy')
+            embs.append(np.asarray(c['embedding'][:], dtype=np.float32))
+            lnglat.append(np.stack([np.asarray(c['lng'][:], np.float32), np.asarray(c['lat'][:], np.float32)], axis=1))
+            cnt.append(np.asarray(c['count'][:], np.int32))
+            idxs.extend([list(map(int, x)) for x in c['indices'][:]])
+        cell_off.append(cell_off[-1] + (0 if cell is None else len(cell)))
+    lens = np.array([len(l) for l in idxs], dtype=np.int64)
+    member_off = np.zeros(len(idxs) + 1, dtype=np.int64)
+    np.cumsum(lens, out=member_off[1:])
+    return HostBank(proto_emb=np.concatenate(embs) if embs else np.zeros((0, 1024), np.float32),
+                    cell_off=np.asarray(cell_off, np.int64),
+                    proto_lnglat=np.concatenate(lnglat) if lnglat else np.zeros((0, 2), np.float32),
+                    proto_count=np.concatenate(cnt) if cnt else np.zeros((0,), np.int32), member_off=member_off,
+                    member_idx=np.fromiter((i for l in idxs for i in l), dtype=np.int64, count=int(member_off[-1])),
+                    train_emb=train_emb, train_lnglat=train_lnglat)
+
+
+class ProtoRefiner(nn.Module):
+    """Proto-Net refinement model (reference models/proto_refiner.py:17-90)."""
+
+    def __init__(self, topk: int = 5, hedge: bool = False, max_refinement: int = 1000,
+                 temperature: float = 1.6, proto_path: str = PROTO_PATH,
+                 dataset_path: str = DATASET_PATH, protos: List = None,
+                 verbose: bool = False, bank=None, device: str = 'cuda'):
+        """Arguments as the reference.  Extra: `bank` (HostBank / SyntheticBank / path to a packed .npz) supplies
+        the CSR bank directly; `protos` accepts the reference's pickled list of per-cell datasets."""
+        super(ProtoRefiner, self).__init__()
+        if hedge:
+            raise NotImplementedError('hedge=True is out of scope: disabled in the final model (models/README.md:11)')
+        self.topk = topk
+        self.hedge = hedge
+        self.max_refinement = max_refinement
+        self.verbose = verbose
+        if bank is not None:
+            host = HostBank.load(bank) if isinstance(bank, str) else bank
+        elif protos is not None:
+            host = bank_from_protos(protos, dataset_path)
+        else:
+            print('Initializing ProtoRefiner. This might take a while ...')
+            host = build_bank(proto_path, dataset_path, verbose)
+            print('Initialization of ProtoRefiner complete.')
+        self.host_bank = host
+        self.num_geocells = host.cell_off.shape[0] - 1
+        self.protos = host                     # attribute name kept (evaluate.py:66-75 reads `ref.protos`)
+        self.temperature = Parameter(torch.tensor(temperature), requires_grad=False)
+        self.geo_scaling = Parameter(torch.tensor(20.), requires_grad=False)
+        self._dbank = None
+        self._device = device
+
+    def _device_bank(self, device) -> hip_ops.DeviceBank:
+        if self._dbank is None:
+            self._dbank = hip_ops.DeviceBank(self.host_bank, device=device)
+        return self._dbank
+
+    def __str__(self):
+        rep = 'ProtoRefiner(\n'
+        rep += f'\ttopk\t\t= {self.topk}\n'
+        rep += f'\thedge\t\t= {self.hedge}\n'
+        rep += f'\tmax_refinement\t= {self.max_refinement}\n'
+        rep += f'\ttemperature\t= {self.temperature.data.item()}\n'
+        rep += f'\tgeo_scaling\t= {self.geo_scaling.data.item()}\n'
+        rep += ')'
+        return rep
+
+    def forward(self, embedding: Tensor = None, geo_tensor: Tensor = None, initial_preds: Tensor = None,
+                candidate_cells: Tensor = None, candidate_probs: Tensor = None, cluster: Tensor = None,
+                quiet: bool = False):
+        """reference models/proto_refiner.py:121-231.  Returns (loss, preds_LLH (B,2) f32, preds_geocell (B,) i64)."""
+        assert self.topk <= candidate_cells.size(1), \
+            '"topk" parameter must be smaller or equal to the number of geocell candidates \
+             passed into the forward function.'
+        dev = embedding.device if embedding.is_cuda else torch.device(self._device)
+        if dev.type != 'cuda':
+            raise RuntimeError('pigeon_amd.ProtoRefiner runs on the GPU only (no CPU fallback)')
+        with torch.no_grad():
+            q = embedding.to(dev, torch.float32).contiguous()
+            init = initial_preds.to(dev, torch.float64).contiguous()
+            cand = candidate_cells.to(dev, torch.int64).contiguous()
+            probs = None if candidate_probs is None else candidate_probs.to(dev, torch.float32).contiguous()
+            preds_LLH, preds_geocell, guess_index = hip_ops.refine_forward(
+                self._device_bank(dev), q, init, cand, probs, self.topk,
+                float(self.temperature.data.item()), float(self.max_refinement))
+            if not quiet:                                          # :224-227 (costs one D2H sync, like the reference)
+                perc_changed = (guess_index != 0).sum() / guess_index.size(0)
+                print(f'Changed geocell predictions of {perc_changed * 100:.1f} % of guesses.')
+        loss = 0 if self.training else None
+        return loss, preds_LLH, preds_geocell

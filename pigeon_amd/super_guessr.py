@@ -1,0 +1,194 @@
+"""SuperGuessr geocell classification model on the HIP kernels, behind the reference's call surface.
+
+Mirrors reference models/super_guessr.py (same constructor signature, `load_geocells`, `load_state`,
+`forward(pixel_values | embedding, ..., labels_clf, ...)` returning `ModelOutput` or the serving tuple).
+Only the inference branch that evaluation/evaluate.py:42-44 constructs is accelerated and supported:
+`hierarchical=False, multi_task=False, heading=False`.  The training-only options raise NotImplementedError
+(SURVEY.md section 2 row 4 lists them as out of scope).
+"""
+from __future__ import annotations
+
+import pandas as pd
+import torch
+from torch import nn, Tensor
+from torch.nn.parameter import Parameter
+
+from . import hip_ops
+from .clip_embedder import HipCLIPVisionModel
+from .config import CLIP_EMBED_DIM, GEOCELL_PATH, GEOCELL_PATH_YFCC
+from .utils import ModelOutput, TopK
+
+
+class SuperGuessr(nn.Module):
+    def __init__(self, base_model: nn.Module, panorama: bool = False, hierarchical: bool = False,
+                 should_smooth_labels: bool = False, multi_task: bool = False, heading: bool = False,
+                 yfcc: bool = False, serving: bool = False, freeze_base: bool = False,
+                 num_candidates: int = 5, embed_dim: int = CLIP_EMBED_DIM, **kwargs):
+        """Same arguments as reference models/super_guessr.py:31-34.
+
+        base_model: None (run on precomputed embeddings), a `HipCLIPVisionModel`, or any module exposing a
+        transformers-CLIPVisionModel state dict (e.g. a HuggingFace CLIPVisionModel): its weights are packed
+        into the HIP encoder on first use.
+        One extra keyword, `geocell_path`, overrides config.GEOCELL_PATH(_YFCC) (the reference hard-wires the
+        path through its config module, :87-88).
+        """
+        super(SuperGuessr, self).__init__()
+        geocell_path = kwargs.pop('geocell_path', None)
+        if len(kwargs) > 0:
+            print(f'Not using keyword arguments: {list(kwargs.keys())}')
+        if hierarchical or multi_task or heading:
+            raise NotImplementedError('pigeon_amd.SuperGuessr implements the inference configuration of '
+                                      'evaluation/evaluate.py:42-44 (hierarchical=False, multi_task=False, heading=False)')
+
+        self.base_model = base_model
+        self.panorama = panorama
+        self.hidden_size = embed_dim
+        self.serving = serving
+        self.should_smooth_labels = should_smooth_labels
+        self.multi_task = multi_task
+        self.heading = heading
+        self.yfcc = yfcc
+        self.freeze_base = freeze_base
+        self.hierarchical = hierarchical
+        self.num_candidates = num_candidates
+
+        self._set_hidden_size()
+        if geocell_path is None:
+            geocell_path = GEOCELL_PATH_YFCC if self.yfcc else GEOCELL_PATH
+        self.lla_geocells = self.load_geocells(geocell_path)
+        self.num_cells = self.lla_geocells.size(0)
+        self.input_dim = self.hidden_size
+
+        self.cell_layer = nn.Linear(self.input_dim, self.num_cells)
+        self.softmax = nn.Softmax(dim=-1)
+        self._freeze_params()
+        self.loss_fnc = nn.CrossEntropyLoss()
+        self._hip_base = None
+        print(f'Initialized SuperGuessr classification model with {self.num_cells} geocells.')
+
+    def _set_hidden_size(self):
+        if self.base_model is not None:
+            self.hidden_size = self.base_model.config.hidden_size
+            self.mode = 'transformer'
+
+    def _freeze_params(self):
+        if self.base_model is not None and self.freeze_base:
+            for param in self.base_model.parameters():
+                param.requires_grad = False
+
+    def load_geocells(self, path: str) -> Tensor:
+        """reference models/super_guessr.py:162-174: CSV columns lng,lat -> (C,2) float64 Parameter"""
+        geo_df = pd.read_csv(path)
+        lla_coords = torch.tensor(geo_df[['lng', 'lat']].values)
+        return nn.parameter.Parameter(data=lla_coords, requires_grad=False)
+
+    def load_state(self, path: str):
+        """reference models/super_guessr.py:222-238: name-wise copy of a saved state dict"""
+        own_state = self.state_dict()
+        state_dict = torch.load(path, map_location=torch.device('cuda') if torch.cuda.is_available() else 'cpu')
+        for name, param in state_dict.items():
+            if name not in own_state:
+                print(f'Parameter {name} not in model\'s state.')
+                continue
+            if isinstance(param, Parameter):
+                param = param.data
+            own_state[name].copy_(param)
+        self._hip_base = None
+        if isinstance(self.base_model, HipCLIPVisionModel):
+            self.base_model._weights_changed()
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        sd.pop('base_model._dummy', None)
+        if isinstance(self.base_model, HipCLIPVisionModel):
+            sd.update(self.base_model.state_dict(prefix='base_model.'))
+        return sd
+
+    # ------------------------------------------------------------------------------------------ hot path
+    def _encoder(self) -> HipCLIPVisionModel:
+        if isinstance(self.base_model, HipCLIPVisionModel):
+            return self.base_model
+        if self._hip_base is None:                       # e.g. a transformers CLIPVisionModel: pack its weights once
+            self._hip_base = HipCLIPVisionModel(self.base_model.state_dict())
+            self._hip_base.to(self.cell_layer.weight.device)
+        return self._hip_base
+
+    def _assert_requirements(self, pixel_values=None, embedding=None, heading=None):
+        if self.base_model is not None:
+            assert pixel_values is not None, 'Parameter "pixel_values" must be supplied if model has a base model.'
+        else:
+            assert embedding is not None, 'Parameter "embedding" must be supplied if model does not have a base model.'
+
+    def _to_one_hot(self, tensor: Tensor) -> Tensor:
+        if tensor.dim() == 0:
+            one_hot = torch.zeros(self.num_cells, device=tensor.device)
+            one_hot[tensor.item()] = 1
+            return one_hot
+        return tensor
+
+    def forward(self, pixel_values: Tensor = None, embedding: Tensor = None, heading: Tensor = None,
+                labels: Tensor = None, labels_clf: Tensor = None, labels_multi_task: Tensor = None,
+                labels_climate: Tensor = None, labels_month: Tensor = None, index: Tensor = None):
+        """Inference branch of reference models/super_guessr.py:350-483.
+
+        pixel_values (B,12,336,336) [panorama] or (B,3,336,336); or embedding (B,4,1024)/(B,1024).
+        Returns ModelOutput (or, with serving=True in eval mode, the (pred_LLH, topk, embedding) tuple, :462-466).
+        """
+        self._assert_requirements(pixel_values, embedding, heading)
+        if not self.cell_layer.weight.is_cuda:
+            raise RuntimeError('pigeon_amd.SuperGuessr runs on the GPU only: call .to("cuda") first (no CPU fallback)')
+        dev = self.cell_layer.weight.device
+        with torch.no_grad():
+            if self.panorama and pixel_values is not None:                      # :386-388
+                num_samples = pixel_values.size(0)
+                pixel_values = pixel_values.reshape((num_samples * 4, 3, 336, 336))
+            if self.base_model is not None and pixel_values is not None:
+                if pixel_values.dim() > 4:
+                    pixel_values = pixel_values.squeeze(1)                      # :392-393
+                embedding = self._encoder().embed(pixel_values.to(dev))         # :395-398 (ViT + token mean)
+                if self.panorama:
+                    embedding = embedding.reshape((num_samples, 4, -1))         # :404-405
+            else:
+                embedding = embedding.to(dev, torch.float32).contiguous()
+
+            layer_input = embedding
+            if self.panorama:
+                head_in = layer_input if layer_input.dim() == 3 else layer_input[:, None, :]   # mean over panels :437
+            elif layer_input.dim() == 3 and layer_input.size(1) == 4:
+                head_in = layer_input[:, 0].contiguous()                        # :440-441
+            else:
+                head_in = layer_input
+            o = hip_ops.head_forward(head_in.contiguous(), self.cell_layer.weight.data, self.cell_layer.bias.data,
+                                     self.lla_geocells.data, self.num_candidates)          # :447-459
+            logits = o['logits']
+            geocell_preds = o['preds_geocell']
+            pred_LLH = o['preds_LLH']
+            geocell_topk = TopK(o['topk_values'], o['topk_indices'])
+
+            if not self.training and self.serving:                              # :462-466
+                return pred_LLH, geocell_topk, embedding
+
+            loss_clf = None
+            if labels_clf is not None:                                          # :456, :474 (logged only)
+                label_probs = self._to_one_hot(labels_clf.to(dev))
+                loss_clf = self.loss_fnc(logits, label_probs)
+            loss = loss_clf
+            return ModelOutput(loss, loss_clf, 0, 0, 0, pred_LLH, geocell_preds, None, None, None,
+                               geocell_topk, embedding)
+
+    def __str__(self):
+        rep = 'SuperGuessr(\n'
+        rep += f'\tbase_model\t= {self.base_model is not None}\n'
+        rep += f'\tpanorama\t= {self.panorama}\n'
+        rep += f'\thierarchical\t= {self.hierarchical}\n'
+        rep += f'\tmulti-task\t= {self.multi_task}\n'
+        rep += f'\tyfcc\t\t= {self.yfcc}\n'
+        rep += f'\tembedding_size\t= {self.hidden_size}\n'
+        rep += f'\tinput_dim\t= {self.input_dim}\n'
+        rep += f'\tnum_geocells\t= {self.num_cells}\n'
+        rep += f'\tlabel_smoothing\t= {self.should_smooth_labels}\n'
+        rep += f'\tuses_headings\t= {self.heading}\n'
+        rep += f'\tfreeze_base\t= {self.freeze_base}\n'
+        rep += f'\tserving\t\t= {self.serving}\n'
+        rep += ')'
+        return rep

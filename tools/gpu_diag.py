@@ -46,16 +46,19 @@ def timeit(fn, iters=5, warm=2):
     return a.elapsed_time(b) / iters
 
 
+DT = torch.float16
+
+
 def bf16_rand(shape, seed, scale=1.0):
     g = torch.Generator(device="cpu").manual_seed(seed)
-    return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16).to(dev)
+    return (torch.randn(shape, generator=g) * scale).to(DT).to(dev)
 
 
 @section("gemm_correct")
 def gemm_correct():
     res = {}
-    for variant in (1, 2, 3, 11, 12):
-        for (M, N, K) in ((300, 256, 128), (1000, 512, 320), (577 * 3, 1024, 1024)):
+    for variant in (1, 2, 3, 4, 5, 7, 11):
+        for (M, N, K) in ((300, 256, 64), (300, 256, 128), (1000, 512, 320), (577 * 3, 1024, 1024), (2000, 3072, 192)):
             A = bf16_rand((M, K), 1 + M)
             W = bf16_rand((N, K), 2 + N, 0.05)
             bias = torch.randn(N, device=dev)
@@ -63,7 +66,7 @@ def gemm_correct():
             out = torch.full((M, N), float("nan"), device=dev)
             key = f"v{variant}_M{M}_N{N}_K{K}"
             try:
-                hip_ops.gemm_bf16(A, W, bias, out, _lib.EPI_F32, variant=variant)
+                hip_ops.gemm16(A, W, bias, out, _lib.EPI_F32, variant=variant)
                 torch.cuda.synchronize()
                 err = (out - ref).abs().max().item()
                 errT = float("nan")
@@ -76,10 +79,10 @@ def gemm_correct():
                 log("gemm", key, "ERROR", e)
     # transposition / layout detector: A = identity-like, asymmetric W
     M = N = K = 256
-    A = torch.eye(256, device=dev).to(torch.bfloat16)
-    W = (torch.arange(N, device=dev)[:, None] * 1.0 + torch.arange(K, device=dev)[None, :] * 0.001).to(torch.bfloat16)
+    A = torch.eye(256, device=dev).to(DT)
+    W = (torch.arange(N, device=dev)[:, None] * 1.0 + torch.arange(K, device=dev)[None, :] * 0.001).to(DT)
     out = torch.zeros((M, N), device=dev)
-    hip_ops.gemm_bf16(A, W, None, out, _lib.EPI_F32, variant=2)
+    hip_ops.gemm16(A, W, None, out, _lib.EPI_F32, variant=2)
     torch.cuda.synchronize()
     ref = A.float() @ W.float().T
     res["identity_err"] = (out - ref).abs().max().item()
@@ -91,28 +94,28 @@ def gemm_correct():
 @section("gemm_epilogues")
 def gemm_epilogues():
     res = {}
-    for variant in (1, 2, 3, 11):
+    for variant in (1, 2, 3, 4, 5, 7, 11):
         M, N, K = 1154, 1024, 256
         A = bf16_rand((M, K), 5)
         W = bf16_rand((N, K), 6, 0.05)
         bias = torch.randn(N, device=dev)
         acc = A.float() @ W.float().T
         # QKV
-        out = torch.zeros((M, N), dtype=torch.bfloat16, device=dev)
-        hip_ops.gemm_bf16(A, W, bias, out, _lib.EPI_QKV, qscale=0.25, qcols=512, variant=variant)
+        out = torch.zeros((M, N), dtype=DT, device=dev)
+        hip_ops.gemm16(A, W, bias, out, _lib.EPI_QKV, qscale=0.25, qcols=512, variant=variant)
         ref = acc + bias
         ref[:, :512] *= 0.25
         res[f"v{variant}_qkv"] = (out.float() - ref).abs().max().item() / ref.abs().max().item()
         # GELU
-        out = torch.zeros((M, N), dtype=torch.bfloat16, device=dev)
-        hip_ops.gemm_bf16(A, W, bias, out, _lib.EPI_GELU, variant=variant)
+        out = torch.zeros((M, N), dtype=DT, device=dev)
+        hip_ops.gemm16(A, W, bias, out, _lib.EPI_GELU, variant=variant)
         y = acc + bias
         ref = y * torch.sigmoid(1.702 * y)
         res[f"v{variant}_gelu"] = (out.float() - ref).abs().max().item() / ref.abs().max().item()
         # RESID
         X0 = torch.randn((M, N), device=dev)
         X = X0.clone()
-        hip_ops.gemm_bf16(A, W, bias, X, _lib.EPI_RESID, variant=variant)
+        hip_ops.gemm16(A, W, bias, X, _lib.EPI_RESID, variant=variant)
         ref = X0 + acc + bias
         res[f"v{variant}_resid"] = (X - ref).abs().max().item() / ref.abs().max().item()
         # PATCH: M = n*576 rows -> rows img*577+1+p
@@ -121,7 +124,7 @@ def gemm_epilogues():
         Wp = bf16_rand((N, 640), 8, 0.05)
         pos = torch.randn((577, N), device=dev)
         Xp = torch.full((n * 577, N), 7.0, device=dev)
-        hip_ops.gemm_bf16(Ap, Wp, None, Xp, _lib.EPI_PATCH, aux=pos, variant=variant)
+        hip_ops.gemm16(Ap, Wp, None, Xp, _lib.EPI_PATCH, aux=pos, variant=variant)
         refp = (Ap.float() @ Wp.float().T).view(n, 576, N) + pos[1:][None]
         got = Xp.view(n, 577, N)
         res[f"v{variant}_patch"] = (got[:, 1:] - refp).abs().max().item() / refp.abs().max().item()
@@ -139,15 +142,15 @@ def gemm_perf():
         A = bf16_rand((M, K), 11)
         W = bf16_rand((N, K), 12, 0.03)
         bias = torch.zeros(N, device=dev)
-        for variant in (1, 2, 3):
+        for variant in (4, 5, 6, 7):
             if name in ("qkv", "fc1"):
-                out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+                out = torch.empty((M, N), dtype=DT, device=dev)
                 epi = _lib.EPI_QKV if name == "qkv" else _lib.EPI_GELU
             else:
                 out = torch.zeros((M, N), dtype=torch.float32, device=dev)
                 epi = _lib.EPI_RESID
             try:
-                ms = timeit(lambda: hip_ops.gemm_bf16(A, W, bias, out, epi, qscale=0.18, qcols=1024, variant=variant), iters=5)
+                ms = timeit(lambda: hip_ops.gemm16(A, W, bias, out, epi, qscale=0.18, qcols=1024, variant=variant), iters=5)
                 tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
                 res[f"{name}_v{variant}"] = dict(ms=ms, tflops=tf)
                 log("gemm_perf", name, "variant", variant, f"{ms:.3f} ms  {tf:.1f} TF/s")
@@ -166,19 +169,21 @@ def rowops():
     g = torch.randn(1024, device=dev) * 0.1 + 1
     b = torch.randn(1024, device=dev) * 0.1
     ref = torch.nn.functional.layer_norm(x, (1024,), g, b, 1e-5)
-    y = hip_ops.layernorm(x, g, b, out_bf16=False)
+    y = hip_ops.layernorm(x, g, b, out_dtype=torch.float32)
     res["ln_f32_max_abs"] = (y - ref).abs().max().item()
-    y = hip_ops.layernorm(x, g, b, out_bf16=True)
-    res["ln_bf16_max_abs_vs_rounded"] = (y.float() - ref.to(torch.bfloat16).float()).abs().max().item()
+    for dt in (torch.float16, torch.bfloat16):
+        y = hip_ops.layernorm(x, g, b, out_dtype=dt)
+        res[f"ln_{dt}_max_abs_vs_rounded"] = (y.float() - ref.to(dt).float()).abs().max().item()
     px = torch.randn((3, 3, 336, 336), device=dev)
-    col = hip_ops.im2col(px)
+    col = hip_ops.im2col(px, DT)
     refc = torch.nn.functional.unfold(px, kernel_size=14, stride=14).transpose(1, 2).reshape(3 * 576, 588)
-    res["im2col_max_abs"] = (col[:, :588].float() - refc.to(torch.bfloat16).float()).abs().max().item()
+    res["im2col_max_abs"] = (col[:, :588].float() - refc.to(DT).float()).abs().max().item()
     res["im2col_pad_zero"] = float((col[:, 588:] == 0).all().item())
     h = torch.randn((5, 577, 1024), device=dev)
     res["token_mean_max_abs"] = (hip_ops.token_mean(h) - h.mean(dim=1)).abs().max().item()
     z = torch.randn(1000003, device=dev)
-    res["cast_exact"] = float((hip_ops.f32_to_bf16(z) == z.to(torch.bfloat16)).all().item())
+    res["cast_exact_f16"] = float((hip_ops.cast_f32(z, torch.float16) == z.to(torch.float16)).all().item())
+    res["cast_exact_bf16"] = float((hip_ops.cast_f32(z, torch.bfloat16) == z.to(torch.bfloat16)).all().item())
     log("rowops", res)
     return res
 
@@ -305,7 +310,12 @@ def vit2():
     gold = np.load(os.path.join(ROOT, "tests", "golden", "vit2.npz"))
     sd = synthetic.make_vit_weights(seed=11, layers=2, affine_jitter=True)
     px = synthetic.make_pixels(4, seed=77)
+    encb = hip_ops.VitEncoder(sd, mma_dtype="bf16")
+    embb = encb.forward(px.to(dev))
+    res["bf16_emb_rel_err"] = orc.rel_err(embb.cpu(), torch.from_numpy(gold["embedding"]))
+    encb.close()
     enc = hip_ops.VitEncoder(sd)
+    res["mma_dtype"] = enc.mma_dtype
     emb, hid = enc.forward(px.to(dev), return_hidden=True)
     torch.cuda.synchronize()
     ref = torch.from_numpy(gold["embedding"])
