@@ -178,8 +178,8 @@ def proto_refiner_forward(bank, embedding: torch.Tensor, initial_preds: torch.Te
     if candidate_probs is None:
         candidate_probs = torch.zeros_like(candidate_cells)                        # :143-145
         candidate_probs[:, 0] = 1
-    proto_emb = torch.as_tensor(bank.proto_emb)
-    train_emb = torch.as_tensor(bank.train_emb)
+    proto_emb = bank.proto_emb          # sliced first, converted after: the bank may be lazily materialised
+    train_emb = bank.train_emb
     preds_llh, preds_cell, choices, dbg_scores = [], [], [], []
     T = torch.tensor(temperature, dtype=torch.float32)
     for i in range(embedding.shape[0]):
@@ -194,14 +194,14 @@ def proto_refiner_forward(bank, embedding: torch.Tensor, initial_preds: torch.Te
                 top_dist.append(-100000.0)
                 top_preds.append([0.0, 0.0])
                 continue
-            logits = -torch.cdist(proto_emb[s:e], emb[None]).flatten()
+            logits = -torch.cdist(torch.as_tensor(proto_emb[s:e]), emb[None]).flatten()
             top_dist.append(torch.max(logits).item())
             pid = s + int(torch.argmax(logits))
             if int(bank.proto_count[pid]) == 1:
                 lng, lat = float(bank.proto_lnglat[pid, 0]), float(bank.proto_lnglat[pid, 1])
             else:
                 idx = torch.as_tensor(bank.member_idx[int(bank.member_off[pid]):int(bank.member_off[pid + 1])])
-                d = torch.cdist(train_emb[idx], emb[None]).flatten()
+                d = torch.cdist(torch.as_tensor(train_emb[idx.numpy() if not torch.is_tensor(train_emb) else idx]), emb[None]).flatten()
                 mi = int(idx[int(torch.argmax(d))])
                 lng, lat = float(bank.train_lnglat[mi, 0]), float(bank.train_lnglat[mi, 1])
             top_preds.append([lng, lat])

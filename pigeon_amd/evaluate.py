@@ -1,0 +1,161 @@
+"""Evaluation entry points behind the reference's names: `evaluate()` (evaluation/evaluate.py:10-85) builds
+SuperGuessr + ProtoRefiner, `evaluate_model()` (training/train_eval_loop.py:35-161) runs the batch loop
+`model(**data)` -> `refiner(...)` -> collect.  Plus `PanoramaPipeline`, the data-parallel step the benchmark
+times: ViT + head on the local shard, ONE all-gather of embeddings / candidates, refinement.
+
+Out of scope here (SURVEY.md section 2 rows 14,17): TensorBoard writers, the geopandas country metrics; the
+haversine-based distance metrics (evaluation/metrics.py:90-137 via haversine_np) are provided.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+
+from .config import EVAL_BATCH_SIZE_PER_GPU
+from .distributed import Communicator
+from .geo_utils import haversine_np
+from .proto_refiner import ProtoRefiner
+from .super_guessr import SuperGuessr
+
+logger = logging.getLogger('train')
+
+
+def distance_metrics(preds: np.ndarray, labels: np.ndarray) -> Dict[str, float]:
+    """km-error statistics + %-within-radius + GeoGuessr score (reference evaluation/metrics.py:90-137,162-181;
+    DECAY_CONSTANT 1492.7, config.py:50)."""
+    km = haversine_np(np.asarray(labels, dtype=np.float64), np.asarray(preds, dtype=np.float64))
+    out = {'Mean_km_error': float(km.mean()), 'Median_km_error': float(np.median(km)),
+           'Mean_geoguessr_score': float((5000 * np.exp(-km / 1492.7)).mean())}
+    for name, r in (('Street_1km', 1), ('City_25km', 25), ('Region_200km', 200), ('Country_750km', 750),
+                    ('Continent_2500km', 2500)):
+        out[f'Percentage_{name}'] = float((km <= r).mean() * 100)
+    return out
+
+
+def evaluate_model(model: SuperGuessr, dataset, metrics: Optional[Callable] = None, train_args=None,
+                   refiner: Optional[ProtoRefiner] = None, yfcc: bool = False, writer=None, step: int = 0,
+                   batch_size: Optional[int] = None, num_workers: int = 0):
+    """reference training/train_eval_loop.py:35-161 (eval loop :77-112).
+
+    dataset items are dicts of forward() keyword arguments (pixel_values | embedding, labels, labels_clf, ...).
+    Returns the dict of concatenated numpy results; if `metrics` is given it is called with the same 11-tuple
+    the reference builds (:138-140) and its dict is merged in.
+    """
+    from torch.utils.data import DataLoader
+    logger.warning('Starting evaluation ...')
+    if batch_size is None:
+        batch_size = getattr(train_args, 'per_device_eval_batch_size', EVAL_BATCH_SIZE_PER_GPU)
+    eval_data = DataLoader(dataset, batch_size, shuffle=False, pin_memory=False, num_workers=num_workers)
+    model.eval()
+    if refiner is not None:
+        refiner.eval()
+    combined_preds, combined_geocell_preds, combined_top5_cells, combined_top5_probs = [], [], [], []
+    combined_loss = 0.0
+    n_seen = 0
+    with torch.no_grad():
+        for data in eval_data:
+            outputs = model(**data)                                               # :80
+            if outputs.loss_clf is not None:
+                combined_loss += float(outputs.loss_clf) * len(data)              # :81-82 (`len(data)` as the reference)
+            if refiner is not None:                                               # :98-103
+                _, preds_LLH, _ = refiner(outputs.embedding, initial_preds=outputs.preds_LLH,
+                                          candidate_cells=outputs.top5_geocells.indices,
+                                          candidate_probs=outputs.top5_geocells.values)
+                combined_preds.append(preds_LLH.cpu().detach().numpy())
+            else:
+                combined_preds.append(outputs.preds_LLH.cpu().detach().numpy())
+            combined_geocell_preds.append(outputs.preds_geocell.cpu().detach().numpy())  # :106-112
+            top5 = outputs.top5_geocells
+            combined_top5_cells.append(top5.indices.cpu().detach().numpy())
+            combined_top5_probs.append(top5.values.cpu().detach().numpy())
+            n_seen += outputs.preds_geocell.shape[0]
+    preds = np.concatenate(combined_preds, axis=0)
+    preds_geocells = np.concatenate(combined_geocell_preds, axis=0)
+    top5_geocells = np.concatenate(combined_top5_cells, axis=0)
+    results = dict(preds=preds, preds_geocells=preds_geocells, top5_geocells=top5_geocells,
+                   top5_probs=np.concatenate(combined_top5_probs, axis=0), loss_clf=combined_loss / max(n_seen, 1))
+    try:
+        labels_lla = np.asarray(dataset['labels'])
+        labels_cell = np.asarray(dataset['labels_clf'])
+        results.update(distance_metrics(preds, labels_lla))
+        results['Geocell_accuracy'] = float((preds_geocells == labels_cell).mean())
+        if metrics is not None:
+            results.update(metrics((preds, preds_geocells, None, None, None, top5_geocells,
+                                    labels_lla, labels_cell, None, None, None)))
+    except (KeyError, TypeError, IndexError):
+        pass                                                                      # dataset without label columns
+    model.train()
+    logger.warning('Back to training ...')
+    return results
+
+
+def evaluate(model: str, dataset, yfcc: bool, landmarks: bool, base_model=None, heading: bool = False,
+             refine: bool = True, geocell_path: Optional[str] = None, proto_path: Optional[str] = None,
+             dataset_path=None, bank=None, head_state: Optional[str] = None):
+    """reference evaluation/evaluate.py:10-85.
+
+    `base_model`: a `HipCLIPVisionModel` (or None to evaluate on precomputed embeddings).  `model` is the path of
+    the head checkpoint (`full_model.load_state(model)`, :46); evaluate() uses the reference's two refiner
+    parameter sets (:73-80): first build -> ProtoRefiner(20, False, 10000, temperature=1); cached prototypes ->
+    ProtoRefiner(40, False, 100000, temperature=0.6).
+    """
+    import os
+    from . import config as cfg
+    full_model = SuperGuessr(base_model, panorama=True, hierarchical=False, multi_task=False, heading=heading,
+                             freeze_base=True, yfcc=yfcc, num_candidates=50, geocell_path=geocell_path)
+    if head_state and os.path.exists(head_state):
+        full_model.load_state(head_state)
+    if model and os.path.exists(model):
+        full_model.load_state(model)
+    full_model.to('cuda')
+    print(full_model)
+    refiner = None
+    if refine:
+        proto_model_path = cfg.PROTO_MODEL_YFCC_PATH if yfcc else cfg.PROTO_MODEL_PATH
+        proto_path = proto_path or (cfg.PROTO_PATH_YFCC if yfcc else cfg.PROTO_PATH)
+        dataset_path = dataset_path or (cfg.DATASET_PATH_YFCC if yfcc else cfg.DATASET_PATH)
+        if landmarks:
+            proto_path, proto_model_path = cfg.PROTO_PATH_LANDMARKS, cfg.PROTO_MODEL_LANDMARKS_PATH
+            dataset_path = [cfg.DATASET_PATH_YFCC, cfg.DATASET_PATH_LANDMARKS]
+        packed = proto_model_path + '.npz'
+        if bank is not None:
+            refiner = ProtoRefiner(40, False, 100000, bank=bank, temperature=0.6)
+        elif os.path.exists(packed):                                              # cached bank (:65-69)
+            refiner = ProtoRefiner(40, False, 100000, bank=packed, temperature=0.6, verbose=False)
+        else:                                                                     # first build (:72-75)
+            refiner = ProtoRefiner(20, False, 10000, proto_path=proto_path, dataset_path=dataset_path, temperature=1)
+            os.makedirs(os.path.dirname(packed) or '.', exist_ok=True)
+            refiner.host_bank.save(packed)
+        print(refiner)
+    return evaluate_model(full_model, dataset, None, None, refiner)
+
+
+class PanoramaPipeline:
+    """The data-parallel inference step (BASELINE.json configs[3]/[4]): every rank runs the ViT + geocell head on
+    its shard of panoramas, ONE all-gather moves per-image embeddings (B,4,1024) f32 + top-k candidates + initial
+    predictions + sample indices to every rank (the reference's accelerator.gather, preprocessing/embed.py:36-37),
+    then each rank refines its 1/W slice of the gathered batch against its replica of the prototype bank."""
+
+    def __init__(self, model: SuperGuessr, refiner: Optional[ProtoRefiner], comm: Optional[Communicator] = None):
+        self.model, self.refiner = model, refiner
+        self.comm = comm or Communicator()
+
+    @torch.no_grad()
+    def step(self, pixel_values: torch.Tensor, index: Optional[torch.Tensor] = None):
+        out = self.model(pixel_values=pixel_values, labels_clf=None)
+        B = out.preds_geocell.shape[0]
+        if index is None:
+            index = torch.arange(B, device=out.embedding.device) + self.comm.rank * B
+        emb, topi, topv, llh, idx = self.comm.gather_many([out.embedding, out.top5_geocells.indices,
+                                                           out.top5_geocells.values, out.preds_LLH, index.to(out.embedding.device)])
+        res = dict(embedding=emb, index=idx, preds_geocell=topi[:, 0], preds_LLH=llh)
+        if self.refiner is not None:
+            r, W = self.comm.rank, self.comm.world_size
+            sl = slice(r * B, (r + 1) * B)                                        # this rank's slice of the gathered batch
+            _, ref_llh, ref_cell = self.refiner(emb[sl], initial_preds=llh[sl], candidate_cells=topi[sl],
+                                                candidate_probs=topv[sl], quiet=True)
+            res['refined_LLH'], res['refined_geocell'] = ref_llh, ref_cell
+        return res

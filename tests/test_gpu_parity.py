@@ -1,0 +1,367 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI behind the reference's
+class surface, against (a) the golden vectors produced by the REAL reference (tests/golden, oracle/make_golden.py)
+and (b) the CPU oracle on fresh seeded inputs.
+
+Tolerances (BASELINE.json north_star): geocell argmax / top-k indices / refined geocell bit-exact, refined (lng,lat)
+exact (they are picked from a discrete set), embeddings within 1e-3 relative (||a-b||/||b||, whole tensor and worst
+row).  The MFMA operands are fp16 (default); the bf16 variant is checked against its own measured floor.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+EMB_TOL = 1e-3          # north_star: embeddings within 1e-3 relative
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def env():
+    from pigeon_amd import _lib, hip_ops, synthetic
+    from oracle import pigeon_oracle as orc
+    _lib.require_gpu()                       # fails loudly if the HIP library / GPU is missing -- no fallback
+    return dict(lib=_lib, ops=hip_ops, syn=synthetic, orc=orc)
+
+
+@pytest.fixture(scope="module")
+def vit2(env):
+    from pigeon_amd.clip_embedder import HipCLIPVisionModel
+    sd = env["syn"].make_vit_weights(seed=11, layers=2, affine_jitter=True)
+    return sd, HipCLIPVisionModel(sd, layers=2).to(DEV)
+
+
+@pytest.fixture(scope="module")
+def vit24(env):
+    from pigeon_amd.clip_embedder import HipCLIPVisionModel
+    sd = env["syn"].make_vit_weights(seed=0, layers=24)
+    return sd, HipCLIPVisionModel(sd, layers=24).to(DEV)
+
+
+def _gold(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _geocells_csv(tmp_path, C, seed=0):
+    from pigeon_amd import synthetic
+    p = os.path.join(str(tmp_path), f"geocells_{C}.csv")
+    synthetic.write_geocell_csv(p, synthetic.make_geocells(C, seed=seed))
+    return p
+
+
+# ------------------------------------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("variant", [0, 1, 5])
+def test_gemm_epilogues(env, dt, variant):
+    ops, L = env["ops"], env["lib"]
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 1154 + 37, 512, 320                       # ragged M tail, K = 5 tiles
+    A = torch.randn((M, K), generator=g).to(dt).to(DEV)
+    W = (torch.randn((N, K), generator=g) * 0.05).to(dt).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    acc = (A.float().cpu() @ W.float().cpu().T)         # plain fp32 reference on the same rounded operands
+    out = torch.zeros((M, N), device=DEV)
+    ops.gemm16(A, W, bias, out, L.EPI_F32, variant=variant)
+    assert torch.allclose(out.cpu(), acc + bias.cpu(), rtol=1e-5, atol=1e-4)
+    o16 = torch.zeros((M, N), dtype=dt, device=DEV)
+    ops.gemm16(A, W, bias, o16, L.EPI_QKV, qscale=0.25, qcols=256, variant=variant)
+    ref = acc + bias.cpu()
+    ref[:, :256] *= 0.25
+    ulp = 2.0 ** (-8 if dt == torch.bfloat16 else -11)
+    assert (o16.float().cpu() - ref).abs().max() <= 2 * ref.abs().max() * ulp
+    ops.gemm16(A, W, bias, o16, L.EPI_GELU, variant=variant)
+    y = acc + bias.cpu()
+    ref = y * torch.sigmoid(1.702 * y)
+    assert (o16.float().cpu() - ref).abs().max() <= 2 * ref.abs().max() * ulp
+    X0 = torch.randn((M, N), generator=g)
+    X = X0.to(DEV).clone()
+    ops.gemm16(A, W, bias, X, L.EPI_RESID, variant=variant)
+    assert torch.allclose(X.cpu(), X0 + acc + bias.cpu(), rtol=1e-5, atol=1e-4)
+
+
+def test_gemm_identity_is_not_transposed(env):
+    ops, L = env["ops"], env["lib"]
+    A = torch.eye(256).to(torch.float16).to(DEV)
+    W = (torch.arange(256)[:, None] * 1.0 + torch.arange(256)[None, :] * 0.001).to(torch.float16).to(DEV)   # asymmetric
+    out = torch.zeros((256, 256), device=DEV)
+    ops.gemm16(A, W, None, out, L.EPI_F32)
+    assert torch.equal(out.cpu(), W.float().cpu().T)
+
+
+def test_rowops(env):
+    ops = env["ops"]
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((1003, 1024), generator=g) * 3 + 0.5
+    gam, bet = torch.randn(1024, generator=g) * 0.1 + 1, torch.randn(1024, generator=g) * 0.1
+    ref = torch.nn.functional.layer_norm(x, (1024,), gam, bet, 1e-5)
+    y = ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV), out_dtype=torch.float32)
+    assert torch.allclose(y.cpu(), ref, rtol=1e-5, atol=2e-6)
+    y16 = ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV), out_dtype=torch.float16)
+    assert (y16.float().cpu() - ref).abs().max() <= 2.0 ** -9 * ref.abs().max()
+    px = torch.randn((3, 3, 336, 336), generator=g)
+    col = ops.im2col(px.to(DEV), torch.float16).cpu()
+    refc = torch.nn.functional.unfold(px, kernel_size=14, stride=14).transpose(1, 2).reshape(3 * 576, 588)
+    assert torch.equal(col[:, :588], refc.to(torch.float16)) and bool((col[:, 588:] == 0).all())
+    h = torch.randn((5, 577, 1024), generator=g)
+    assert torch.allclose(ops.token_mean(h.to(DEV)).cpu(), h.mean(dim=1), rtol=1e-5, atol=1e-6)
+    z = torch.randn(100003, generator=g) * 100
+    assert torch.equal(ops.cast_f32(z.to(DEV), torch.float16).cpu(), z.to(torch.float16))
+    assert torch.equal(ops.cast_f32(z.to(DEV), torch.bfloat16).cpu(), z.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 6e-4), (torch.bfloat16, 4e-3)])
+def test_attention_vs_fp32(env, dt, tol):
+    ops = env["ops"]
+    n = 2
+    g = torch.Generator().manual_seed(21)
+    qkv = torch.randn((n * 577, 3072), generator=g)
+    qkv[:, :1024] *= 0.125 * 1.4426950408889634 * 2.0     # Q carries log2(e)/8 (x2: sharper softmax)
+    qkv[300, 1024:2048] *= 30                              # one spiky key: forces an online-softmax rescale
+    qkv = qkv.to(dt)
+    out = ops.attention(qkv.to(DEV), n).float().cpu()
+    q, k, v = qkv.float().view(n, 577, 3, 16, 64).permute(2, 0, 3, 1, 4)
+    p = torch.softmax(q @ k.transpose(-1, -2) * float(np.log(2.0)), dim=-1)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(n * 577, 1024)
+    assert float((out - ref).norm() / ref.norm()) < tol
+
+
+# ------------------------------------------------------------------------------------------------ ViT vs the reference
+def test_vit2_embedding_matches_reference(env, vit2, golden_dir):
+    from pigeon_amd.clip_embedder import CLIPEmbedding
+    sd, model = vit2
+    g = _gold(golden_dir, "vit2.npz")
+    px = env["syn"].make_pixels(4, seed=77)
+    emb = CLIPEmbedding("unused", device=DEV, clip_model=model)(px)           # reference call surface
+    ref = torch.from_numpy(g["embedding"])
+    assert env["orc"].rel_err(emb.cpu(), ref) < EMB_TOL
+    assert env["orc"].max_rel_err_rows(emb.cpu(), ref) < EMB_TOL
+    hid = model(pixel_values=px).last_hidden_state.cpu()
+    rows = torch.from_numpy(g["lhs_rows"])
+    assert env["orc"].rel_err(hid[:, [0, 1, 2, 288, 575, 576]], rows) < EMB_TOL   # incl. CLS row 0 and last patch 576
+
+
+def test_vit24_embedding_matches_reference(env, vit24, golden_dir):
+    sd, model = vit24
+    g = _gold(golden_dir, "vit24.npz")
+    emb = model.embed(env["syn"].make_pixels(4, seed=1234)).cpu()
+    ref = torch.from_numpy(g["embedding"])
+    assert env["orc"].rel_err(emb, ref) < EMB_TOL
+    assert env["orc"].max_rel_err_rows(emb, ref) < EMB_TOL
+
+
+def test_vit24_stress_weights_match_reference(env, golden_dir):
+    """jittered biases / LayerNorm affine + 2x projection scale: a far less benign numeric regime"""
+    from pigeon_amd.clip_embedder import HipCLIPVisionModel
+    sd = env["syn"].make_vit_weights(seed=5, layers=24, affine_jitter=True, scale=2.0)
+    model = HipCLIPVisionModel(sd, layers=24).to(DEV)
+    g = _gold(golden_dir, "vit24_stress.npz")
+    emb = model.embed(env["syn"].make_pixels(2, seed=99)).cpu()
+    assert env["orc"].rel_err(emb, torch.from_numpy(g["embedding"])) < EMB_TOL
+
+
+def test_vit_bf16_operands_floor(env, vit2, golden_dir):
+    """bf16 MFMA operands are supported; their measured error floor (2e-3, weight rounding survives the token mean,
+    DESIGN.md) is why fp16 is the default."""
+    sd, _ = vit2
+    enc = env["ops"].VitEncoder(sd, mma_dtype="bf16")
+    emb = enc.forward(env["syn"].make_pixels(4, seed=77).to(DEV)).cpu()
+    e = env["orc"].rel_err(emb, torch.from_numpy(_gold(golden_dir, "vit2.npz")["embedding"]))
+    assert 2e-4 < e < 4e-3
+    enc.close()
+
+
+def test_vit_batch_invariance_and_chunking(env, vit2):
+    """Size-independent properties: an image's embedding is BIT-identical whatever batch it rides in (row results do
+    not depend on the tile they land in), across internal chunking, and across repeated runs."""
+    sd, model = vit2
+    px = env["syn"].make_pixels(11, seed=5).to(DEV)
+    full = model.embed(px)
+    assert torch.equal(full, model.embed(px))                                     # deterministic
+    assert torch.equal(full[3:4], model.embed(px[3:4].contiguous()))              # batch of 1
+    assert torch.equal(full[5:9], model.embed(px[5:9].contiguous()))
+    enc = env["ops"].VitEncoder(sd, max_chunk=4)                                   # 11 images = chunks 4+4+3
+    assert torch.equal(full, enc.forward(px))
+    enc.close()
+    e16 = model.embed(px.to(torch.bfloat16))
+    assert env["orc"].rel_err(e16.cpu(), full.cpu()) < 5e-3
+
+
+def test_vit_fresh_inputs_vs_oracle(env, vit2):
+    sd, model = vit2
+    px = env["syn"].make_pixels(3, seed=4242) * 1.7 + 0.3
+    ref = env["orc"].clip_embedding(sd, px)
+    assert env["orc"].rel_err(model.embed(px).cpu(), ref) < EMB_TOL
+
+
+# ------------------------------------------------------------------------------------------------ head
+def test_head_matches_reference(env, golden_dir, tmp_path):
+    from pigeon_amd.super_guessr import SuperGuessr
+    g = _gold(golden_dir, "head.npz")
+    C, seed, B, eseed, k = [int(x) for x in g["meta"]]
+    model = SuperGuessr(None, panorama=True, num_candidates=k, geocell_path=_geocells_csv(tmp_path, C))
+    W, b = env["syn"].make_head_weights(C, seed=seed)
+    with torch.no_grad():
+        model.cell_layer.weight.copy_(W)
+        model.cell_layer.bias.copy_(b)
+    model.to(DEV).eval()
+    gen = torch.Generator().manual_seed(eseed)
+    emb = torch.randn((B, 4, 1024), generator=gen) * 0.7 + 0.1
+    out = model(embedding=emb, labels=torch.zeros(B, 2, dtype=torch.float64), labels_clf=torch.zeros(B, dtype=torch.long))
+    assert np.array_equal(out.preds_geocell.cpu().numpy(), g["preds_geocell"])              # bit-exact argmax
+    assert np.array_equal(out.top5_geocells.indices.cpu().numpy(), g["topk_indices"])       # bit-exact top-50
+    assert np.array_equal(out.preds_LLH.cpu().numpy(), g["preds_LLH"])                      # float64 gather
+    np.testing.assert_allclose(out.top5_geocells.values.cpu().numpy(), g["topk_values"], rtol=1e-5)
+    assert abs(float(out.loss_clf) - float(g["loss_clf"])) < 1e-4
+    v = out.top5_geocells.values
+    assert bool((v[:, :-1] >= v[:, 1:]).all())                                              # sorted descending
+    model.serving = True
+    llh, topk, e = model(embedding=emb, labels_clf=torch.zeros(B, dtype=torch.long))         # serving tuple (:462-466)
+    assert np.array_equal(llh.cpu().numpy(), g["preds_LLH"]) and e.shape == (B, 4, 1024)
+
+
+def test_head_ties_pick_lowest_index(env):
+    ops = env["ops"]
+    C, k = 300, 7
+    W = torch.zeros((C, 1024)); b = torch.zeros(C)
+    b[[17, 5, 200]] = 1.0                                        # exact three-way tie for the maximum
+    cen = torch.arange(2 * C, dtype=torch.float64).view(C, 2)
+    o = ops.head_forward(torch.randn((2, 1, 1024)).to(DEV), W.to(DEV), b.to(DEV), cen.to(DEV), k)
+    assert o["topk_indices"][0, :3].tolist() == [5, 17, 200] and int(o["preds_geocell"][0]) == 5
+    assert o["topk_indices"][0, 3:].tolist() == [0, 1, 2, 3]
+
+
+# ------------------------------------------------------------------------------------------------ refiner
+def _bank(env, g):
+    C, ppc, bseed = [int(x) for x in g["meta"][:3]]
+    return env["syn"].make_bank(C, ppc, seed=bseed, empty_frac=0.05)
+
+
+@pytest.mark.parametrize("tag", ["default", "evaluate", "tight"])
+def test_refiner_matches_reference(env, golden_dir, tag, capsys):
+    from pigeon_amd.proto_refiner import ProtoRefiner
+    g = _gold(golden_dir, "refine.npz")
+    topk, T, mr = g[f"{tag}_params"]
+    ref = ProtoRefiner(topk=int(topk), max_refinement=float(mr), temperature=float(T), bank=_bank(env, g)).eval()
+    loss, llh, cell = ref(torch.from_numpy(g["embedding"]).to(DEV), initial_preds=torch.from_numpy(g["initial_preds"]).to(DEV),
+                          candidate_cells=torch.from_numpy(g["candidate_cells"]).to(DEV),
+                          candidate_probs=torch.from_numpy(g["candidate_probs"]).to(DEV))
+    assert loss is None and llh.dtype == torch.float32 and cell.dtype == torch.int64
+    assert np.array_equal(cell.cpu().numpy(), g[f"{tag}_cell"])
+    assert np.array_equal(llh.cpu().numpy(), g[f"{tag}_LLH"])
+    assert "Changed geocell predictions of" in capsys.readouterr().out                      # reference's status print
+
+
+def test_refiner_3d_embedding_no_probs_and_assert(env, golden_dir):
+    from pigeon_amd.proto_refiner import ProtoRefiner
+    g = _gold(golden_dir, "refine.npz")
+    ref = ProtoRefiner(topk=5, bank=_bank(env, g)).eval()
+    emb = torch.from_numpy(g["embedding"])
+    emb3 = (emb[:, None, :] + torch.tensor([0.1, -0.1, 0.2, -0.2])[None, :, None]).contiguous()
+    _, llh, cell = ref(emb3.to(DEV), initial_preds=torch.from_numpy(g["initial_preds"]).to(DEV),
+                       candidate_cells=torch.from_numpy(g["candidate_cells"]).to(DEV), candidate_probs=None, quiet=True)
+    assert np.array_equal(cell.cpu().numpy(), g["noprobs3d_cell"]) and np.array_equal(llh.cpu().numpy(), g["noprobs3d_LLH"])
+    with pytest.raises(AssertionError):                                                       # proto_refiner.py:135
+        ref(emb.to(DEV), initial_preds=torch.zeros(48, 2, dtype=torch.float64), candidate_cells=torch.zeros((48, 3), dtype=torch.long))
+
+
+def test_refiner_built_from_reference_files(env, golden_dir, tmp_path):
+    """ProtoRefiner(proto_path=CSV, dataset_path=HF dataset dir): the reference's own on-disk inputs."""
+    from pigeon_amd.proto_refiner import ProtoRefiner
+    g = _gold(golden_dir, "refine.npz")
+    bank = _bank(env, g)
+    csv, ds = os.path.join(str(tmp_path), "p.csv"), os.path.join(str(tmp_path), "ds")
+    env["syn"].write_bank_reference_files(bank, csv, ds)
+    ref = ProtoRefiner(topk=5, max_refinement=1000, temperature=1.6, proto_path=csv, dataset_path=ds).eval()
+    assert np.array_equal(ref.host_bank.proto_emb, bank.proto_emb)
+    _, llh, cell = ref(torch.from_numpy(g["embedding"]).to(DEV), initial_preds=torch.from_numpy(g["initial_preds"]).to(DEV),
+                       candidate_cells=torch.from_numpy(g["candidate_cells"]).to(DEV),
+                       candidate_probs=torch.from_numpy(g["candidate_probs"]).to(DEV), quiet=True)
+    assert np.array_equal(cell.cpu().numpy(), g["default_cell"]) and np.array_equal(llh.cpu().numpy(), g["default_LLH"])
+
+
+def test_refiner_full_size_bank_vs_oracle(env):
+    """BASELINE-size bank (10 000 cells x 100 prototypes = 1M x 1024 fp32): parity on a 24-query sample against the
+    oracle, plus the size-independent property that the result does not depend on the other queries in the batch."""
+    ops, syn, orc = env["ops"], env["syn"], env["orc"]
+    bank = syn.make_bank_device(10000, 100, seed=2, device=DEV)
+    dbank = ops.DeviceBank(bank, device=DEV)
+    g = torch.Generator().manual_seed(3)
+    B = 128
+    q = torch.randn((B, 4, 1024), generator=g)
+    cand = torch.randint(0, 10000, (B, 5), generator=g)
+    cp = torch.softmax(torch.randn((B, 5), generator=g), dim=-1)
+    ini = torch.stack([torch.rand(B, generator=g, dtype=torch.float64) * 360 - 180, torch.rand(B, generator=g, dtype=torch.float64) * 180 - 90], 1)
+    llh, cell, choice = ops.refine_forward(dbank, q.to(DEV), ini.to(DEV), cand.to(DEV), cp.to(DEV), 5, 1.6, 1000.0)
+    llh2, cell2, _ = ops.refine_forward(dbank, q[40:64].contiguous().to(DEV), ini[40:64].contiguous().to(DEV),
+                                        cand[40:64].contiguous().to(DEV), cp[40:64].contiguous().to(DEV), 5, 1.6, 1000.0)
+    assert torch.equal(llh[40:64], llh2) and torch.equal(cell[40:64], cell2)
+
+    class Lazy:
+        def __init__(s, t): s.t = t
+        def __getitem__(s, i):
+            i = torch.from_numpy(i) if isinstance(i, np.ndarray) else i
+            return s.t[i.to(DEV) if torch.is_tensor(i) else i].cpu()
+
+    class HB: pass
+    hb = HB()
+    hb.proto_emb, hb.train_emb, hb.train_lnglat = Lazy(bank["proto_emb"]), Lazy(bank["train_emb"]), Lazy(bank["train_lnglat"])
+    for k in ("cell_off", "proto_count", "member_off", "member_idx", "proto_lnglat"):
+        setattr(hb, k, bank[k].cpu().numpy())
+    _, o_llh, o_cell = orc.proto_refiner_forward(hb, q[:24], ini[:24], cand[:24], cp[:24], 5, 1.6, 1000.0)
+    assert torch.equal(cell[:24].cpu(), o_cell)
+    assert np.allclose(llh[:24].cpu().numpy(), o_llh.numpy(), rtol=1e-6, atol=0)
+
+
+# ------------------------------------------------------------------------------------------------ end to end
+def test_pipeline_matches_reference(env, vit2, golden_dir, tmp_path):
+    """pixels -> SuperGuessr(ViT + head) -> ProtoRefiner, against the real reference's outputs (pipeline.npz)."""
+    from pigeon_amd.super_guessr import SuperGuessr
+    from pigeon_amd.proto_refiner import ProtoRefiner
+    sd, vit = vit2
+    g = _gold(golden_dir, "pipeline.npz")
+    wseed, layers, jitter, n, pseed, C, ppc, bseed, hseed = [int(x) for x in g["meta"]]
+    model = SuperGuessr(vit, panorama=True, hierarchical=False, multi_task=False, heading=False, freeze_base=True,
+                        num_candidates=50, geocell_path=_geocells_csv(tmp_path, C))
+    W, b = env["syn"].make_head_weights(C, seed=hseed)
+    with torch.no_grad():
+        model.cell_layer.weight.copy_(W * 8)
+        model.cell_layer.bias.copy_(b)
+    model.to(DEV).eval()
+    px = env["syn"].make_pixels(n, seed=pseed, panorama=True)
+    out = model(pixel_values=px, labels=torch.zeros(2, 2, dtype=torch.float64), labels_clf=torch.zeros(2, dtype=torch.long))
+    assert env["orc"].rel_err(out.embedding.cpu(), torch.from_numpy(g["embedding"])) < EMB_TOL
+    assert np.array_equal(out.preds_geocell.cpu().numpy(), g["preds_geocell"])
+    assert np.array_equal(out.preds_LLH.cpu().numpy(), g["preds_LLH"])
+    # top-k ORDER deep in the tail may swap where the reference's own margins are below the fp16 error; the first 5
+    # (the ones refinement consumes) must match
+    assert np.array_equal(out.top5_geocells.indices.cpu().numpy()[:, :5], g["topk_indices"][:, :5])
+    refiner = ProtoRefiner(topk=5, max_refinement=1000, temperature=1.6,
+                           bank=env["syn"].make_bank(C, ppc, seed=bseed, empty_frac=0.05)).eval()
+    _, llh, cell = refiner(out.embedding, initial_preds=out.preds_LLH, candidate_cells=out.top5_geocells.indices,
+                           candidate_probs=out.top5_geocells.values, quiet=True)
+    assert np.array_equal(cell.cpu().numpy(), g["refined_cell"])
+    assert np.array_equal(llh.cpu().numpy(), g["refined_LLH"])
+
+
+def test_full_size_step_properties(env, vit24, tmp_path):
+    """BASELINE configs[2] size (128 panoramas = 512 images, C = 10 000): size-independent checks."""
+    from pigeon_amd.super_guessr import SuperGuessr
+    sd, vit = vit24
+    C = 10000
+    model = SuperGuessr(vit, panorama=True, freeze_base=True, num_candidates=5, geocell_path=_geocells_csv(tmp_path, C))
+    W, b = env["syn"].make_head_weights(C, seed=0)
+    with torch.no_grad():
+        model.cell_layer.weight.copy_(W); model.cell_layer.bias.copy_(b)
+    model.to(DEV).eval()
+    g = torch.Generator(device=DEV).manual_seed(1)
+    px = torch.randn((128, 12, 336, 336), generator=g, device=DEV)
+    out = model(pixel_values=px, labels_clf=None)
+    assert out.embedding.shape == (128, 4, 1024) and bool(torch.isfinite(out.embedding).all())
+    sub = model(pixel_values=px[17:19].contiguous(), labels_clf=None)               # same panoramas, tiny batch
+    assert torch.equal(sub.embedding, out.embedding[17:19]) and torch.equal(sub.preds_geocell, out.preds_geocell[17:19])
+    assert torch.equal(out.top5_geocells.indices[:, 0], out.preds_geocell)
+    ref = env["orc"].super_guessr_forward(W, b, model.lla_geocells.data.cpu(), 5, embedding=out.embedding.cpu())
+    assert torch.equal(out.preds_geocell.cpu(), ref["preds_geocell"])               # head argmax bit-exact on 128 rows
+    assert torch.equal(out.top5_geocells.indices.cpu(), ref["topk"].indices)
