@@ -164,7 +164,7 @@ class ProtoRefiner(nn.Module):
         self.max_refinement = max_refinement
         self.verbose = verbose
         if bank is not None:
-            host = HostBank.load(bank) if isinstance(bank, str) else bank
+            host = HostBank.load(bank) if isinstance(bank, str) else (HostBank(**bank) if isinstance(bank, dict) else bank)
         elif protos is not None:
             host = bank_from_protos(protos, dataset_path)
         else:

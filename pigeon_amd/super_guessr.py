@@ -8,6 +8,7 @@ Only the inference branch that evaluation/evaluate.py:42-44 constructs is accele
 """
 from __future__ import annotations
 
+import numpy as np
 import pandas as pd
 import torch
 from torch import nn, Tensor
@@ -79,7 +80,7 @@ class SuperGuessr(nn.Module):
     def load_geocells(self, path: str) -> Tensor:
         """reference models/super_guessr.py:162-174: CSV columns lng,lat -> (C,2) float64 Parameter"""
         geo_df = pd.read_csv(path)
-        lla_coords = torch.tensor(geo_df[['lng', 'lat']].values)
+        lla_coords = torch.tensor(np.ascontiguousarray(geo_df[['lng', 'lat']].values))
         return nn.parameter.Parameter(data=lla_coords, requires_grad=False)
 
     def load_state(self, path: str):
