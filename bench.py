@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--protos-per-cell", type=int, default=100)
     ap.add_argument("--topk", type=int, default=5)
     ap.add_argument("--layers", type=int, default=24)
-    ap.add_argument("--cpu-images", type=int, default=8, help="images in the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-images", type=int, default=4, help="images in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-refine", action="store_true")
     return ap.parse_args()
 
@@ -71,7 +71,7 @@ def cpu_baseline(args, vit_sd, model, bank_t, pixels_dev):
     from oracle import pigeon_oracle as orc
     n_img = args.cpu_images
     npano = max(1, n_img // 4)
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))      # torch's CPU GEMMs stop scaling (and regress) beyond ~32 threads at this size
     px = pixels_dev[:npano].cpu()
     W = model.cell_layer.weight.data.cpu()
     b = model.cell_layer.bias.data.cpu()
@@ -97,6 +97,21 @@ def cpu_baseline(args, vit_sd, model, bank_t, pixels_dev):
             "sample": f"{npano} panoramas ({npano * 4} images) through oracle ViT-L/14 fp32 + head + top-{args.topk} refine "
                       f"(torch CPU, {dt:.1f} s, ViT+head {t_vit:.1f} s); linear in images",
             "cpu_model": _cpu_model()}, o
+
+
+def _committed_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (profiles/rNN/traffic.json;
+    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).  Counters cannot be read from inside the process; None if absent."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            if kernel in d and "hbm_bytes_per_launch_corrected" in d[kernel]:
+                return {"bytes_per_launch": d[kernel]["hbm_bytes_per_launch_corrected"],
+                        "algorithmic_bytes": d[kernel].get("algorithmic_bytes"), "source": os.path.relpath(f, ROOT)}
+        except (OSError, ValueError):
+            pass
+    return None
 
 
 def _cpu_model():
@@ -204,7 +219,7 @@ def main():
         "mfma_frac_end_to_end": value * FLOP_PER_IMAGE / (world * PEAK_MFMA),
         "roofline": {"bound": "mfma", "kernel": f"gemm16 {dom}: M={chunk_rows} rows x {GEMM_FLOPS[dom]} FLOP/row per launch",
                      "achieved": achieved, "peak": PEAK_MFMA / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_MFMA / 1e12),
-                     "traffic": None,
+                     "traffic": _committed_traffic(dom),
                      "note": "sustained MFMA ceiling on non-zero data is ~1750 TFLOP/s (DVFS, tools/mfma_peak.hip); peak is the 2.4 GHz datasheet number"},
         "kernels": kernels,
     }
