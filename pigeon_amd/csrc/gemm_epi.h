@@ -1,0 +1,88 @@
+// gemm_epi.h -- argument block and fused epilogue element functions shared by the GEMM kernels
+// (gemm_bf16.hip: one-tile-per-block kernels; gemm_pp.hip: persistent ping-pong kernel).
+#pragma once
+#include "common.h"
+#include "pigeon_internal.h"
+
+#define BK 64
+#define ROWB 128   // bytes per LDS row (BK bf16)
+
+struct GemmArgs {
+    const uint16_t* A; int64_t lda;
+    const uint16_t* W;            // [N][K]
+    const float* bias;            // [N] or null
+    void* out; int64_t ldc;
+    int M, N, K;
+    float qscale; int qcols;
+    const float* aux;             // epi 3: position embedding [577][N]
+    int tilesM, tilesN, ntiles;
+    int gn;                       // N tiles per raster group (see tile_coords)
+};
+
+// gemm_pp.hip: persistent ping-pong kernel (variants 30..39); tilesM/tilesN/ntiles are filled in by the callee
+int pg_gemm_pp_launch(int dtype, GemmArgs g, int epi, int variant, hipStream_t s);
+
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_base_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_base_uniform, 16, 0, 0);
+}
+
+__device__ __forceinline__ float quick_gelu(float v) { return v / (1.0f + __expf(-1.702f * v)); }
+
+// Apply the epilogue to 4 consecutive columns [col, col+4) of one output row (fp32-out epilogues).
+template <int EPI>
+__device__ __forceinline__ void epi_store_f32x4(const GemmArgs& g, int row, int col, f32x4 v, const f32x4& b4) {
+    if (EPI == EPI_RESID) {
+        float* p = (float*)g.out + (int64_t)row * g.ldc + col;
+        f32x4 x = *(const f32x4*)p;
+        x += v + b4;
+        *(f32x4*)p = x;
+    } else if (EPI == EPI_PATCH) {
+        const int img = row / VIT_PATCHES, p = row - img * VIT_PATCHES;
+        float* o = (float*)g.out + ((int64_t)img * VIT_TOKENS + 1 + p) * g.ldc + col;
+        const f32x4 pos = *(const f32x4*)(g.aux + (int64_t)(1 + p) * g.N + col);
+        *(f32x4*)o = v + pos;
+    } else {  // EPI_F32
+        *(f32x4*)((float*)g.out + (int64_t)row * g.ldc + col) = v + b4;
+    }
+}
+
+// 16-bit-out epilogues on 8 consecutive columns.
+template <typename T, int EPI>
+__device__ __forceinline__ void epi_store_bf16x8(const GemmArgs& g, int row, int col, f32x4 lo, f32x4 hi,
+                                                 const f32x4& b_lo, const f32x4& b_hi) {
+    lo += b_lo; hi += b_hi;
+    if (EPI == EPI_QKV) {
+        if (col < g.qcols) { lo *= g.qscale; hi *= g.qscale; }   // qcols is a multiple of 8
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[e] = quick_gelu(lo[e]); hi[e] = quick_gelu(hi[e]); }
+    }
+    u32x4 pk;
+    pk[0] = pack16x2<T>(lo[0], lo[1]); pk[1] = pack16x2<T>(lo[2], lo[3]);
+    pk[2] = pack16x2<T>(hi[0], hi[1]); pk[3] = pack16x2<T>(hi[2], hi[3]);
+    *(u32x4*)((uint16_t*)g.out + (int64_t)row * g.ldc + col) = pk;
+}
+
+template <typename T, int EPI>
+__device__ __forceinline__ void epi_store_scalar(const GemmArgs& g, int row, int col, float v) {
+    if (EPI == EPI_QKV) {
+        if (g.bias) v += g.bias[col];
+        if (col < g.qcols) v *= g.qscale;
+        ((uint16_t*)g.out)[(int64_t)row * g.ldc + col] = T::bits(v);
+    } else if (EPI == EPI_GELU) {
+        v = quick_gelu(v + g.bias[col]);
+        ((uint16_t*)g.out)[(int64_t)row * g.ldc + col] = T::bits(v);
+    } else if (EPI == EPI_RESID) {
+        float* p = (float*)g.out + (int64_t)row * g.ldc + col;
+        *p = *p + (v + g.bias[col]);
+    } else if (EPI == EPI_PATCH) {
+        const int img = row / VIT_PATCHES, p = row - img * VIT_PATCHES;
+        float* o = (float*)g.out + ((int64_t)img * VIT_TOKENS + 1 + p) * g.ldc + col;
+        *o = v + g.aux[(int64_t)(1 + p) * g.N + col];
+    } else {
+        if (g.bias) v += g.bias[col];
+        ((float*)g.out)[(int64_t)row * g.ldc + col] = v;
+    }
+}
+

@@ -1,0 +1,442 @@
+// gemm_pp.hip -- persistent "ping-pong" GEMM: C[M,N] = A[M,K] * W[N,K]^T, fp16/bf16 operands, fp32 MFMA accumulation,
+// the same fused epilogues as gemm_bf16.hip (which stays as the one-tile-per-block reference implementation).
+//
+// Replaces the nn.Linear GEMMs the reference reaches through transformers (modeling_clip.py CLIPAttention.q/k/v/
+// out_proj, CLIPMLP.fc1/fc2, CLIPVisionEmbeddings.patch_embedding) -- SURVEY.md section 2c rows K1,K4,K6,K7,K8.
+//
+// What is different from gemm_bf16.hip (all three address losses measured in profiles/r01):
+//   1. PERSISTENT blocks: one 512-thread block per CU walks tiles L0, L0+G, L0+2G, ...  The first K tile of the NEXT
+//      output tile is DMA'd into LDS stage 0 before the epilogue of the current tile starts, the epilogue's global
+//      stores are never waited for inside the epilogue, and no block launch / prologue latency sits between tiles.
+//      (One-tile-per-block: every CU finishes its mainloop at the same moment, all 256 epilogues hit HBM together and
+//      nothing computes meanwhile: ~8 us of a ~34 us tile.)
+//   2. PING-PONG phases: the 8 waves form two groups (waves 0-3 / 4-7 = the two waves of every SIMD).  A k-step is
+//      {LOAD phase: 6 ds_read_b128 fragments + this k-step's share of the next K tile's DMA; barrier; MFMA phase:
+//      8 x v_mfma_f32_32x32x16 at raised priority; barrier}.  Group 1 runs one barrier behind group 0, so on every SIMD
+//      one wave is in its MFMA phase while the other is in its LOAD phase: the matrix pipe always has exactly one
+//      wave feeding it and LDS/DMA issue stalls never sit in front of an MFMA (cdna guide T3/T4/T5).
+//   3. DMA through buffer descriptors (buffer_load_dwordx4 ... lds): one 32-bit VGPR offset per DMA that never
+//      changes, the K advance is an SGPR offset, the M tail is handled by the descriptor's bounds check (rows past
+//      M read as zero) -- no 64-bit per-lane address arithmetic in the loop.
+//
+// LDS map (160 KB): stage 0 [0,64K) | stage 1 [64K,128K) | spare [128K,160K).  A stage holds 256 A rows then 256 W rows
+// of one K tile (BK = 64 -> 128-byte rows), lane-linear as the DMA requires, 16-byte chunk c of row r stored at
+// chunk c ^ ((r>>1)&7) (swizzle applied on the source address) so ds_read_b128 fragments are conflict-free.
+// K/64 is even for every GEMM of the model (16, 64, 10), so the last K tile of an output tile always sits in stage 1:
+// the epilogue's transpose slabs (8 waves x 8.5 KB) live in [64K, 132K) while stage 0 already receives the next tile.
+//
+// Synchronisation (B_n = n-th s_barrier of an output tile; S = 4*K/64 k-steps):
+//   group 0: LOAD(s) in (B_2s, B_2s+1), MFMA(s) in (B_2s+1, B_2s+2);  group 1: one interval later.
+//   RAW  K tile t+1 is first read by group 0 after B_8t+8; every wave waits vmcnt(0) for its own DMAs of that tile at
+//        the end of LOAD(4t+3): group 0 before B_8t+7, group 1 before B_8t+8.
+//   WAR  stage of K tile t-1 is last read in group 1's LOAD(4t-1), which ends with lgkmcnt(0) before B_8t; the first
+//        DMA into it is group 0's LOAD(4t), after B_8t.
+//   Both groups execute 2S+2 barriers per tile (group 1: one extra after B_0, group 0: one extra at the end).
+#include "gemm_epi.h"
+
+namespace {
+
+constexpr int PP_BM = 256, PP_BN = 256;
+constexpr int PP_STAGE = (PP_BM + PP_BN) * ROWB;          // 64 KB
+constexpr int PP_W_OFF = PP_BM * ROWB;                     // W rows start 32 KB into a stage
+constexpr int PP_SLAB_OFF = PP_STAGE;                      // epilogue slabs overlay stage 1 (+ spare)
+constexpr int PP_SLAB_ROWF = 64 + 4;                       // padded slab row, floats
+constexpr int PP_SLAB_BYTES = 32 * PP_SLAB_ROWF * 4;       // 8704 B per wave
+constexpr int PP_LDS = 160 * 1024;
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_uniform, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_wave_uniform, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+
+struct TileCtx {
+    __amdgpu_buffer_rsrc_t ra, rw;
+    int m0, n0;
+};
+
+__device__ __forceinline__ TileCtx make_tile(const GemmArgs& g, int L) {
+    TileCtx c;
+    const int tm = L / g.tilesN, tn = L - tm * g.tilesN;
+    c.m0 = tm * PP_BM; c.n0 = tn * PP_BN;
+    const int rows = min(PP_BM, g.M - c.m0);
+    c.ra = make_rsrc(g.A + (int64_t)c.m0 * g.lda, (uint32_t)rows * (uint32_t)g.lda * 2u);
+    c.rw = make_rsrc(g.W + (int64_t)c.n0 * g.K, (uint32_t)PP_BN * (uint32_t)g.K * 2u);
+    return c;
+}
+
+// DMA d of a K tile: d 0..3 = this wave's four 8-row groups of A, d 4..7 = of W.
+template <int FROM, int CNT>
+__device__ __forceinline__ void issue_dma(const TileCtx& c, char* stage, int wave, const int (&voffA)[4], const int (&voffW)[4],
+                                          int soff) {
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        if (d < FROM || d >= FROM + CNT) continue;
+        if (d < 4) dma16(c.ra, stage + (wave + 8 * d) * 8 * ROWB, voffA[d], soff);
+        else dma16(c.rw, stage + PP_W_OFF + (wave + 8 * (d - 4)) * 8 * ROWB, voffW[d - 4], soff);
+    }
+}
+
+template <typename T> struct Frag { typename T::v8 a[4], b[2]; };
+
+template <typename T>
+__device__ __forceinline__ void load_frag(Frag<T>& f, const char* sa, const char* sb, int xo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f.a[i] = *(const typename T::v8*)(sa + i * 32 * ROWB + xo);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) f.b[j] = *(const typename T::v8*)(sb + j * 32 * ROWB + xo);
+}
+
+// swapped operands (weights as "A"): D[n][m] -> a lane owns output row m = lane&31 and column quads
+template <typename T>
+__device__ __forceinline__ void mma8(f32x16 (&acc)[4][2], const Frag<T>& f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma(f.b[j], f.a[i], acc[i][j]);
+}
+
+__device__ __forceinline__ void wait_lgkm0() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void wait_vm0() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void raw_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// One K tile in ping-pong form.  D0..D2 = number of this wave's 8 DMAs issued in LOAD phases 0..2 (rest in phase 3).
+template <typename T, int D0, int D1, int D2>
+__device__ __forceinline__ void ktile_pp(f32x16 (&acc)[4][2], const char* cur, char* nxt, int a_base, int b_base,
+                                         const int (&xoff)[4], const TileCtx& c, int wave, const int (&voffA)[4],
+                                         const int (&voffW)[4], int soff_next, bool has_next) {
+    constexpr int D3 = 8 - D0 - D1 - D2;
+    static_assert(D3 >= 0, "DMA schedule");
+    Frag<T> f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        load_frag<T>(f, cur + a_base, cur + b_base, xoff[kk]);
+        if (has_next) {
+            if (kk == 0) issue_dma<0, D0>(c, nxt, wave, voffA, voffW, soff_next);
+            if (kk == 1) issue_dma<D0, D1>(c, nxt, wave, voffA, voffW, soff_next);
+            if (kk == 2) issue_dma<D0 + D1, D2>(c, nxt, wave, voffA, voffW, soff_next);
+            if (kk == 3) issue_dma<D0 + D1 + D2, D3>(c, nxt, wave, voffA, voffW, soff_next);
+        }
+        if (kk == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_lgkm0();
+        raw_barrier();
+        __builtin_amdgcn_s_setprio(1);
+        mma8<T>(acc, f);
+        __builtin_amdgcn_s_setprio(0);
+        raw_barrier();
+    }
+}
+
+// Free-running form of the same K tile (MODE 0): one barrier per K tile (taken by the caller), fragments double
+// buffered in registers, the DMAs of the next tile spread 2 per k-step between the MFMA groups (= gemm_bf16 variant 8).
+template <typename T>
+__device__ __forceinline__ void ktile_free(f32x16 (&acc)[4][2], const char* cur, char* nxt, int a_base, int b_base,
+                                           const int (&xoff)[4], const TileCtx& c, int wave, const int (&voffA)[4],
+                                           const int (&voffW)[4], int soff_next, bool has_next) {
+    Frag<T> f[2];
+    load_frag<T>(f[0], cur + a_base, cur + b_base, xoff[0]);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) load_frag<T>(f[(kk + 1) & 1], cur + a_base, cur + b_base, xoff[kk < 3 ? kk + 1 : 3]);
+        if (has_next) {
+            if (kk == 0) issue_dma<0, 2>(c, nxt, wave, voffA, voffW, soff_next);
+            if (kk == 1) issue_dma<2, 2>(c, nxt, wave, voffA, voffW, soff_next);
+            if (kk == 2) issue_dma<4, 2>(c, nxt, wave, voffA, voffW, soff_next);
+            if (kk == 3) issue_dma<6, 2>(c, nxt, wave, voffA, voffW, soff_next);
+        }
+        __builtin_amdgcn_s_setprio(1);
+        mma8<T>(acc, f[kk & 1]);
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// ---- epilogue: per wave, four 32-row x 64-column fp32 slabs transposed through LDS -------------------------------
+// A lane owns row m = lane&31 of the wave's 32x32 MFMA blocks; the slab turns that into row-major 16-byte pieces so a
+// wave-wide store covers whole 128-byte (16-bit out) / 256-byte (fp32 out) row segments.  The slab is private to the
+// wave, so only wave-level ordering is needed between its ds_writes and ds_reads (no block barrier).
+__device__ __forceinline__ void wave_lds_fence() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Bias of the lane's row-major columns, fetched at the START of an output tile (before the K loop) and forced to
+// retire there: a global_load that is still "pending" in the compiler's scoreboard when the epilogue runs would make
+// it insert vmcnt(0) in front of every use -- which also drains the epilogue's own stores and the next tile's DMA.
+template <int EPI> struct EpiBias { f32x4 lo, hi; };
+
+template <int EPI>
+__device__ __forceinline__ void load_bias(EpiBias<EPI>& b, const GemmArgs& g, int col) {
+    constexpr bool OUT16 = (EPI == EPI_QKV || EPI == EPI_GELU);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    b.lo = z; b.hi = z;
+    if (g.bias) {
+        b.lo = *(const f32x4*)(g.bias + col);
+        if (OUT16) b.hi = *(const f32x4*)(g.bias + col + 4);
+    }
+}
+template <int EPI>
+__device__ __forceinline__ void pin_bias(EpiBias<EPI>& b) {
+    asm volatile("" : "+v"(b.lo), "+v"(b.hi));               // a use: the compiler's wait for the loads lands here
+}
+
+template <typename T, int EPI>
+__device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs& g, char* smem, int wave, int lane,
+                                            int row0, int col0, const EpiBias<EPI>& bias) {
+    constexpr bool OUT16 = (EPI == EPI_QKV || EPI == EPI_GELU);
+    constexpr int ROWPF = PP_SLAB_ROWF;
+    constexpr int ESZ = OUT16 ? 2 : 4;
+    constexpr int CPL = 16 / ESZ;                            // columns per lane on the row-major side (16-byte stores)
+    constexpr int LPR = 64 / CPL, RPI = 64 / LPR, ITS = 32 / RPI;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    float* slab = (float*)(smem + PP_SLAB_OFF + wave * PP_SLAB_BYTES);
+    const int rr = lane / LPR, cc = (lane % LPR) * CPL;
+    const int col = col0 + cc;
+
+    if constexpr (EPI == EPI_PATCH) {
+        // rows are re-mapped (image, patch) -> token row and the position embedding is added: generic guarded path
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    *(f32x4*)(slab + lrow * ROWPF + j * 32 + q * 8 + 4 * lhalf) = v;
+                }
+            wave_lds_fence();
+#pragma unroll
+            for (int it = 0; it < ITS; ++it) {
+                const int r = it * RPI + rr;
+                const int row = row0 + i * 32 + r;
+                const f32x4 lo = *(const f32x4*)(slab + r * ROWPF + cc);
+                if (row < g.M) epi_store_f32x4<EPI>(g, row, col, lo, bias.lo);
+            }
+            wave_lds_fence();
+        }
+        return;
+    } else {
+        // Output (and, for EPI_RESID, residual input) through a buffer descriptor based at the wave's (row0, col0):
+        // rows past M fail the bounds check (stores dropped, loads return 0), so there is no exec-mask branching and
+        // no per-store 64-bit address arithmetic: voffset is one VGPR, the slab/iteration row offset is an SGPR.
+        int rv = g.M - row0; rv = rv < 0 ? 0 : (rv > 128 ? 128 : rv);
+        const uint32_t nbytes = rv > 0 ? (uint32_t)(((int64_t)(rv - 1) * g.ldc + 64) * ESZ) : 0u;
+        __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)g.out + ((int64_t)row0 * g.ldc + col0) * ESZ, nbytes);
+        const int voff = (rr * (int)g.ldc + cc) * ESZ;
+        const int rstep = RPI * (int)g.ldc * ESZ;            // bytes between two store iterations
+        const int sstep = 32 * (int)g.ldc * ESZ;             // bytes between two slabs
+
+        // EPI_RESID: the fp32 residual rows are fetched one slab ahead of their use (two register sets)
+        u32x4 xr[2][EPI == EPI_RESID ? ITS : 1];
+        auto fetch_x = [&](int i, int set) {
+            if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+                for (int it = 0; it < ITS; ++it)
+                    xr[set][it] = __builtin_amdgcn_raw_buffer_load_b128(ro, voff, i * sstep + it * rstep, 0);
+            }
+        };
+        fetch_x(0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i + 1 < 4) fetch_x(i + 1, (i + 1) & 1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    *(f32x4*)(slab + lrow * ROWPF + j * 32 + q * 8 + 4 * lhalf) = v;
+                }
+            wave_lds_fence();
+#pragma unroll
+            for (int it = 0; it < ITS; ++it) {
+                const int r = it * RPI + rr;
+                f32x4 lo = *(const f32x4*)(slab + r * ROWPF + cc);
+                u32x4 pk;
+                if constexpr (OUT16) {
+                    f32x4 hi = *(const f32x4*)(slab + r * ROWPF + cc + 4);
+                    lo += bias.lo; hi += bias.hi;
+                    if constexpr (EPI == EPI_QKV) {
+                        if (col < g.qcols) { lo *= g.qscale; hi *= g.qscale; }   // qcols is a multiple of 8
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { lo[e] = quick_gelu(lo[e]); hi[e] = quick_gelu(hi[e]); }
+                    }
+                    pk[0] = pack16x2<T>(lo[0], lo[1]); pk[1] = pack16x2<T>(lo[2], lo[3]);
+                    pk[2] = pack16x2<T>(hi[0], hi[1]); pk[3] = pack16x2<T>(hi[2], hi[3]);
+                } else if constexpr (EPI == EPI_RESID) {
+                    f32x4 x = __builtin_bit_cast(f32x4, xr[i & 1][it]);
+                    x += lo + bias.lo;                       // same expression as epi_store_f32x4<EPI_RESID>
+                    pk = __builtin_bit_cast(u32x4, x);
+                } else {                                     // EPI_F32
+                    pk = __builtin_bit_cast(u32x4, lo + bias.lo);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(pk, ro, voff, i * sstep + it * rstep, 0);
+            }
+            wave_lds_fence();                                // slab reads retired before the next slab overwrites it
+        }
+    }
+}
+
+// MODE 0: free-running (one barrier per K tile).  MODE 1: ping-pong.  MODE 2: ping-pong phases without the stagger
+// (both groups in lock step; A/B arm only).
+template <typename T, int EPI, int MODE, int D0, int D1, int D2>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool follower = (MODE == 1) && (wm == 1);
+
+    // per-lane DMA offsets inside a tile (bytes), constant for the whole kernel
+    int voffA[4], voffW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave + 8 * i) * 8 + (lane >> 3);      // row inside the 256-row operand panel
+        const int c = (lane & 7) ^ ((r >> 1) & 7);           // logical 16-byte chunk this lane must fetch
+        voffA[i] = r * (int)g.lda * 2 + c * 16;
+        voffW[i] = r * g.K * 2 + c * 16;
+    }
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int sw = (lane >> 1) & 7;
+    int xoff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) xoff[kk] = ((kk * 2 + lhalf) ^ sw) << 4;
+    const int a_base = (wm * 128 + lrow) * ROWB;
+    const int b_base = PP_W_OFF + (wn * 64 + lrow) * ROWB;
+
+    constexpr int ECPL = (EPI == EPI_QKV || EPI == EPI_GELU) ? 8 : 4;
+    const int ecc = (lane % (64 / ECPL)) * ECPL;             // the lane's first column inside the wave's 64 on the store side
+    const int nt = g.K / BK;                                 // even (checked on the host)
+    const int nblk = gridDim.x;
+    int L = xcd_remap(blockIdx.x, nblk);
+    if (L >= g.ntiles) return;
+    TileCtx c = make_tile(g, L);
+    issue_dma<0, 8>(c, smem, wave, voffA, voffW, 0);         // K tile 0 of the first output tile -> stage 0
+
+    while (true) {
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        EpiBias<EPI> bias;
+        load_bias<EPI>(bias, g, c.n0 + wn * 64 + ecc);
+        pin_bias<EPI>(bias);
+
+        if constexpr (MODE == 0) {
+            for (int t = 0; t < nt; t += 2) {
+                wait_vm0(); wait_lgkm0(); raw_barrier();
+                ktile_free<T>(acc, smem, smem + PP_STAGE, a_base, b_base, xoff, c, wave, voffA, voffW, (t + 1) * ROWB, true);
+                wait_vm0(); wait_lgkm0(); raw_barrier();
+                ktile_free<T>(acc, smem + PP_STAGE, smem, a_base, b_base, xoff, c, wave, voffA, voffW, (t + 2) * ROWB, t + 2 < nt);
+            }
+            wait_lgkm0(); raw_barrier();
+        } else {
+            wait_vm0(); wait_lgkm0();
+            raw_barrier();                                   // B_0: K tile 0 visible, previous epilogue's slabs released
+            if (follower) raw_barrier();
+            for (int t = 0; t < nt; t += 2) {
+                ktile_pp<T, D0, D1, D2>(acc, smem, smem + PP_STAGE, a_base, b_base, xoff, c, wave, voffA, voffW,
+                                        (t + 1) * ROWB, true);
+                ktile_pp<T, D0, D1, D2>(acc, smem + PP_STAGE, smem, a_base, b_base, xoff, c, wave, voffA, voffW,
+                                        (t + 2) * ROWB, t + 2 < nt);
+            }
+            if (MODE == 1 && !follower) raw_barrier();       // re-align: every wave has left the mainloop
+        }
+
+        const int row0 = c.m0 + wm * 128, col0 = c.n0 + wn * 64;
+        L += nblk;
+        const bool more = L < g.ntiles;
+        if (more) {
+            c = make_tile(g, L);
+            issue_dma<0, 8>(c, smem, wave, voffA, voffW, 0);  // next output tile's K tile 0 -> stage 0 (free since K tile nt-2)
+        }
+        pp_epilogue<T, EPI>(acc, g, smem, wave, lane, row0, col0, bias);
+        if (!more) break;
+    }
+}
+
+template <typename T, int EPI, int MODE, int D0, int D1, int D2>
+int launch_pp(const GemmArgs& g, int nblk, hipStream_t s) {
+    static bool attr_set = false;
+    auto kfn = gemm_pp_kernel<T, EPI, MODE, D0, D1, D2>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+        if (e != hipSuccess) { pg_set_error("gemm_pp: set LDS attr: %s", hipGetErrorString(e)); return PG_EHIP; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(nblk), dim3(512), PP_LDS, s, g);
+    return pg_check_launch("gemm_pp");
+}
+
+template <typename T, int MODE, int D0, int D1, int D2>
+int launch_pp_epi(const GemmArgs& g, int epi, int nblk, hipStream_t s) {
+    switch (epi) {
+        case EPI_QKV: return launch_pp<T, EPI_QKV, MODE, D0, D1, D2>(g, nblk, s);
+        case EPI_GELU: return launch_pp<T, EPI_GELU, MODE, D0, D1, D2>(g, nblk, s);
+        case EPI_RESID: return launch_pp<T, EPI_RESID, MODE, D0, D1, D2>(g, nblk, s);
+        case EPI_PATCH: return launch_pp<T, EPI_PATCH, MODE, D0, D1, D2>(g, nblk, s);
+        case EPI_F32: return launch_pp<T, EPI_F32, MODE, D0, D1, D2>(g, nblk, s);
+        default: pg_set_error("gemm_pp: bad epilogue %d", epi); return PG_EINVAL;
+    }
+}
+
+template <typename T>
+int dispatch_pp(const GemmArgs& g, int epi, int variant, int nblk, hipStream_t s) {
+    switch (variant) {
+        case 30: return launch_pp_epi<T, 0, 2, 2, 2>(g, epi, nblk, s);    // persistent, free-running
+        case 31: return launch_pp_epi<T, 1, 3, 3, 2>(g, epi, nblk, s);    // ping-pong, DMA 3/3/2/0
+        case 32: return launch_pp_epi<T, 1, 2, 2, 2>(g, epi, nblk, s);    // ping-pong, DMA 2/2/2/2
+        case 33: return launch_pp_epi<T, 1, 4, 4, 0>(g, epi, nblk, s);    // ping-pong, DMA 4/4/0/0
+        case 34: return launch_pp_epi<T, 2, 3, 3, 2>(g, epi, nblk, s);    // phases without stagger
+        case 35: return launch_pp_epi<T, 1, 2, 3, 3>(g, epi, nblk, s);    // ping-pong, DMA 2/3/3/0
+        default: pg_set_error("gemm_pp: unknown variant %d", variant); return PG_EINVAL;
+    }
+}
+
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+}  // namespace
+
+int pg_gemm_pp_launch(int dtype, GemmArgs g, int epi, int variant, hipStream_t s) {
+    if (g.N % PP_BN != 0 || g.K % (2 * BK) != 0) {
+        pg_set_error("gemm_pp: N %% 256 or K %% 128 != 0 (N=%d K=%d)", g.N, g.K);
+        return PG_EINVAL;
+    }
+    if ((int64_t)g.lda * 2 * PP_BM >= (1ll << 31) || (int64_t)g.K * 2 * PP_BN >= (1ll << 31)) {
+        pg_set_error("gemm_pp: operand panel exceeds the 2 GB buffer-descriptor range");
+        return PG_EINVAL;
+    }
+    g.tilesM = (g.M + PP_BM - 1) / PP_BM;
+    g.tilesN = g.N / PP_BN;
+    g.ntiles = g.tilesM * g.tilesN;
+    const int nblk = g.ntiles < num_cus() ? g.ntiles : num_cus();
+    if (dtype == PG_DTYPE_F16) return dispatch_pp<T_F16>(g, epi, variant, nblk, s);
+    if (dtype == PG_DTYPE_BF16) return dispatch_pp<T_BF16>(g, epi, variant, nblk, s);
+    pg_set_error("gemm_pp: operand dtype must be PG_DTYPE_F16 or PG_DTYPE_BF16 (got %d)", dtype);
+    return PG_EINVAL;
+}

@@ -1,0 +1,117 @@
+"""Bit-compare GEMM variants against variant 8 (the one-tile-per-block kernel) and time them on the model's shapes.
+
+   python tools/gemm_pp_check.py --variants 30,31,32 [--time] [--images 256]
+
+Every variant runs in its own subprocess under a timeout (a wrong barrier count would hang the GPU), the parent only
+collects the printed lines.  The accumulation order of every output element is identical across variants (same MFMA
+sequence over K), so outputs must be BIT-identical, not merely close.
+"""
+import argparse
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def child(args):
+    import torch
+    from pigeon_amd import _lib, hip_ops
+    L = _lib
+    dev = "cuda"
+    v = args.child
+    dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
+    ok = True
+    if not args.skip_check:
+        # (M, N, K): ragged M tail with one tile per block; > 256 tiles so persistent blocks walk several tiles;
+        # a long-K shape; the patch-embedding shape (K = 640, 10 K tiles)
+        for (M, N, K) in [(1191, 512, 384), (70 * 256 + 19, 1024, 256), (3 * 577, 1024, 4096), (2 * 576, 1024, 640)]:
+            g = torch.Generator().manual_seed(M + N + K)
+            A = torch.randn((M, K), generator=g).to(dt).to(dev)
+            W = (torch.randn((N, K), generator=g) * 0.05).to(dt).to(dev)
+            bias = torch.randn(N, generator=g).to(dev)
+            X0 = torch.randn((M, N), generator=g).to(dev)
+            for epi, name in [(L.EPI_F32, "f32"), (L.EPI_QKV, "qkv"), (L.EPI_GELU, "gelu"), (L.EPI_RESID, "resid")]:
+                outs = []
+                for var in (8, v):
+                    if epi in (L.EPI_QKV, L.EPI_GELU):
+                        o = torch.full((M + 3, N), 7.0, dtype=dt, device=dev)      # 3 guard rows past M
+                    elif epi == L.EPI_RESID:
+                        o = torch.cat([X0, torch.full((3, N), 7.0, device=dev)]).contiguous()
+                    else:
+                        o = torch.full((M + 3, N), 7.0, device=dev)
+                    hip_ops.gemm16(A, W, bias, o, epi, qscale=0.25, qcols=256, variant=var, M=M)
+                    torch.cuda.synchronize()
+                    outs.append(o)
+                same = torch.equal(outs[0], outs[1])
+                guard = bool((outs[1][M:].float() == 7.0).all())
+                if not (same and guard):
+                    ok = False
+                    d = (outs[0].float() - outs[1].float()).abs()
+                    bad = (d > 0).nonzero()
+                    print(f"CHECK v{v} {M}x{N}x{K} {name}: MISMATCH same={same} guard={guard} n_bad={bad.shape[0]} "
+                          f"first={bad[:3].tolist()} maxdiff={d.max().item():.3e}", flush=True)
+            print(f"CHECK v{v} {M}x{N}x{K}: done ok={ok}", flush=True)
+    if args.time:
+        shapes = {"qkv": (3072, 1024, L.EPI_QKV), "out": (1024, 1024, L.EPI_RESID),
+                  "fc1": (4096, 1024, L.EPI_GELU), "fc2": (1024, 4096, L.EPI_RESID)}
+        M = args.images * 577
+        for name, (N, K, epi) in shapes.items():
+            g = torch.Generator().manual_seed(1)
+            A = torch.randn((M, K), generator=g).to(dt).to(dev)
+            W = (torch.randn((N, K), generator=g) * 0.03).to(dt).to(dev)
+            bias = torch.zeros(N, device=dev)
+            out = torch.zeros((M, N), dtype=dt if epi in (L.EPI_QKV, L.EPI_GELU) else torch.float32, device=dev)
+            for _ in range(3):
+                hip_ops.gemm16(A, W, bias, out, epi, qscale=0.18, qcols=1024, variant=v)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(args.rounds):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(args.iters):
+                    hip_ops.gemm16(A, W, bias, out, epi, qscale=0.18, qcols=1024, variant=v)
+                b.record(); torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b) / args.iters)
+            ts.sort()
+            fl = 2.0 * M * N * K
+            print(f"TIME v{v} {name} n={args.images}: median {ts[len(ts)//2]:.3f} ms {fl/(ts[len(ts)//2]*1e-3)/1e12:7.1f} TF/s"
+                  f"   best {ts[0]:.3f} ms {fl/(ts[0]*1e-3)/1e12:7.1f} TF/s", flush=True)
+            del A, W, out
+    print(f"RESULT v{v} ok={ok}", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variants", default="31")
+    ap.add_argument("--child", type=int, default=-1)
+    ap.add_argument("--time", action="store_true")
+    ap.add_argument("--skip-check", action="store_true")
+    ap.add_argument("--images", type=int, default=256)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--timeout", type=int, default=150)
+    args = ap.parse_args()
+    if args.child >= 0:
+        child(args)
+        return
+    for v in [int(x) for x in args.variants.split(",")]:
+        cmd = ["timeout", "-k", "10", str(args.timeout), sys.executable, os.path.abspath(__file__), "--child", str(v),
+               "--images", str(args.images), "--iters", str(args.iters), "--rounds", str(args.rounds), "--dtype", args.dtype]
+        if args.time:
+            cmd.append("--time")
+        if args.skip_check:
+            cmd.append("--skip-check")
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        sys.stdout.write(r.stdout)
+        if r.returncode != 0:
+            print(f"RESULT v{v} FAILED rc={r.returncode} stderr tail: {r.stderr[-600:]}", flush=True)
+            if r.returncode in (124, 137):
+                print("a variant hung: stopping here (the GPU may need a reset)", flush=True)
+                break
+
+
+if __name__ == "__main__":
+    main()
