@@ -60,7 +60,7 @@ typedef struct pg_vit_cfg {
     int32_t heads;        /* must be 16  */
     int32_t mlp;          /* must be 4096 */
     float   ln_eps;       /* 1e-5 */
-    int32_t max_chunk;    /* images processed per internal pass (0 = default 256) */
+    int32_t max_chunk;    /* images processed per internal pass (0 = default 512) */
     int32_t mma_dtype;    /* 16-bit MFMA operand format for weights and activations: PG_DTYPE_F16, PG_DTYPE_BF16, or
                              0 = default (fp16, unless env PIGEON_MMA_DTYPE=bf16).  Same MFMA rate on gfx950; fp16
                              keeps embeddings within 1e-3 of the fp32 reference, bf16 measures 2e-3. */
@@ -166,6 +166,11 @@ int pg_refine_forward(const pg_bank* bank, const float* q, int B, int P, const d
 int pg_op_gemm16(int dtype, const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
                  int M, int N, int K, int epi, float qscale, int qcols, const float* aux,
                  int variant, void* stream);
+/* Same, with an explicit row stride ldw (elements, >= K, multiple of 8) for W: padded strides keep the rows of an
+ * operand panel off the same L2 / memory channels (power-of-two strides camp on a few channels). */
+int pg_op_gemm16_ld(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out,
+                    int64_t ldc, int M, int N, int K, int epi, float qscale, int qcols, const float* aux,
+                    int variant, void* stream);
 /* y = LayerNorm(x) over the last dim (1024), eps, gamma/beta fp32.  x fp32 (rows,1024).
  * out_dtype PG_DTYPE_F16/BF16 -> y 16-bit (rows,1024); PG_DTYPE_F32 -> fp32 (may alias x). */
 int pg_op_layernorm(const float* x, const float* gamma, const float* beta, void* y, int out_dtype,

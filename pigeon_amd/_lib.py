@@ -51,6 +51,7 @@ SIGNATURES = {
     "pg_head_forward": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "pg_refine_forward": (_I, [C.POINTER(Bank), _P, _I, _I, _P, _P, _P, _I, _I, _F, _D, _P, _P, _P, _P, _P]),
     "pg_op_gemm16": (_I, [_I, _P, _I64, _P, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _P, _I, _P]),
+    "pg_op_gemm16_ld": (_I, [_I, _P, _I64, _P, _I64, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _P, _I, _P]),
     "pg_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I64, _F, _P]),
     "pg_op_attention": (_I, [_I, _P, _P, _I, _P]),
     "pg_op_im2col": (_I, [_P, _I, _P, _I, _I, _P]),

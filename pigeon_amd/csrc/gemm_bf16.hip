@@ -194,7 +194,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmArgs g) {
             src[i] = g.A + (int64_t)row * g.lda + c * 8;
         } else {
             const int row = n0 + (r - BM);
-            src[i] = g.W + (int64_t)row * g.K + c * 8;
+            src[i] = g.W + (int64_t)row * g.ldw + c * 8;
         }
         ldsoff[i] = grp * 8 * ROWB;              // wave-uniform LDS base of this DMA
     }
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(512) void gemm16_a3w2_kernel(GemmArgs g) {
         int row = m0 + r;
         row = row < g.M ? row : g.M - 1;
         srcA[i] = g.A + (int64_t)row * g.lda + c * 8;
-        srcW[i] = g.W + (int64_t)(n0 + r) * g.K + c * 8;
+        srcW[i] = g.W + (int64_t)(n0 + r) * g.ldw + c * 8;
         ldsoff[i] = grp * 8 * ROWB;
     }
     const int lrow = lane & 31, lhalf = lane >> 5;
@@ -456,19 +456,19 @@ static int gemm_dispatch(GemmArgs& g, int epi, int variant, hipStream_t s) {
     }
 }
 
-int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
+int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldc,
                    int M, int N, int K, int epi, float qscale, int qcols, const float* aux, int variant,
                    hipStream_t s) {
     if (M <= 0) return PG_OK;
     GemmArgs g;
-    g.A = (const uint16_t*)A; g.lda = lda; g.W = (const uint16_t*)W; g.bias = bias; g.out = out; g.ldc = ldc;
+    g.A = (const uint16_t*)A; g.lda = lda; g.W = (const uint16_t*)W; g.ldw = ldw > 0 ? ldw : K; g.bias = bias; g.out = out; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.qscale = qscale; g.qcols = qcols; g.aux = aux;
     g.tilesM = 0; g.tilesN = 0; g.ntiles = 0; g.gn = 0;
     if ((epi == EPI_GELU || epi == EPI_RESID) && !bias) { pg_set_error("gemm: epilogue %d needs a bias", epi); return PG_EINVAL; }
     if (epi == EPI_PATCH && !aux) { pg_set_error("gemm: patch epilogue needs aux"); return PG_EINVAL; }
-    if ((lda % 8) || (ldc % 8) || (qcols % 8)) { pg_set_error("gemm: lda/ldc/qcols must be multiples of 8"); return PG_EINVAL; }
+    if ((lda % 8) || (ldc % 8) || (qcols % 8) || (g.ldw % 8) || g.ldw < K) { pg_set_error("gemm: lda/ldw/ldc/qcols must be multiples of 8, ldw >= K"); return PG_EINVAL; }
     if (variant == 0) variant = pg_default_gemm_variant();
-    if (variant >= 30 && variant < 40) {
+    if (variant >= 30 && variant < 50) {
         // the persistent kernel needs N % 256 == 0 and an even number of K tiles; everything the model launches qualifies
         if (N % 256 == 0 && K % 128 == 0) return pg_gemm_pp_launch(dtype, g, epi, variant, s);
         variant = 8;

@@ -9,7 +9,7 @@
 
 struct GemmArgs {
     const uint16_t* A; int64_t lda;
-    const uint16_t* W;            // [N][K]
+    const uint16_t* W; int64_t ldw;   // [N][K], row stride ldw elements
     const float* bias;            // [N] or null
     void* out; int64_t ldc;
     int M, N, K;

@@ -58,13 +58,30 @@ struct TileCtx {
     int m0, n0;
 };
 
+// Tile order.  Logical ids are laid out band by band (a band = 32/gn M-panels x all N-panels); inside a band the ids
+// walk gn-wide super-tiles: N fastest inside the super-tile, then M, then the next super-tile.  With gn = tilesN this
+// is plain N-fastest order.  A persistent round gives every XCD 32 consecutive ids, i.e. one (32/gn) x gn super-tile:
+// the unique operand bytes an XCD's L2 must fetch per K step are (32/gn + gn) panels (12 for 8 x 4, against 14.7 /
+// 18 for N-fastest rows of 12 / 16 tiles).
+template <int ABL>
 __device__ __forceinline__ TileCtx make_tile(const GemmArgs& g, int L) {
     TileCtx c;
-    const int tm = L / g.tilesN, tn = L - tm * g.tilesN;
+    const int gmax = g.gn >= 32 ? 1 : 32 / g.gn;
+    const int band_sz = gmax * g.tilesN;
+    const int band = L / band_sz, rem = L - band * band_sz;
+    const int gm = min(gmax, g.tilesM - band * gmax);
+    const int sup = rem / (gm * g.gn), rem2 = rem - sup * gm * g.gn;
+    const int im = rem2 / g.gn, in = rem2 - im * g.gn;
+    const int tm = band * gmax + im, tn = sup * g.gn + in;
     c.m0 = tm * PP_BM; c.n0 = tn * PP_BN;
     const int rows = min(PP_BM, g.M - c.m0);
-    c.ra = make_rsrc(g.A + (int64_t)c.m0 * g.lda, (uint32_t)rows * (uint32_t)g.lda * 2u);
-    c.rw = make_rsrc(g.W + (int64_t)c.n0 * g.K, (uint32_t)PP_BN * (uint32_t)g.K * 2u);
+    if constexpr ((ABL & 2) != 0) {                          // ablation: every tile streams operand panel 0 (all L2 hits)
+        c.ra = make_rsrc(g.A, (uint32_t)PP_BM * (uint32_t)g.lda * 2u);
+        c.rw = make_rsrc(g.W, (uint32_t)PP_BN * (uint32_t)g.ldw * 2u);
+    } else {
+        c.ra = make_rsrc(g.A + (int64_t)c.m0 * g.lda, (uint32_t)rows * (uint32_t)g.lda * 2u);
+        c.rw = make_rsrc(g.W + (int64_t)c.n0 * g.ldw, (uint32_t)PP_BN * (uint32_t)g.ldw * 2u);
+    }
     return c;
 }
 
@@ -114,17 +131,21 @@ __device__ __forceinline__ void raw_barrier() {
 }
 
 // One K tile in ping-pong form.  D0..D2 = number of this wave's 8 DMAs issued in LOAD phases 0..2 (rest in phase 3).
-template <typename T, int D0, int D1, int D2>
+template <typename T, int D0, int D1, int D2, int ABL>
 __device__ __forceinline__ void ktile_pp(f32x16 (&acc)[4][2], const char* cur, char* nxt, int a_base, int b_base,
                                          const int (&xoff)[4], const TileCtx& c, int wave, const int (&voffA)[4],
                                          const int (&voffW)[4], int soff_next, bool has_next) {
     constexpr int D3 = 8 - D0 - D1 - D2;
     static_assert(D3 >= 0, "DMA schedule");
     Frag<T> f;
+    if constexpr ((ABL & 4) != 0) {                          // ablation: fragments read once per K tile (wrong results)
+        load_frag<T>(f, cur + a_base, cur + b_base, xoff[0]);
+        asm volatile("" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]));
+    }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-        load_frag<T>(f, cur + a_base, cur + b_base, xoff[kk]);
-        if (has_next) {
+        if constexpr ((ABL & 4) == 0) load_frag<T>(f, cur + a_base, cur + b_base, xoff[kk]);
+        if (has_next && (ABL & 1) == 0) {                    // ABL&1: ablation, no DMA inside the K loop (wrong results)
             if (kk == 0) issue_dma<0, D0>(c, nxt, wave, voffA, voffW, soff_next);
             if (kk == 1) issue_dma<D0, D1>(c, nxt, wave, voffA, voffW, soff_next);
             if (kk == 2) issue_dma<D0 + D1, D2>(c, nxt, wave, voffA, voffW, soff_next);
@@ -282,7 +303,10 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs&
                 } else {                                     // EPI_F32
                     pk = __builtin_bit_cast(u32x4, lo + bias.lo);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(pk, ro, voff, i * sstep + it * rstep, 0);
+                // The row offset goes into the VGPR offset, NOT the SGPR soffset: with a register soffset hipcc pads no
+                // wait states after a >64-bit buffer store and lets the next VALU overwrite the data registers while the
+                // store is still reading them (measured on gfx950: dword 3 of ~3 % of such stores corrupted).
+                __builtin_amdgcn_raw_buffer_store_b128(pk, ro, voff + (i * sstep + it * rstep), 0, 0);
             }
             wave_lds_fence();                                // slab reads retired before the next slab overwrites it
         }
@@ -291,7 +315,7 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs&
 
 // MODE 0: free-running (one barrier per K tile).  MODE 1: ping-pong.  MODE 2: ping-pong phases without the stagger
 // (both groups in lock step; A/B arm only).
-template <typename T, int EPI, int MODE, int D0, int D1, int D2>
+template <typename T, int EPI, int MODE, int D0, int D1, int D2, int ABL>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -307,7 +331,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         const int r = (wave + 8 * i) * 8 + (lane >> 3);      // row inside the 256-row operand panel
         const int c = (lane & 7) ^ ((r >> 1) & 7);           // logical 16-byte chunk this lane must fetch
         voffA[i] = r * (int)g.lda * 2 + c * 16;
-        voffW[i] = r * g.K * 2 + c * 16;
+        voffW[i] = r * (int)g.ldw * 2 + c * 16;
     }
     const int lrow = lane & 31, lhalf = lane >> 5;
     const int sw = (lane >> 1) & 7;
@@ -323,7 +347,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     const int nblk = gridDim.x;
     int L = xcd_remap(blockIdx.x, nblk);
     if (L >= g.ntiles) return;
-    TileCtx c = make_tile(g, L);
+    TileCtx c = make_tile<ABL>(g, L);
     issue_dma<0, 8>(c, smem, wave, voffA, voffW, 0);         // K tile 0 of the first output tile -> stage 0
 
     while (true) {
@@ -351,9 +375,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
             raw_barrier();                                   // B_0: K tile 0 visible, previous epilogue's slabs released
             if (follower) raw_barrier();
             for (int t = 0; t < nt; t += 2) {
-                ktile_pp<T, D0, D1, D2>(acc, smem, smem + PP_STAGE, a_base, b_base, xoff, c, wave, voffA, voffW,
+                ktile_pp<T, D0, D1, D2, ABL>(acc, smem, smem + PP_STAGE, a_base, b_base, xoff, c, wave, voffA, voffW,
                                         (t + 1) * ROWB, true);
-                ktile_pp<T, D0, D1, D2>(acc, smem + PP_STAGE, smem, a_base, b_base, xoff, c, wave, voffA, voffW,
+                ktile_pp<T, D0, D1, D2, ABL>(acc, smem + PP_STAGE, smem, a_base, b_base, xoff, c, wave, voffA, voffW,
                                         (t + 2) * ROWB, t + 2 < nt);
             }
             if (MODE == 1 && !follower) raw_barrier();       // re-align: every wave has left the mainloop
@@ -363,7 +387,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         L += nblk;
         const bool more = L < g.ntiles;
         if (more) {
-            c = make_tile(g, L);
+            c = make_tile<ABL>(g, L);
             issue_dma<0, 8>(c, smem, wave, voffA, voffW, 0);  // next output tile's K tile 0 -> stage 0 (free since K tile nt-2)
         }
         pp_epilogue<T, EPI>(acc, g, smem, wave, lane, row0, col0, bias);
@@ -371,10 +395,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     }
 }
 
-template <typename T, int EPI, int MODE, int D0, int D1, int D2>
+template <typename T, int EPI, int MODE, int D0, int D1, int D2, int ABL>
 int launch_pp(const GemmArgs& g, int nblk, hipStream_t s) {
     static bool attr_set = false;
-    auto kfn = gemm_pp_kernel<T, EPI, MODE, D0, D1, D2>;
+    auto kfn = gemm_pp_kernel<T, EPI, MODE, D0, D1, D2, ABL>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
         if (e != hipSuccess) { pg_set_error("gemm_pp: set LDS attr: %s", hipGetErrorString(e)); return PG_EHIP; }
@@ -384,27 +408,40 @@ int launch_pp(const GemmArgs& g, int nblk, hipStream_t s) {
     return pg_check_launch("gemm_pp");
 }
 
-template <typename T, int MODE, int D0, int D1, int D2>
+template <typename T, int MODE, int D0, int D1, int D2, int ABL = 0>
 int launch_pp_epi(const GemmArgs& g, int epi, int nblk, hipStream_t s) {
-    switch (epi) {
-        case EPI_QKV: return launch_pp<T, EPI_QKV, MODE, D0, D1, D2>(g, nblk, s);
-        case EPI_GELU: return launch_pp<T, EPI_GELU, MODE, D0, D1, D2>(g, nblk, s);
-        case EPI_RESID: return launch_pp<T, EPI_RESID, MODE, D0, D1, D2>(g, nblk, s);
-        case EPI_PATCH: return launch_pp<T, EPI_PATCH, MODE, D0, D1, D2>(g, nblk, s);
-        case EPI_F32: return launch_pp<T, EPI_F32, MODE, D0, D1, D2>(g, nblk, s);
-        default: pg_set_error("gemm_pp: bad epilogue %d", epi); return PG_EINVAL;
+    if constexpr (ABL != 0) {                                // ablations: timing only, two epilogues are enough
+        switch (epi) {
+            case EPI_QKV: case EPI_GELU: return launch_pp<T, EPI_QKV, MODE, D0, D1, D2, ABL>(g, nblk, s);
+            default: return launch_pp<T, EPI_RESID, MODE, D0, D1, D2, ABL>(g, nblk, s);
+        }
+    } else {
+        switch (epi) {
+            case EPI_QKV: return launch_pp<T, EPI_QKV, MODE, D0, D1, D2, 0>(g, nblk, s);
+            case EPI_GELU: return launch_pp<T, EPI_GELU, MODE, D0, D1, D2, 0>(g, nblk, s);
+            case EPI_RESID: return launch_pp<T, EPI_RESID, MODE, D0, D1, D2, 0>(g, nblk, s);
+            case EPI_PATCH: return launch_pp<T, EPI_PATCH, MODE, D0, D1, D2, 0>(g, nblk, s);
+            case EPI_F32: return launch_pp<T, EPI_F32, MODE, D0, D1, D2, 0>(g, nblk, s);
+            default: pg_set_error("gemm_pp: bad epilogue %d", epi); return PG_EINVAL;
+        }
     }
 }
 
 template <typename T>
-int dispatch_pp(const GemmArgs& g, int epi, int variant, int nblk, hipStream_t s) {
+int dispatch_pp(GemmArgs& g, int epi, int variant, int nblk, hipStream_t s) {
+    g.gn = g.tilesN;                                         // N-fastest raster unless the variant says otherwise
     switch (variant) {
         case 30: return launch_pp_epi<T, 0, 2, 2, 2>(g, epi, nblk, s);    // persistent, free-running
         case 31: return launch_pp_epi<T, 1, 3, 3, 2>(g, epi, nblk, s);    // ping-pong, DMA 3/3/2/0
-        case 32: return launch_pp_epi<T, 1, 2, 2, 2>(g, epi, nblk, s);    // ping-pong, DMA 2/2/2/2
         case 33: return launch_pp_epi<T, 1, 4, 4, 0>(g, epi, nblk, s);    // ping-pong, DMA 4/4/0/0
-        case 34: return launch_pp_epi<T, 2, 3, 3, 2>(g, epi, nblk, s);    // phases without stagger
-        case 35: return launch_pp_epi<T, 1, 2, 3, 3>(g, epi, nblk, s);    // ping-pong, DMA 2/3/3/0
+        case 34: return launch_pp_epi<T, 2, 4, 4, 0>(g, epi, nblk, s);    // phases without stagger
+        case 36: if (g.tilesN % 4 == 0) g.gn = 4; return launch_pp_epi<T, 1, 4, 4, 0>(g, epi, nblk, s);   // 33 + 8x4 super-tile raster
+        case 37: if (g.tilesN % 4 == 0) g.gn = 4; return launch_pp_epi<T, 1, 3, 3, 2>(g, epi, nblk, s);   // 31 + 8x4 super-tile raster
+        // ablations of 33 (timing only, wrong results)
+        case 40: return launch_pp_epi<T, 1, 4, 4, 0, 1>(g, epi, nblk, s);          // no DMA in the K loop
+        case 41: return launch_pp_epi<T, 1, 4, 4, 0, 2>(g, epi, nblk, s);          // every DMA hits panel 0 (L2 resident)
+        case 42: return launch_pp_epi<T, 1, 4, 4, 0, 4>(g, epi, nblk, s);          // no fragment ds_reads
+        case 43: return launch_pp_epi<T, 1, 4, 4, 0, 5>(g, epi, nblk, s);          // MFMA + barriers only
         default: pg_set_error("gemm_pp: unknown variant %d", variant); return PG_EINVAL;
     }
 }
@@ -427,7 +464,7 @@ int pg_gemm_pp_launch(int dtype, GemmArgs g, int epi, int variant, hipStream_t s
         pg_set_error("gemm_pp: N %% 256 or K %% 128 != 0 (N=%d K=%d)", g.N, g.K);
         return PG_EINVAL;
     }
-    if ((int64_t)g.lda * 2 * PP_BM >= (1ll << 31) || (int64_t)g.K * 2 * PP_BN >= (1ll << 31)) {
+    if ((int64_t)g.lda * 2 * PP_BM >= (1ll << 31) || (int64_t)g.ldw * 2 * PP_BN >= (1ll << 31)) {
         pg_set_error("gemm_pp: operand panel exceeds the 2 GB buffer-descriptor range");
         return PG_EINVAL;
     }

@@ -20,7 +20,7 @@ int pg_default_gemm_variant();                   // env PIGEON_GEMM_VARIANT or t
     } while (0)
 
 // gemm_bf16.hip
-int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
+int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldc,
                    int M, int N, int K, int epi, float qscale, int qcols, const float* aux, int variant,
                    hipStream_t s);
 // rowops.hip

@@ -40,8 +40,8 @@ int pg_default_gemm_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("PIGEON_GEMM_VARIANT");
-        v = e ? atoi(e) : 8;
-        if (v <= 0) v = 8;
+        v = e ? atoi(e) : 33;                                // persistent ping-pong kernel (gemm_pp.hip)
+        if (v <= 0) v = 33;
     }
     return v;
 }
@@ -101,7 +101,7 @@ extern "C" int pg_vit_create(pg_vit** out, int device, const pg_vit_cfg* cfg) {
     pg_vit* h = new pg_vit();
     h->cfg = *cfg;
     if (h->cfg.ln_eps <= 0) h->cfg.ln_eps = 1e-5f;
-    if (h->cfg.max_chunk <= 0) h->cfg.max_chunk = 256;
+    if (h->cfg.max_chunk <= 0) h->cfg.max_chunk = 512;
     if (h->cfg.mma_dtype == 0) {
         const char* e = getenv("PIGEON_MMA_DTYPE");
         h->cfg.mma_dtype = (e && (!strcmp(e, "bf16") || !strcmp(e, "BF16"))) ? PG_DTYPE_BF16 : PG_DTYPE_F16;
@@ -263,23 +263,23 @@ static int vit_forward_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n
     const int dt = h->cfg.mma_dtype;
     { ProfScope p(h, s, 7); RC(pg_im2col_launch(pixels, pix_dtype, big, dt, n, s)); }
     { ProfScope p(h, s, 4);
-      RC(pg_gemm_launch(dt, big, VIT_PATCH_KPAD, h->wpatch, nullptr, X, VIT_HIDDEN, n * VIT_PATCHES, VIT_HIDDEN, VIT_PATCH_KPAD,
+      RC(pg_gemm_launch(dt, big, VIT_PATCH_KPAD, h->wpatch, VIT_PATCH_KPAD, nullptr, X, VIT_HIDDEN, n * VIT_PATCHES, VIT_HIDDEN, VIT_PATCH_KPAD,
                         EPI_PATCH, 1.f, 0, h->pos, 0, s)); }
     { ProfScope p(h, s, 6); RC(pg_preln_launch(X, h->cls, h->pos, h->preg, h->preb, M, eps, s)); }
     for (int l = 0; l < h->cfg.layers; ++l) {
         const LayerW& L = h->layers[l];
         { ProfScope p(h, s, 6); RC(pg_layernorm_launch(X, L.ln1g, L.ln1b, Xn, dt, M, eps, s)); }
         { ProfScope p(h, s, 0);
-          RC(pg_gemm_launch(dt, Xn, VIT_HIDDEN, L.wqkv, L.bqkv, big, 3 * VIT_HIDDEN, (int)M, 3 * VIT_HIDDEN, VIT_HIDDEN, EPI_QKV,
+          RC(pg_gemm_launch(dt, Xn, VIT_HIDDEN, L.wqkv, VIT_HIDDEN, L.bqkv, big, 3 * VIT_HIDDEN, (int)M, 3 * VIT_HIDDEN, VIT_HIDDEN, EPI_QKV,
                             kQScale, VIT_HIDDEN, nullptr, 0, s)); }
         { ProfScope p(h, s, 5); RC(pg_attention_launch(dt, big, Xn, n, s)); }
         { ProfScope p(h, s, 1);
-          RC(pg_gemm_launch(dt, Xn, VIT_HIDDEN, L.wo, L.bo, X, VIT_HIDDEN, (int)M, VIT_HIDDEN, VIT_HIDDEN, EPI_RESID, 1.f, 0, nullptr, 0, s)); }
+          RC(pg_gemm_launch(dt, Xn, VIT_HIDDEN, L.wo, VIT_HIDDEN, L.bo, X, VIT_HIDDEN, (int)M, VIT_HIDDEN, VIT_HIDDEN, EPI_RESID, 1.f, 0, nullptr, 0, s)); }
         { ProfScope p(h, s, 6); RC(pg_layernorm_launch(X, L.ln2g, L.ln2b, Xn, dt, M, eps, s)); }
         { ProfScope p(h, s, 2);
-          RC(pg_gemm_launch(dt, Xn, VIT_HIDDEN, L.w1, L.b1, big, VIT_MLP, (int)M, VIT_MLP, VIT_HIDDEN, EPI_GELU, 1.f, 0, nullptr, 0, s)); }
+          RC(pg_gemm_launch(dt, Xn, VIT_HIDDEN, L.w1, VIT_HIDDEN, L.b1, big, VIT_MLP, (int)M, VIT_MLP, VIT_HIDDEN, EPI_GELU, 1.f, 0, nullptr, 0, s)); }
         { ProfScope p(h, s, 3);
-          RC(pg_gemm_launch(dt, big, VIT_MLP, L.w2, L.b2, X, VIT_HIDDEN, (int)M, VIT_HIDDEN, VIT_MLP, EPI_RESID, 1.f, 0, nullptr, 0, s)); }
+          RC(pg_gemm_launch(dt, big, VIT_MLP, L.w2, VIT_MLP, L.b2, X, VIT_HIDDEN, (int)M, VIT_HIDDEN, VIT_MLP, EPI_RESID, 1.f, 0, nullptr, 0, s)); }
     }
     { ProfScope p(h, s, 8); RC(pg_token_mean_launch(X, emb_out, n, s)); }
     if (hidden_out) PG_HIP(hipMemcpyAsync(hidden_out, X, (size_t)M * VIT_HIDDEN * 4, hipMemcpyDeviceToDevice, s));
@@ -358,7 +358,13 @@ extern "C" int pg_op_gemm16(int dtype, const void* A, int64_t lda, const void* W
                             int M, int N, int K, int epi, float qscale, int qcols, const float* aux, int variant,
                             void* stream) {
     if (!A || !W || !out) { pg_set_error("op_gemm16: null argument"); return PG_EINVAL; }
-    return pg_gemm_launch(dtype, A, lda, W, bias, out, ldc, M, N, K, epi, qscale, qcols, aux, variant, (hipStream_t)stream);
+    return pg_gemm_launch(dtype, A, lda, W, K, bias, out, ldc, M, N, K, epi, qscale, qcols, aux, variant, (hipStream_t)stream);
+}
+extern "C" int pg_op_gemm16_ld(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out,
+                               int64_t ldc, int M, int N, int K, int epi, float qscale, int qcols, const float* aux,
+                               int variant, void* stream) {
+    if (!A || !W || !out) { pg_set_error("op_gemm16_ld: null argument"); return PG_EINVAL; }
+    return pg_gemm_launch(dtype, A, lda, W, ldw, bias, out, ldc, M, N, K, epi, qscale, qcols, aux, variant, (hipStream_t)stream);
 }
 extern "C" int pg_op_layernorm(const float* x, const float* gamma, const float* beta, void* y, int out_dtype,
                                int64_t rows, float eps, void* stream) {

@@ -47,12 +47,16 @@ def gemm16(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: 
            qscale: float = 1.0, qcols: int = 0, aux: Optional[torch.Tensor] = None, variant: int = 0,
            M: Optional[int] = None):
     """out (epilogue-dependent) <- A[M,K] x W[N,K]^T, both fp16 or both bf16; see pg_op_gemm16."""
-    _dev(A); _dev(W, A.dtype)
+    for t in (A, W, out):                                  # row-strided views are fine (padded leading dimensions)
+        if not t.is_cuda or t.stride(1) != 1:
+            raise _lib.PigeonHipError("gemm16 expects device tensors with unit inner stride")
+    if W.dtype != A.dtype:
+        raise _lib.PigeonHipError("gemm16: A and W must have the same 16-bit dtype")
     M = A.shape[0] if M is None else M
     K = A.shape[1]
     N = W.shape[0]
-    check(load().pg_op_gemm16(_dt16(A), _p(A), A.stride(0), _p(W), _p(bias), _p(out), out.stride(0), M, N, K, epi,
-                              float(qscale), int(qcols), _p(aux), variant, _stream()), "pg_op_gemm16")
+    check(load().pg_op_gemm16_ld(_dt16(A), _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
+                                 epi, float(qscale), int(qcols), _p(aux), variant, _stream()), "pg_op_gemm16_ld")
     return out
 
 
@@ -136,7 +140,7 @@ class VitEncoder:
         check(lib.pg_vit_finalize(h), "pg_vit_finalize")
         self.mma_dtype = {_lib.PG_DTYPE_F16: "f16", _lib.PG_DTYPE_BF16: "bf16"}[lib.pg_vit_mma_dtype(h)]
         self._ws = None
-        self.max_chunk = max_chunk if max_chunk > 0 else 256
+        self.max_chunk = max_chunk if max_chunk > 0 else 512
 
     def _workspace(self, n: int) -> torch.Tensor:
         need = C.c_size_t()

@@ -53,11 +53,11 @@ def _geocells_csv(tmp_path, C, seed=0):
 
 # ------------------------------------------------------------------------------------------------ kernels
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("variant", [0, 1, 5])
-def test_gemm_epilogues(env, dt, variant):
+@pytest.mark.parametrize("variant,K", [(0, 384), (1, 320), (5, 320), (8, 320), (33, 384), (36, 640), (30, 384)])
+def test_gemm_epilogues(env, dt, variant, K):
     ops, L = env["ops"], env["lib"]
     g = torch.Generator().manual_seed(3)
-    M, N, K = 1154 + 37, 512, 320                       # ragged M tail, K = 5 tiles
+    M, N = 1154 + 37, 512                               # ragged M tail; K = 5 tiles (odd) or 6 / 10 (persistent kernel)
     A = torch.randn((M, K), generator=g).to(dt).to(DEV)
     W = (torch.randn((N, K), generator=g) * 0.05).to(dt).to(DEV)
     bias = torch.randn(N, generator=g).to(DEV)
@@ -79,6 +79,34 @@ def test_gemm_epilogues(env, dt, variant):
     X = X0.to(DEV).clone()
     ops.gemm16(A, W, bias, X, L.EPI_RESID, variant=variant)
     assert torch.allclose(X.cpu(), X0 + acc + bias.cpu(), rtol=1e-5, atol=1e-4)
+
+
+def test_gemm_persistent_many_tiles_bit_identical(env):
+    """More output tiles than CUs (persistent blocks walk several tiles, the next tile's first K tile is prefetched
+    under the epilogue), ragged M, padded leading dimensions: the persistent ping-pong kernel must reproduce the
+    one-tile-per-block kernel BIT for bit (same MFMA order over K), and must not touch rows past M."""
+    ops, L = env["ops"], env["lib"]
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 70 * 256 + 19, 1024, 256
+    A = torch.empty((M, K + 64), dtype=torch.float16, device=DEV)[:, :K]
+    A.copy_(torch.randn((M, K), generator=g).to(torch.float16))
+    W = (torch.randn((N, K), generator=g) * 0.05).to(torch.float16).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    X0 = torch.randn((M, N), generator=g).to(DEV)
+    for epi in (L.EPI_QKV, L.EPI_GELU, L.EPI_RESID, L.EPI_F32):
+        outs = []
+        for var in (8, 33, 36):
+            if epi in (L.EPI_QKV, L.EPI_GELU):
+                o = torch.full((M + 3, N), 7.0, dtype=torch.float16, device=DEV)
+            elif epi == L.EPI_RESID:
+                o = torch.cat([X0, torch.full((3, N), 7.0, device=DEV)]).contiguous()
+            else:
+                o = torch.full((M + 3, N), 7.0, device=DEV)
+            ops.gemm16(A, W, bias, o, epi, qscale=0.25, qcols=256, variant=var, M=M)
+            outs.append(o)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), f"epilogue {epi}"
+        assert bool((outs[1][M:].float() == 7.0).all()) and bool((outs[2][M:].float() == 7.0).all())
 
 
 def test_gemm_identity_is_not_transposed(env):

@@ -59,10 +59,13 @@ def child(args):
         M = args.images * 577
         for name, (N, K, epi) in shapes.items():
             g = torch.Generator().manual_seed(1)
-            A = torch.randn((M, K), generator=g).to(dt).to(dev)
-            W = (torch.randn((N, K), generator=g) * 0.03).to(dt).to(dev)
+            pa, pw, po = args.pad_a, args.pad_w, args.pad_o          # leading-dimension padding in elements
+            A = torch.empty((M, K + pa), dtype=dt, device=dev)[:, :K]
+            A.copy_(torch.randn((M, K), generator=g).to(dt))
+            W = torch.empty((N, K + pw), dtype=dt, device=dev)[:, :K]
+            W.copy_((torch.randn((N, K), generator=g) * 0.03).to(dt))
             bias = torch.zeros(N, device=dev)
-            out = torch.zeros((M, N), dtype=dt if epi in (L.EPI_QKV, L.EPI_GELU) else torch.float32, device=dev)
+            out = torch.zeros((M, N + po), dtype=dt if epi in (L.EPI_QKV, L.EPI_GELU) else torch.float32, device=dev)[:, :N]
             for _ in range(3):
                 hip_ops.gemm16(A, W, bias, out, epi, qscale=0.18, qcols=1024, variant=v)
             torch.cuda.synchronize()
@@ -76,7 +79,7 @@ def child(args):
                 ts.append(a.elapsed_time(b) / args.iters)
             ts.sort()
             fl = 2.0 * M * N * K
-            print(f"TIME v{v} {name} n={args.images}: median {ts[len(ts)//2]:.3f} ms {fl/(ts[len(ts)//2]*1e-3)/1e12:7.1f} TF/s"
+            print(f"TIME v{v} {name} n={args.images} pad={args.pad_a}/{args.pad_w}/{args.pad_o}: median {ts[len(ts)//2]:.3f} ms {fl/(ts[len(ts)//2]*1e-3)/1e12:7.1f} TF/s"
                   f"   best {ts[0]:.3f} ms {fl/(ts[0]*1e-3)/1e12:7.1f} TF/s", flush=True)
             del A, W, out
     print(f"RESULT v{v} ok={ok}", flush=True)
@@ -93,13 +96,17 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--timeout", type=int, default=150)
+    ap.add_argument("--pad-a", type=int, default=0)
+    ap.add_argument("--pad-w", type=int, default=0)
+    ap.add_argument("--pad-o", type=int, default=0)
     args = ap.parse_args()
     if args.child >= 0:
         child(args)
         return
     for v in [int(x) for x in args.variants.split(",")]:
         cmd = ["timeout", "-k", "10", str(args.timeout), sys.executable, os.path.abspath(__file__), "--child", str(v),
-               "--images", str(args.images), "--iters", str(args.iters), "--rounds", str(args.rounds), "--dtype", args.dtype]
+               "--images", str(args.images), "--iters", str(args.iters), "--rounds", str(args.rounds), "--dtype", args.dtype,
+               "--pad-a", str(args.pad_a), "--pad-w", str(args.pad_w), "--pad-o", str(args.pad_o)]
         if args.time:
             cmd.append("--time")
         if args.skip_check:
