@@ -78,7 +78,7 @@ int pg_vit_load_weight(pg_vit* h, const char* name, const void* data, int dtype,
 int pg_vit_finalize(pg_vit* h);
 /* Bytes of DEVICE workspace pg_vit_forward needs for n_images (caller allocates, e.g. a torch uint8 tensor). */
 int pg_vit_workspace_bytes(const pg_vit* h, int n_images, size_t* bytes);
-/* pixels: DEVICE (n_images,3,336,336) contiguous NCHW, fp32 (PG_DTYPE_F32) or bf16.
+/* pixels: DEVICE (n_images,3,336,336) contiguous NCHW, fp32 (PG_DTYPE_F32), fp16 (what pg_prep_forward writes) or bf16.
  * emb_out: DEVICE (n_images,1024) fp32 -- mean over the 577 tokens of last_hidden_state. */
 int pg_vit_forward(pg_vit* h, const void* pixels, int pix_dtype, int n_images, float* emb_out,
                    void* workspace, size_t workspace_bytes, void* stream);
@@ -153,6 +153,26 @@ int pg_refine_forward(const pg_bank* bank, const float* q, int B, int P, const d
                       float* out_llh, int64_t* out_cell, int32_t* out_choice, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * CLIP image preprocessing (the step in front of the encoder): uint8 RGB -> pixel_values.
+ * Replaces `CLIPProcessor(images=..., return_tensors='pt')` (reference models/clip_embedder.py:52,
+ * dataset_creation/finetune/embed_dataset.py:20, preprocessing/dataset_preprocessing.py:193,
+ * dataset_creation/benchmark/benchmark_dataset.py:99): resize shorter edge to 336 with Pillow's fixed-point BICUBIC,
+ * centre crop 336x336, float32 /255.0, (x-mean)/std, HWC->CHW -- bit-exact with Pillow + numpy float32.
+ * A handle is bound to one input geometry (in_h, in_w); coefficient tables live on the device.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct pg_prep pg_prep;
+int pg_prep_create(pg_prep** out, int device, int in_h, int in_w);
+int pg_prep_destroy(pg_prep* h);
+/* out6 = { resized_h, resized_w, crop_top, crop_left, first_source_row, source_rows_used } */
+int pg_prep_geometry(const pg_prep* h, int32_t* out6);
+int pg_prep_workspace_bytes(const pg_prep* h, int n_images, size_t* bytes);
+/* images_u8: DEVICE (n_images, in_h, in_w, 3) uint8 RGB; out: DEVICE (n_images,3,336,336) fp32 (PG_DTYPE_F32) or fp16
+ * (PG_DTYPE_F16, the fp32 value rounded to nearest even -- exactly what the encoder's im2col would do to the fp32 value).
+ * Asynchronous on `stream`. */
+int pg_prep_forward(pg_prep* h, const void* images_u8, int n_images, void* out, int out_dtype, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Building-block ops (exported so the parity tests can check every kernel in isolation through the ABI).
  * ------------------------------------------------------------------------------------------------ */
 /* `dtype` below is the 16-bit operand/activation format: PG_DTYPE_F16 or PG_DTYPE_BF16.
@@ -178,7 +198,7 @@ int pg_op_layernorm(const float* x, const float* gamma, const float* beta, void*
 /* Multi-head attention over the fused QKV buffer (n_images*577, 3072) 16-bit -> out (n_images*577,1024) 16-bit.
  * Q must already carry the factor log2(e)/sqrt(64) (the GEMM epilogue applies it); softmax in fp32. */
 int pg_op_attention(int dtype, const void* qkv, void* out, int n_images, void* stream);
-/* fp32/bf16 NCHW pixels -> 16-bit patch matrix (n_images*576, 640), k = c*196+ky*14+kx, cols 588..639 zero. */
+/* fp32/fp16/bf16 NCHW pixels -> 16-bit patch matrix (n_images*576, 640), k = c*196+ky*14+kx, cols 588..639 zero. */
 int pg_op_im2col(const void* pixels, int pix_dtype, void* out, int out_dtype, int n_images, void* stream);
 /* mean over the 577 tokens: x fp32 (n_images,577,1024) -> (n_images,1024). */
 int pg_op_token_mean(const float* x, float* out, int n_images, void* stream);

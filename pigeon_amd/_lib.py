@@ -48,6 +48,11 @@ SIGNATURES = {
     "pg_vit_profile_enable": (_I, [_P, _I]),
     "pg_vit_profile_read": (_I, [_P, C.POINTER(_I64), C.POINTER(_D)]),
     "pg_vit_profile_reset": (_I, [_P]),
+    "pg_prep_create": (_I, [C.POINTER(_P), _I, _I, _I]),
+    "pg_prep_destroy": (_I, [_P]),
+    "pg_prep_geometry": (_I, [_P, C.POINTER(C.c_int32)]),
+    "pg_prep_workspace_bytes": (_I, [_P, _I, C.POINTER(_SZ)]),
+    "pg_prep_forward": (_I, [_P, _P, _I, _P, _I, _P, _SZ, _P]),
     "pg_head_forward": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "pg_refine_forward": (_I, [C.POINTER(Bank), _P, _I, _I, _P, _P, _P, _I, _I, _F, _D, _P, _P, _P, _P, _P]),
     "pg_op_gemm16": (_I, [_I, _P, _I64, _P, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _P, _I, _P]),

@@ -96,32 +96,81 @@ def _to_device_pixels(pixel_values: Tensor, device) -> Tensor:
     if not pixel_values.is_cuda:
         dev = device if (isinstance(device, torch.device) and device.type == "cuda") else torch.device("cuda")
         pixel_values = pixel_values.to(dev)
-    if pixel_values.dtype not in (torch.float32, torch.bfloat16):
+    if pixel_values.dtype not in (torch.float32, torch.float16, torch.bfloat16):
         pixel_values = pixel_values.float()
     return pixel_values.contiguous()
 
 
+def _resize_output_size(h: int, w: int, size: int = 336):
+    """transformers 4.23.1 (reference env.yml:60) ImageFeatureExtractionMixin.resize with an int size and
+    default_to_square=False: the shorter edge becomes `size`, the longer one int(size * long / short)."""
+    short, long = (w, h) if w <= h else (h, w)
+    if short == size:
+        return h, w
+    new_short, new_long = size, int(size * long / short)
+    return (new_long, new_short) if w <= h else (new_short, new_long)
+
+
 def clip_preprocess(images) -> Tensor:
-    """CLIPImageProcessor restated for PIL inputs (what `self.processor(images=...)` does at reference
-    models/clip_embedder.py:52): resize shortest edge to 336 (bicubic), centre crop 336x336, scale 1/255,
-    normalise with OPENAI_CLIP_MEAN/STD -> (N,3,336,336) fp32."""
+    """CLIPProcessor restated for PIL inputs on the HOST (what `self.processor(images=...)` does at reference
+    models/clip_embedder.py:52; this is DataLoader-worker work in the reference too): convert RGB, resize shorter edge
+    to 336 (PIL BICUBIC), centre crop 336x336, float32 / 255.0, (x - mean) / std -> (N,3,336,336) fp32.
+    `gpu_preprocess` below is the device path and produces bit-identical values."""
     from PIL import Image
     if not isinstance(images, (list, tuple)):
         images = [images]
     out = []
-    mean = np.asarray(OPENAI_CLIP_MEAN, dtype=np.float32)[:, None, None]
-    std = np.asarray(OPENAI_CLIP_STD, dtype=np.float32)[:, None, None]
+    mean = np.asarray(OPENAI_CLIP_MEAN).astype(np.float32)
+    std = np.asarray(OPENAI_CLIP_STD).astype(np.float32)
     for im in images:
         im = im.convert("RGB")
         w, h = im.size
-        s = 336 / min(w, h)
-        nw, nh = max(336, int(round(w * s))), max(336, int(round(h * s)))
-        im = im.resize((nw, nh), resample=Image.BICUBIC)
+        nh, nw = _resize_output_size(h, w)
+        if (nh, nw) != (h, w):
+            im = im.resize((nw, nh), resample=Image.BICUBIC)
         left, top = (nw - 336) // 2, (nh - 336) // 2
         im = im.crop((left, top, left + 336, top + 336))
-        a = np.asarray(im, dtype=np.float32).transpose(2, 0, 1) * (1.0 / 255.0)
-        out.append((a - mean) / std)
-    return torch.from_numpy(np.stack(out))
+        a = np.asarray(im).astype(np.float32) / 255.0
+        out.append(((a - mean) / std).transpose(2, 0, 1))
+    return torch.from_numpy(np.ascontiguousarray(np.stack(out)))
+
+
+_PREPROCESSORS: Dict = {}
+
+
+def gpu_preprocess(images, device="cuda", out_dtype: torch.dtype = torch.float32) -> Tensor:
+    """CLIP preprocessing on the GPU (pg_prep_forward): `images` is a uint8 RGB tensor / ndarray (N,H,W,3) or (H,W,3),
+    or a list of PIL images / arrays (grouped by size; every size gets its own coefficient tables).  Returns the
+    (N,3,336,336) pixel_values on `device`, bit-identical to `clip_preprocess` / the reference's CLIPProcessor."""
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    if torch.is_tensor(images) or isinstance(images, np.ndarray):
+        t = torch.as_tensor(images)
+        if t.dim() == 3:
+            t = t[None]
+        groups = [(None, t)]
+    else:
+        arrs = [np.asarray(im.convert("RGB")) if hasattr(im, "convert") else np.asarray(im) for im in images]
+        by_size: Dict = {}
+        for i, a in enumerate(arrs):
+            by_size.setdefault(a.shape, []).append(i)
+        groups = [(idx, torch.from_numpy(np.stack([arrs[i] for i in idx]))) for idx in by_size.values()]
+    n_total = sum(g[1].shape[0] for g in groups)
+    out = torch.empty((n_total, 3, 336, 336), dtype=out_dtype, device=dev)
+    for idx, t in groups:
+        if t.dtype != torch.uint8 or t.shape[-1] != 3:
+            raise ValueError(f"gpu_preprocess expects uint8 RGB (N,H,W,3), got {t.dtype} {tuple(t.shape)}")
+        key = (int(t.shape[1]), int(t.shape[2]), dev.index)
+        if key not in _PREPROCESSORS:
+            _PREPROCESSORS[key] = hip_ops.Preprocessor(key[0], key[1], device=dev.index)
+        with torch.cuda.device(dev):
+            px = _PREPROCESSORS[key](t.to(dev, non_blocking=True).contiguous(), out_dtype)
+        if idx is None:
+            out = px
+        else:
+            out[torch.as_tensor(idx, device=dev)] = px
+    return out
 
 
 class CLIPEmbedding(torch.nn.Module):
@@ -168,8 +217,11 @@ class CLIPEmbedding(torch.nn.Module):
     def _get_embedding(self, image) -> Tensor:
         """reference models/clip_embedder.py:42-66"""
         with torch.no_grad():
-            if isinstance(image, Tensor) == False:
-                pixel_values = self.processor(image)
+            if isinstance(image, Tensor) == False or image.dtype == torch.uint8:
+                # PIL image(s) / uint8 HWC arrays: resize + crop + normalise on the GPU (bit-identical to the
+                # reference's host-side CLIPProcessor); 16-bit pixels when the encoder's MFMA operands are fp16
+                dev = self.device if type(self.device) == str else f'cuda:{self.device}'
+                pixel_values = gpu_preprocess(image, dev, self._pixel_dtype())
             else:
                 pixel_values = image
             if type(self.device) == str:
@@ -178,6 +230,10 @@ class CLIPEmbedding(torch.nn.Module):
                 pixel_values = pixel_values.cuda(self.device)
             # last_hidden_state.mean(dim=1), fused in the library (token_mean kernel)
             return self.clip_model.base_model.embed(pixel_values)
+
+    def _pixel_dtype(self) -> torch.dtype:
+        mma = os.environ.get("PIGEON_MMA_DTYPE", "f16").lower()
+        return torch.float16 if mma != "bf16" else torch.float32
 
     def _pre_embed_hook(self) -> Callable:
         def hook(model, input, output):

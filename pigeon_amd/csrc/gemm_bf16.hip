@@ -463,7 +463,7 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
     GemmArgs g;
     g.A = (const uint16_t*)A; g.lda = lda; g.W = (const uint16_t*)W; g.ldw = ldw > 0 ? ldw : K; g.bias = bias; g.out = out; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.qscale = qscale; g.qcols = qcols; g.aux = aux;
-    g.tilesM = 0; g.tilesN = 0; g.ntiles = 0; g.gn = 0;
+    g.tilesM = 0; g.tilesN = 0; g.ntiles = 0; g.gn = 0; g.stagger = 0;
     if ((epi == EPI_GELU || epi == EPI_RESID) && !bias) { pg_set_error("gemm: epilogue %d needs a bias", epi); return PG_EINVAL; }
     if (epi == EPI_PATCH && !aux) { pg_set_error("gemm: patch epilogue needs aux"); return PG_EINVAL; }
     if ((lda % 8) || (ldc % 8) || (qcols % 8) || (g.ldw % 8) || g.ldw < K) { pg_set_error("gemm: lda/ldw/ldc/qcols must be multiples of 8, ldw >= K"); return PG_EINVAL; }

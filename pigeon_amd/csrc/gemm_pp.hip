@@ -210,7 +210,9 @@ __device__ __forceinline__ void load_bias(EpiBias<EPI>& b, const GemmArgs& g, in
 }
 template <int EPI>
 __device__ __forceinline__ void pin_bias(EpiBias<EPI>& b) {
-    asm volatile("" : "+v"(b.lo), "+v"(b.hi));               // a use: the compiler's wait for the loads lands here
+    // a use: the compiler's wait for the loads lands here
+    if constexpr (EPI == EPI_QKV || EPI == EPI_GELU) asm volatile("" : "+v"(b.lo), "+v"(b.hi));
+    else asm volatile("" : "+v"(b.lo));
 }
 
 template <typename T, int EPI>
@@ -256,8 +258,11 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs&
         const uint32_t nbytes = rv > 0 ? (uint32_t)(((int64_t)(rv - 1) * g.ldc + 64) * ESZ) : 0u;
         __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)g.out + ((int64_t)row0 * g.ldc + col0) * ESZ, nbytes);
         const int voff = (rr * (int)g.ldc + cc) * ESZ;
-        const int rstep = RPI * (int)g.ldc * ESZ;            // bytes between two store iterations
-        const int sstep = 32 * (int)g.ldc * ESZ;             // bytes between two slabs
+        int rstep = RPI * (int)g.ldc * ESZ;                  // bytes between two store iterations
+        int sstep = 32 * (int)g.ldc * ESZ;                   // bytes between two slabs
+        // opaque to the optimiser: otherwise all 32 row offsets are hoisted out of the persistent tile loop and pinned
+        // in SGPRs across the K loop (the fp32 epilogues then spill)
+        asm volatile("" : "+s"(rstep), "+s"(sstep));
 
         // EPI_RESID: the fp32 residual rows are fetched one slab ahead of their use (two register sets)
         u32x4 xr[2][EPI == EPI_RESID ? ITS : 1];
@@ -347,8 +352,25 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     const int nblk = gridDim.x;
     int L = xcd_remap(blockIdx.x, nblk);
     if (L >= g.ntiles) return;
+    if (g.stagger > 0) {
+        // De-synchronise the persistent blocks: every tile takes the same time, so blocks that start together also
+        // reach their epilogues together and HBM sees bursts (all CUs storing / fetching residual rows) separated by
+        // idle mainloop stretches.  Slot s of an XCD starts s/32 of a tile period late.
+        const int slot = (blockIdx.x >> 3) & 31;
+        const long long until = (long long)__builtin_readcyclecounter() + (long long)g.stagger * slot / 32;
+        while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(8);
+    }
     TileCtx c = make_tile<ABL>(g, L);
     issue_dma<0, 8>(c, smem, wave, voffA, voffW, 0);         // K tile 0 of the first output tile -> stage 0
+    EpiBias<EPI> bias;
+    load_bias<EPI>(bias, g, c.n0 + wn * 64 + ecc);
+    pin_bias<EPI>(bias);
+    // Number of global stores an epilogue issues AFTER its last load / DMA.  vmcnt retires in order, so at the top of
+    // the next tile `vmcnt(NST)` means "the prefetched K tile 0 (and the next bias) has landed" while the epilogue's
+    // stores are still draining to HBM underneath the first K tile.  (The patch epilogue skips stores of out-of-range
+    // waves, so its count is not static: full drain.)
+    constexpr int NST = (EPI == EPI_QKV || EPI == EPI_GELU || EPI == EPI_RESID) ? 16 : (EPI == EPI_F32 ? 32 : 0);
+    bool first = true;
 
     while (true) {
         f32x16 acc[4][2];
@@ -358,21 +380,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        EpiBias<EPI> bias;
-        load_bias<EPI>(bias, g, c.n0 + wn * 64 + ecc);
-        pin_bias<EPI>(bias);
 
+        if (first || NST == 0) {
+            wait_vm0();
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wait_lgkm0();
+        raw_barrier();                                       // B_0: K tile 0 visible, previous epilogue's slabs released
         if constexpr (MODE == 0) {
             for (int t = 0; t < nt; t += 2) {
-                wait_vm0(); wait_lgkm0(); raw_barrier();
+                if (t > 0) { wait_vm0(); wait_lgkm0(); raw_barrier(); }
                 ktile_free<T>(acc, smem, smem + PP_STAGE, a_base, b_base, xoff, c, wave, voffA, voffW, (t + 1) * ROWB, true);
                 wait_vm0(); wait_lgkm0(); raw_barrier();
                 ktile_free<T>(acc, smem + PP_STAGE, smem, a_base, b_base, xoff, c, wave, voffA, voffW, (t + 2) * ROWB, t + 2 < nt);
             }
             wait_lgkm0(); raw_barrier();
         } else {
-            wait_vm0(); wait_lgkm0();
-            raw_barrier();                                   // B_0: K tile 0 visible, previous epilogue's slabs released
             if (follower) raw_barrier();
             for (int t = 0; t < nt; t += 2) {
                 ktile_pp<T, D0, D1, D2, ABL>(acc, smem, smem + PP_STAGE, a_base, b_base, xoff, c, wave, voffA, voffW,
@@ -386,12 +411,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         const int row0 = c.m0 + wm * 128, col0 = c.n0 + wn * 64;
         L += nblk;
         const bool more = L < g.ntiles;
+        EpiBias<EPI> bias_next = bias;
         if (more) {
             c = make_tile<ABL>(g, L);
             issue_dma<0, 8>(c, smem, wave, voffA, voffW, 0);  // next output tile's K tile 0 -> stage 0 (free since K tile nt-2)
+            load_bias<EPI>(bias_next, g, c.n0 + wn * 64 + ecc);   // older than the epilogue's stores: see NST
         }
         pp_epilogue<T, EPI>(acc, g, smem, wave, lane, row0, col0, bias);
         if (!more) break;
+        pin_bias<EPI>(bias_next);
+        bias = bias_next;
+        first = false;
     }
 }
 
@@ -437,6 +467,8 @@ int dispatch_pp(GemmArgs& g, int epi, int variant, int nblk, hipStream_t s) {
         case 34: return launch_pp_epi<T, 2, 4, 4, 0>(g, epi, nblk, s);    // phases without stagger
         case 36: if (g.tilesN % 4 == 0) g.gn = 4; return launch_pp_epi<T, 1, 4, 4, 0>(g, epi, nblk, s);   // 33 + 8x4 super-tile raster
         case 37: if (g.tilesN % 4 == 0) g.gn = 4; return launch_pp_epi<T, 1, 3, 3, 2>(g, epi, nblk, s);   // 31 + 8x4 super-tile raster
+        case 38: g.stagger = (g.K / BK) * 2600 + 6000; return launch_pp_epi<T, 1, 4, 4, 0>(g, epi, nblk, s);   // 33 + staggered start
+        case 39: g.stagger = (g.K / BK) * 1300 + 3000; return launch_pp_epi<T, 1, 4, 4, 0>(g, epi, nblk, s);   // 33 + half-period stagger
         // ablations of 33 (timing only, wrong results)
         case 40: return launch_pp_epi<T, 1, 4, 4, 0, 1>(g, epi, nblk, s);          // no DMA in the K loop
         case 41: return launch_pp_epi<T, 1, 4, 4, 0, 2>(g, epi, nblk, s);          // every DMA hits panel 0 (L2 resident)

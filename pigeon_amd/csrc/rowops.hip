@@ -118,7 +118,7 @@ int pg_preln_launch(float* x, const float* cls, const float* pos0, const float* 
 // 336 contiguous pixels: reads are fully coalesced; every pixel lands at
 //   out[(img*576 + py*24 + px)*640 + c*196 + ky*14 + kx]   (k order == Conv2d weight [1024,3,14,14] flattened)
 // Columns 588..639 are zero so the GEMM can run K = 640 = 10 x 64.
-template <typename PIX, typename T>
+template <typename PIX, typename T, bool PIX_F16 = false>
 __global__ __launch_bounds__(256) void im2col_kernel(const PIX* __restrict__ pix, uint16_t* __restrict__ out) {
     const int img = blockIdx.x / 24, py = blockIdx.x % 24;
     const PIX* src = pix + (int64_t)img * 3 * VIT_IMG * VIT_IMG;
@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const PIX* __restrict__ pix
         const int px = xcol / 14, kx = xcol - px * 14;
         float v;
         if (sizeof(PIX) == 4) v = (float)src[((int64_t)c * VIT_IMG + py * 14 + ky) * VIT_IMG + xcol];
+        else if (PIX_F16) v = f16_bits_to_f32((uint16_t)src[((int64_t)c * VIT_IMG + py * 14 + ky) * VIT_IMG + xcol]);
         else v = bf16_bits_to_f32((uint16_t)src[((int64_t)c * VIT_IMG + py * 14 + ky) * VIT_IMG + xcol]);
         dst[px * VIT_PATCH_KPAD + c * 196 + ky * 14 + kx] = T::bits(v);
     }
@@ -149,6 +150,9 @@ int pg_im2col_launch(const void* pixels, int pix_dtype, void* out, int out_dtype
     } else if (pix_dtype == PG_DTYPE_BF16) {
         if (h) hipLaunchKernelGGL((im2col_kernel<uint16_t, T_F16>), grid, block, 0, s, (const uint16_t*)pixels, (uint16_t*)out);
         else hipLaunchKernelGGL((im2col_kernel<uint16_t, T_BF16>), grid, block, 0, s, (const uint16_t*)pixels, (uint16_t*)out);
+    } else if (pix_dtype == PG_DTYPE_F16) {                  // what pg_prep_forward writes (preprocess.hip)
+        if (h) hipLaunchKernelGGL((im2col_kernel<uint16_t, T_F16, true>), grid, block, 0, s, (const uint16_t*)pixels, (uint16_t*)out);
+        else hipLaunchKernelGGL((im2col_kernel<uint16_t, T_BF16, true>), grid, block, 0, s, (const uint16_t*)pixels, (uint16_t*)out);
     } else { pg_set_error("im2col: unsupported pixel dtype %d", pix_dtype); return PG_EINVAL; }
     return pg_check_launch("im2col");
 }

@@ -291,7 +291,7 @@ extern "C" int pg_vit_forward_hidden(pg_vit* h, const void* pixels, int pix_dtyp
     if (!h || !pixels || !emb_out || !workspace) { pg_set_error("vit_forward: null argument"); return PG_EINVAL; }
     if (!h->finalized) { pg_set_error("vit_forward: handle not finalized"); return PG_ESTATE; }
     if (n_images <= 0) return PG_OK;
-    if (pix_dtype != PG_DTYPE_F32 && pix_dtype != PG_DTYPE_BF16) { pg_set_error("vit_forward: bad pixel dtype"); return PG_EINVAL; }
+    if (pix_dtype != PG_DTYPE_F32 && pix_dtype != PG_DTYPE_BF16 && pix_dtype != PG_DTYPE_F16) { pg_set_error("vit_forward: bad pixel dtype"); return PG_EINVAL; }
     size_t needb = 0;
     pg_vit_workspace_bytes(h, n_images, &needb);
     if (workspace_bytes < needb) { pg_set_error("vit_forward: workspace %zu < required %zu bytes", workspace_bytes, needb); return PG_ENOMEM; }

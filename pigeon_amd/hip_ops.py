@@ -23,6 +23,7 @@ def _stream():
 
 
 _T16 = {torch.float16: _lib.PG_DTYPE_F16, torch.bfloat16: _lib.PG_DTYPE_BF16}
+_PIXDT = {torch.float32: _lib.PG_DTYPE_F32, torch.float16: _lib.PG_DTYPE_F16, torch.bfloat16: _lib.PG_DTYPE_BF16}
 _PG2T = {_lib.PG_DTYPE_F16: torch.float16, _lib.PG_DTYPE_BF16: torch.bfloat16, _lib.PG_DTYPE_F32: torch.float32}
 
 
@@ -81,7 +82,7 @@ def attention(qkv: torch.Tensor, n_images: int) -> torch.Tensor:
 def im2col(pixels: torch.Tensor, out_dtype: torch.dtype = torch.float16) -> torch.Tensor:
     _dev(pixels)
     n = pixels.shape[0]
-    dt = _lib.PG_DTYPE_F32 if pixels.dtype == torch.float32 else _lib.PG_DTYPE_BF16
+    dt = _PIXDT[pixels.dtype]
     out = torch.empty((n * PATCHES, KPAD), dtype=out_dtype, device=pixels.device)
     check(load().pg_op_im2col(_p(pixels), dt, _p(out), _dt16(out), n, _stream()), "pg_op_im2col")
     return out
@@ -100,6 +101,51 @@ def cast_f32(x: torch.Tensor, out_dtype: torch.dtype = torch.float16) -> torch.T
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     check(load().pg_op_cast_f32(_p(x), _p(y), _dt16(y), x.numel(), _stream()), "pg_op_cast_f32")
     return y
+
+
+# ----------------------------------------------------------------------------------------- image preprocessing
+class Preprocessor:
+    """CLIP preprocessing on the GPU for one input geometry: (N,H,W,3) uint8 RGB -> (N,3,336,336) pixel_values,
+    bit-exact with `CLIPProcessor(images=pil)` (Pillow fixed-point bicubic + numpy float32 normalisation)."""
+
+    def __init__(self, in_h: int, in_w: int, device: int = 0):
+        _lib.require_gpu()
+        self._h = C.c_void_p()
+        check(load().pg_prep_create(C.byref(self._h), int(device), int(in_h), int(in_w)), "pg_prep_create")
+        self.in_h, self.in_w, self.device = int(in_h), int(in_w), int(device)
+        geo = (C.c_int32 * 6)()
+        check(load().pg_prep_geometry(self._h, geo), "pg_prep_geometry")
+        self.resized_h, self.resized_w, self.top, self.left, self.row0, self.nrows = [int(x) for x in geo]
+        self._ws = None
+
+    def forward(self, images_u8: torch.Tensor, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+        _dev(images_u8, torch.uint8)
+        if images_u8.dim() != 4 or tuple(images_u8.shape[1:]) != (self.in_h, self.in_w, 3):
+            raise _lib.PigeonHipError(f"images must be (N,{self.in_h},{self.in_w},3) uint8, got {tuple(images_u8.shape)}")
+        if out_dtype not in (torch.float32, torch.float16):
+            raise _lib.PigeonHipError("preprocess output dtype must be float32 or float16")
+        n = images_u8.shape[0]
+        need = C.c_size_t()
+        check(load().pg_prep_workspace_bytes(self._h, n, C.byref(need)), "pg_prep_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need.value or self._ws.device != images_u8.device:
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=images_u8.device)
+        out = torch.empty((n, 3, 336, 336), dtype=out_dtype, device=images_u8.device)
+        check(load().pg_prep_forward(self._h, _p(images_u8), n, _p(out), _PIXDT[out_dtype], _p(self._ws), self._ws.numel(),
+                                     _stream()), "pg_prep_forward")
+        return out
+
+    __call__ = forward
+
+    def close(self):
+        if self._h:
+            load().pg_prep_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ----------------------------------------------------------------------------------------- ViT encoder handle
@@ -155,14 +201,14 @@ class VitEncoder:
         _dev(pixels)
         if pixels.dim() != 4 or tuple(pixels.shape[1:]) != (3, 336, 336):
             raise _lib.PigeonHipError(f"pixels must be (N,3,336,336), got {tuple(pixels.shape)}")
-        if pixels.dtype not in (torch.float32, torch.bfloat16):
-            raise _lib.PigeonHipError("pixels must be fp32 or bf16")
+        if pixels.dtype not in _PIXDT:
+            raise _lib.PigeonHipError("pixels must be fp32, fp16 or bf16")
         n = pixels.shape[0]
         ws = self._workspace(n)
         off = (-ws.data_ptr()) % 256
         emb = torch.empty((n, HIDDEN), dtype=torch.float32, device=pixels.device)
         hid = torch.empty((n, TOKENS, HIDDEN), dtype=torch.float32, device=pixels.device) if return_hidden else None
-        dt = _lib.PG_DTYPE_F32 if pixels.dtype == torch.float32 else _lib.PG_DTYPE_BF16
+        dt = _PIXDT[pixels.dtype]
         check(load().pg_vit_forward_hidden(self._h, _p(pixels), dt, n, _p(emb), _p(hid),
                                            C.c_void_p(ws.data_ptr() + off), ws.numel() - off, _stream()),
               "pg_vit_forward")

@@ -1,0 +1,67 @@
+"""GPU parity of the CLIP preprocessing kernels (pigeon_amd/csrc/preprocess.hip, through the C ABI) against the
+numpy oracle, which is itself pinned to Pillow (tests/test_preprocess_cpu.py).  Integer work: bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def env():
+    from pigeon_amd import _lib, hip_ops
+    from oracle import clip_preprocess_oracle as orc
+    _lib.require_gpu()
+    return dict(ops=hip_ops, orc=orc)
+
+
+@pytest.mark.parametrize("h,w", [(640, 640), (480, 640), (640, 480), (200, 300), (336, 336), (337, 336), (336, 500),
+                                 (1000, 350)])
+def test_prep_matches_oracle_bit_exact(env, h, w):
+    ops, orc = env["ops"], env["orc"]
+    rng = np.random.default_rng(h * 7 + w)
+    imgs = rng.integers(0, 256, (3, h, w, 3), dtype=np.uint8)          # white noise: every rounding / clipping path
+    imgs[1] = np.kron(rng.integers(0, 256, (h // 16 + 1, w // 16 + 1, 3), dtype=np.uint8),
+                      np.ones((16, 16, 1), dtype=np.uint8))[:h, :w]      # blocky image: overshoot at edges
+    prep = ops.Preprocessor(h, w)
+    nh, nw = orc.resize_output_size(h, w)
+    assert (prep.resized_h, prep.resized_w) == (nh, nw)
+    got = prep(torch.from_numpy(imgs).to(DEV), torch.float32).cpu().numpy()
+    got16 = prep(torch.from_numpy(imgs).to(DEV), torch.float16).cpu()
+    for i in range(3):
+        ref = orc.clip_preprocess(imgs[i])
+        assert np.array_equal(got[i], ref), f"image {i}: {np.abs(got[i] - ref).max()}"
+        assert torch.equal(got16[i], torch.from_numpy(ref).to(torch.float16))
+
+
+def test_prep_matches_pillow_golden(env, golden_dir):
+    ops = env["ops"]
+    gold = np.load(os.path.join(golden_dir, "preprocess.npz"))
+    lut = env["orc"].normalise_lut()
+    for tag in ["square", "landscape", "portrait", "upscale", "crop_only"]:
+        img, u8 = gold[f"{tag}_img"], gold[f"{tag}_u8"]
+        got = ops.Preprocessor(img.shape[0], img.shape[1])(torch.from_numpy(img[None]).to(DEV)).cpu().numpy()[0]
+        ref = np.stack([lut[c][u8[:, :, c]] for c in range(3)])
+        assert np.array_equal(got, ref), tag
+
+
+def test_clip_embedding_accepts_raw_images(env):
+    """CLIPEmbedding.forward(PIL images / uint8 arrays) == forward(host-preprocessed tensor): the GPU preprocessing
+    path feeds the encoder the same operand bits (fp16 pixels = what im2col makes of the fp32 values)."""
+    Image = pytest.importorskip("PIL.Image")
+    from pigeon_amd import synthetic
+    from pigeon_amd.clip_embedder import CLIPEmbedding, HipCLIPVisionModel, clip_preprocess
+    sd = synthetic.make_vit_weights(seed=11, layers=2, affine_jitter=True)
+    emb = CLIPEmbedding("synthetic", device="cuda", clip_model=HipCLIPVisionModel(sd, layers=2))
+    rng = np.random.default_rng(5)
+    arrs = [rng.integers(0, 256, s, dtype=np.uint8) for s in [(480, 640, 3), (640, 480, 3), (480, 640, 3)]]
+    pil = [Image.fromarray(a) for a in arrs]
+    e_raw = emb(pil).cpu()
+    e_host = emb(clip_preprocess(pil)).cpu()
+    assert e_raw.shape == (3, 1024)
+    assert torch.equal(e_raw, e_host)
+    e_u8 = emb(torch.from_numpy(np.stack([arrs[0], arrs[2]]))).cpu()
+    assert torch.equal(e_u8, e_raw[[0, 2]])
