@@ -35,6 +35,7 @@ extern "C" {
 #define PG_DTYPE_F32     0
 #define PG_DTYPE_BF16    1
 #define PG_DTYPE_F16     2
+#define PG_DTYPE_F64     3
 
 #define PG_ABI_VERSION   1
 
@@ -171,6 +172,23 @@ int pg_prep_workspace_bytes(const pg_prep* h, int n_images, size_t* bytes);
  * Asynchronous on `stream`. */
 int pg_prep_forward(pg_prep* h, const void* images_u8, int n_images, void* out, int out_dtype, void* workspace,
                     size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Around the hot path.
+ * ------------------------------------------------------------------------------------------------ */
+/* Prototype construction (reference models/proto_refiner.py:359-384): proto_emb[p] = fp32 mean, in member order, of
+ * train_emb[member_idx[member_off[p] .. member_off[p+1])], each member first averaged over its `panels` (1 or 4) panel
+ * embeddings; an empty prototype gets zeros.  train_emb: DEVICE (num_train, panels, 1024) fp32; proto_emb: DEVICE
+ * (num_protos,1024) fp32.  Bit-identical to torch's `embeddings.mean(dim=1).mean(dim=0)` on the CPU. */
+int pg_proto_build(const float* train_emb, int panels, int64_t num_train, const int64_t* member_off,
+                   const int64_t* member_idx, int64_t num_protos, float* proto_emb, void* stream);
+/* Great-circle distance matrix (reference preprocessing/geo_utils.py:58-74): x DEVICE (N,2) [lng,lat] degrees, fp32
+ * (PG_DTYPE_F32: deg2rad / cos(lat) in fp32 then promoted, torch's type promotion) or fp64; y DEVICE (M,2) fp64 (note:
+ * row-major (M,2), i.e. lla_geocells itself, where the reference passes its transpose); out DEVICE (N,M) fp64 km. */
+int pg_haversine_matrix(const void* x, int x_dtype, const double* y, int N, int M, double* out, void* stream);
+/* Label smoothing (reference preprocessing/utils.py:7-19): out = exp(-(d - rowmin(d)) / constant), NaN/inf -> 0.
+ * distances, out: DEVICE (N,M) fp64 (may alias). */
+int pg_smooth_labels(const double* distances, int N, int M, double constant, double* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Building-block ops (exported so the parity tests can check every kernel in isolation through the ABI).

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpigeon_hip.so")
 
-PG_DTYPE_F32, PG_DTYPE_BF16, PG_DTYPE_F16 = 0, 1, 2
+PG_DTYPE_F32, PG_DTYPE_BF16, PG_DTYPE_F16, PG_DTYPE_F64 = 0, 1, 2, 3
 EPI_QKV, EPI_GELU, EPI_RESID, EPI_PATCH, EPI_F32 = 0, 1, 2, 3, 4
 PROF_CLASSES = ["gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2", "gemm_patch", "attention", "layernorm",
                 "im2col", "token_mean"]
@@ -53,6 +53,9 @@ SIGNATURES = {
     "pg_prep_geometry": (_I, [_P, C.POINTER(C.c_int32)]),
     "pg_prep_workspace_bytes": (_I, [_P, _I, C.POINTER(_SZ)]),
     "pg_prep_forward": (_I, [_P, _P, _I, _P, _I, _P, _SZ, _P]),
+    "pg_proto_build": (_I, [_P, _I, _I64, _P, _P, _I64, _P, _P]),
+    "pg_haversine_matrix": (_I, [_P, _I, _P, _I, _I, _P, _P]),
+    "pg_smooth_labels": (_I, [_P, _I, _I, _D, _P, _P]),
     "pg_head_forward": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "pg_refine_forward": (_I, [C.POINTER(Bank), _P, _I, _I, _P, _P, _P, _I, _I, _F, _D, _P, _P, _P, _P, _P]),
     "pg_op_gemm16": (_I, [_I, _P, _I64, _P, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _P, _I, _P]),

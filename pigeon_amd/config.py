@@ -38,3 +38,6 @@ PROTO_MODEL_LANDMARKS_PATH = 'saved_models/refiner/proto_landmarks.refiner'
 # reference models/clip_embedder.py:52 and dataset_creation/finetune/embed_dataset.py:20)
 OPENAI_CLIP_MEAN = [0.48145466, 0.4578275, 0.40821073]
 OPENAI_CLIP_STD = [0.26862954, 0.26130258, 0.27577711]
+
+# reference config.py:55
+LABEL_SMOOTHING_CONSTANT = 65  # (PIGEOTTO), 75 (PIGEON)

@@ -103,6 +103,40 @@ def cast_f32(x: torch.Tensor, out_dtype: torch.dtype = torch.float16) -> torch.T
     return y
 
 
+# ----------------------------------------------------------------------------------------- around the hot path
+def proto_build(train_emb: torch.Tensor, member_off: torch.Tensor, member_idx: torch.Tensor) -> torch.Tensor:
+    """(Ntr,1024) or (Ntr,4,1024) fp32 training embeddings + CSR member lists -> (P,1024) fp32 prototype means."""
+    _dev(train_emb, torch.float32); _dev(member_off, torch.int64); _dev(member_idx, torch.int64)
+    panels = 1 if train_emb.dim() == 2 else int(train_emb.shape[1])
+    if train_emb.shape[-1] != HIDDEN:
+        raise _lib.PigeonHipError("proto_build: embeddings must have 1024 columns")
+    P = member_off.numel() - 1
+    out = torch.empty((P, HIDDEN), dtype=torch.float32, device=train_emb.device)
+    check(load().pg_proto_build(_p(train_emb), panels, train_emb.shape[0], _p(member_off), _p(member_idx), P, _p(out),
+                                _stream()), "pg_proto_build")
+    return out
+
+
+def haversine_matrix(x: torch.Tensor, y_rows: torch.Tensor) -> torch.Tensor:
+    """x (N,2) fp32/fp64 [lng,lat], y_rows (M,2) fp64 -> (N,M) fp64 km."""
+    _dev(x); _dev(y_rows, torch.float64)
+    if x.dtype not in (torch.float32, torch.float64):
+        raise _lib.PigeonHipError("haversine_matrix: x must be fp32 or fp64")
+    N, M = x.shape[0], y_rows.shape[0]
+    out = torch.empty((N, M), dtype=torch.float64, device=x.device)
+    check(load().pg_haversine_matrix(_p(x), _lib.PG_DTYPE_F64 if x.dtype == torch.float64 else _lib.PG_DTYPE_F32, _p(y_rows),
+                                     N, M, _p(out), _stream()), "pg_haversine_matrix")
+    return out
+
+
+def smooth_labels(distances: torch.Tensor, constant: float) -> torch.Tensor:
+    _dev(distances, torch.float64)
+    N, M = distances.shape
+    out = torch.empty_like(distances)
+    check(load().pg_smooth_labels(_p(distances), N, M, float(constant), _p(out), _stream()), "pg_smooth_labels")
+    return out
+
+
 # ----------------------------------------------------------------------------------------- image preprocessing
 class Preprocessor:
     """CLIP preprocessing on the GPU for one input geometry: (N,H,W,3) uint8 RGB -> (N,3,336,336) pixel_values,

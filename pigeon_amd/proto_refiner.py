@@ -74,7 +74,35 @@ def _training_arrays(dataset_path):
     return np.ascontiguousarray(emb), np.ascontiguousarray(lab[:, :2])
 
 
-def build_bank(proto_path: str, dataset_path, verbose: bool = False) -> HostBank:
+def _segmented_mean_host(train_emb, member_off, member_idx, lens):
+    """Host version (used when no GPU is visible) of the prototype mean, bit-identical to torch's
+    `embeddings.mean(dim=0)`: below 16 members torch's CPU reduction is a plain member-order sum (swept here across all
+    prototypes at once; np.add.reduceat sums pairwise and differs in the last ulp), from 16 members on it is a cascade
+    of 16-row chunks -- those prototypes simply go through torch itself."""
+    P = lens.shape[0]
+    proto_emb = np.zeros((P, train_emb.shape[1]), dtype=np.float32)
+    small = lens < 16
+    for j in range(int(lens[small].max()) if small.any() else 0):
+        sel = np.nonzero(small & (lens > j))[0]
+        proto_emb[sel] += train_emb[member_idx[member_off[sel] + j]]
+    nz = small & (lens > 0)
+    proto_emb[nz] /= lens[nz].astype(np.float32)[:, None]
+    for p in np.nonzero(~small)[0]:
+        rows = train_emb[member_idx[member_off[p]:member_off[p + 1]]]
+        proto_emb[p] = torch.from_numpy(np.ascontiguousarray(rows)).mean(dim=0).numpy()
+    return proto_emb
+
+
+def _segmented_mean_gpu(train_emb, member_off, member_idx, device="cuda"):
+    """pg_proto_build: one block per prototype streams its member rows (HBM-bound), same summation order."""
+    if member_idx.size and (member_idx.min() < 0 or member_idx.max() >= train_emb.shape[0]):
+        raise IndexError("prototype member index outside the training bank")
+    out = hip_ops.proto_build(torch.from_numpy(train_emb).to(device), torch.from_numpy(member_off).to(device),
+                              torch.from_numpy(member_idx).to(device))
+    return out.cpu().numpy()
+
+
+def build_bank(proto_path: str, dataset_path, verbose: bool = False, use_gpu: Optional[bool] = None) -> HostBank:
     """CSV + training embeddings -> CSR bank, reproducing the reference's prototype construction:
     rows of one geocell in CSV order (`proto_df.loc[cell]`, :299), a cell whose FIRST row has no indices is
     empty (:307-308), prototype embedding = fp32 mean of the member embeddings (:359-378), lng/lat/count
@@ -110,14 +138,13 @@ def build_bank(proto_path: str, dataset_path, verbose: bool = False) -> HostBank
     member_off = np.zeros(P + 1, dtype=np.int64)
     np.cumsum(lens, out=member_off[1:])
     member_idx = np.fromiter((i for l in idx_lists for i in l), dtype=np.int64, count=int(member_off[-1]))
-    # segmented fp32 mean, rows added in member order then divided by the count == torch .mean(dim=0)
-    # (np.add.reduceat sums pairwise and differs in the last ulp; the member-by-member sweep below is exact)
-    proto_emb = np.zeros((P, train_emb.shape[1]), dtype=np.float32)
-    for j in range(int(lens.max()) if P else 0):
-        sel = np.nonzero(lens > j)[0]
-        proto_emb[sel] += train_emb[member_idx[member_off[sel] + j]]
-    nz = lens > 0
-    proto_emb[nz] /= lens[nz].astype(np.float32)[:, None]
+    # prototype embedding = mean of the member embeddings (:359-378): on the GPU when one is visible
+    if use_gpu is None:
+        use_gpu = torch.cuda.is_available()
+    if use_gpu and P:
+        proto_emb = _segmented_mean_gpu(train_emb, member_off, member_idx)
+    else:
+        proto_emb = _segmented_mean_host(train_emb, member_off, member_idx, lens)
     return HostBank(proto_emb=proto_emb, cell_off=cell_off, proto_lnglat=np.stack([lng, lat], axis=1),
                     proto_count=cnt, member_off=member_off, member_idx=member_idx,
                     train_emb=train_emb, train_lnglat=train_lnglat)

@@ -15,6 +15,7 @@ from torch import nn, Tensor
 from torch.nn.parameter import Parameter
 
 from . import hip_ops
+from .geo_utils import haversine_matrix, smooth_labels
 from .clip_embedder import HipCLIPVisionModel
 from .config import CLIP_EMBED_DIM, GEOCELL_PATH, GEOCELL_PATH_YFCC
 from .utils import ModelOutput, TopK
@@ -172,6 +173,9 @@ class SuperGuessr(nn.Module):
             loss_clf = None
             if labels_clf is not None:                                          # :456, :474 (logged only)
                 label_probs = self._to_one_hot(labels_clf.to(dev))
+                if self.should_smooth_labels and labels is not None:            # :469-471 soft labels by distance
+                    distances = haversine_matrix(labels.to(dev), self.lla_geocells.data.t())
+                    label_probs = smooth_labels(distances)
                 loss_clf = self.loss_fnc(logits, label_probs)
             loss = loss_clf
             return ModelOutput(loss, loss_clf, 0, 0, 0, pred_LLH, geocell_preds, None, None, None,
