@@ -23,6 +23,8 @@
 #include "common.h"
 #include "pigeon_internal.h"
 
+#include <cstdlib>
+
 #define ATT_KT 64
 #define ATT_QB 128                       // query rows per block
 #define ATT_NQB 5                        // ceil(577 / 128)
@@ -209,13 +211,207 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     }
 }
 
+// ================================================================================================================
+// v2: 64 queries per wave.  The v1 kernel above is LDS-bound: per 64-key tile every wave re-reads the K fragments
+// (8 ds_read_b128) and V^T fragments (16 ds_read_b64) for only 32 queries, and a 128-query block re-stages the whole
+// K/V tile -- LDS read + write cycles per CU exceed the VALU/MFMA cycles of the same work (rocprof: SQ_LDS busy > 100 %
+// of the softmax-bound time).  Here a wave owns TWO 32-query blocks: each K / V^T fragment read feeds two MFMAs, the
+// block covers 256 queries per staged tile (3 blocks per (image, head): 256 + 256 + 65), so LDS traffic per query
+// halves, and the two independent softmax chains of a wave give the scheduler MFMA work of one query block to put
+// under the VALU work of the other.  A wave whose second query block lies entirely past token 576 skips it
+// (wave-uniform branch), so the 577th query costs half a wave, as in v1.  The rescale of O is skipped when no row
+// maximum of the wave moved (multiplying by exactly 1.0) -- bit-identical, saves 32 VALU per tile most of the time.
+// ================================================================================================================
+#define ATT2_QB 256
+#define ATT2_NQB 3                       // ceil(577 / 256)
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attention2_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * K_TILE_BYTES + 2 * VT_TILE_BYTES];
+    char* ks0 = smem;
+    char* vt0 = smem + 2 * K_TILE_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, g = lane >> 5;
+
+    // XCD-aware decode: the ATT2_NQB query blocks of one (image, head) pair share an XCD
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int qb = slot % ATT2_NQB;
+    const int pair = (slot / ATT2_NQB) * 8 + xcd;
+    const int img = pair >> 4, head = pair & 15;
+    const int64_t base = (int64_t)img * VIT_TOKENS;
+
+    const int q_first = qb * ATT2_QB + wave * 64;           // wave-uniform
+    const bool act0 = q_first < VIT_TOKENS;                  // first 32-query block has at least one valid query
+    const bool act1 = q_first + 32 < VIT_TOKENS;             // second one too
+
+    typename T::v8 qf[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int qrow = q_first + b * 32 + lq;
+        const int qr = qrow < VIT_TOKENS ? qrow : VIT_TOKENS - 1;
+#pragma unroll
+        for (int ksi = 0; ksi < 4; ++ksi)
+            qf[b][ksi] = *(const typename T::v8*)(qkv + (base + qr) * QKV_LD + head * 64 + ksi * 16 + g * 8);
+    }
+
+    f32x16 o[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[b][db][r] = 0.f;
+    float m[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f};
+
+    int kxoff[4];
+#pragma unroll
+    for (int ksi = 0; ksi < 4; ++ksi) kxoff[ksi] = ((ksi * 2 + g) ^ ((lq >> 1) & 7)) << 4;
+
+    StageRegs st;
+    att_load_tile(st, qkv, base, head, 0, tid);
+    att_store_tile(st, ks0, vt0, tid);
+    __syncthreads();
+
+    for (int t = 0; t < ATT_NT; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ATT_NT) att_load_tile(st, qkv, base, head, t + 1, tid);   // in flight during the math
+        const char* ks = ks0 + cur * K_TILE_BYTES;
+        const char* vt = vt0 + cur * VT_TILE_BYTES;
+
+        if (act0) {
+            // ---- S^T = K Q^T for both query blocks: one K fragment read, two MFMAs (first one with C = 0) ----
+            f32x16 s[2][2];
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int ksi = 0; ksi < 4; ++ksi) {
+                    const typename T::v8 kf = *(const typename T::v8*)(ks + (kb * 32 + lq) * K_ROWB + kxoff[ksi]);
+                    s[0][kb] = T::mfma(kf, qf[0][ksi], ksi == 0 ? zero16 : s[0][kb]);
+                    if (act1) s[1][kb] = T::mfma(kf, qf[1][ksi], ksi == 0 ? zero16 : s[1][kb]);
+                }
+            // ---- online softmax (base 2), per query block.  Instruction diet (the loop is VALU-bound: 32 scores per lane
+            // per query block): row max as 16 v_max3_f32, s - m and the row sum as packed fp32 adds (2 per instruction),
+            // 32 v_exp_f32, and P goes to 16 bits with the packed converts in the PV section below. ----
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (b == 1 && !act1) break;
+                if (t == ATT_NT - 1) {
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = t * ATT_KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                            if (key >= VIT_TOKENS) s[b][kb][r] = -1e30f;
+                        }
+                }
+                float tmax = max3f(s[b][0][0], s[b][0][1], s[b][0][2]);
+#pragma unroll
+                for (int r = 3; r < 15; r += 2) tmax = max3f(tmax, s[b][0][r], s[b][0][r + 1]);
+                tmax = max3f(tmax, s[b][0][15], s[b][1][0]);
+#pragma unroll
+                for (int r = 1; r < 15; r += 2) tmax = max3f(tmax, s[b][1][r], s[b][1][r + 1]);
+                tmax = max3f(tmax, s[b][1][15], s[b][1][15]);
+                const float m_new = max3f(tmax, __shfl_xor(tmax, 32, 64), m[b]);   // the other half of the row's keys
+                const bool moved = __builtin_amdgcn_ballot_w64(m_new > m[b]) != 0;   // wave-uniform
+                const float alpha = __builtin_amdgcn_exp2f(m[b] - m_new);            // == 1.0f when this row's max stayed
+                m[b] = m_new;
+                const f32x2 m2 = {m_new, m_new};
+                f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 sv = {s[b][kb][r], s[b][kb][r + 1]};
+                        const f32x2 d = sv - m2;
+                        const f32x2 pv = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+                        s[b][kb][r] = pv[0]; s[b][kb][r + 1] = pv[1];
+                        ps2 += pv;
+                    }
+                l[b] = l[b] * alpha + (ps2[0] + ps2[1]);
+                if (moved) {
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[b][db][r] *= alpha;
+                }
+            }
+            // ---- O^T += V^T P^T: one V^T fragment read, two MFMAs ----
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    typename T::v8 pf[2];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        u32x4 pw;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) pw[w] = T::pack2(s[b][kb][8 * s2 + 2 * w], s[b][kb][8 * s2 + 2 * w + 1]);
+                        pf[b] = __builtin_bit_cast(typename T::v8, pw);
+                    }
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const char* vrow = vt + (db * 32 + lq) * VT_STRIDE + (kb * 32 + 16 * s2 + 4 * g) * 2;
+                        const u32x2 lo = *(const u32x2*)(vrow);        // keys +0..3
+                        const u32x2 hi = *(const u32x2*)(vrow + 16);   // keys +8..11
+                        u32x4 vw; vw[0] = lo[0]; vw[1] = lo[1]; vw[2] = hi[0]; vw[3] = hi[1];
+                        const typename T::v8 vf = __builtin_bit_cast(typename T::v8, vw);
+                        o[0][db] = T::mfma(vf, pf[0], o[0][db]);
+                        if (act1) o[1][db] = T::mfma(vf, pf[1], o[1][db]);
+                    }
+                }
+            }
+        }
+
+        if (t + 1 < ATT_NT) att_store_tile(st, ks0 + (cur ^ 1) * K_TILE_BYTES, vt0 + (cur ^ 1) * VT_TILE_BYTES, tid);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (b == 0 ? !act0 : !act1) break;
+        const float ltot = l[b] + __shfl_xor(l[b], 32, 64);
+        const float inv = 1.0f / ltot;
+        const int qrow = q_first + b * 32 + lq;
+        if (qrow < VIT_TOKENS) {
+            uint16_t* orow = out + (base + qrow) * VIT_HIDDEN + head * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    u32x2 pk;
+                    pk[0] = pack16x2<T>(o[b][db][4 * q4] * inv, o[b][db][4 * q4 + 1] * inv);
+                    pk[1] = pack16x2<T>(o[b][db][4 * q4 + 2] * inv, o[b][db][4 * q4 + 3] * inv);
+                    *(u32x2*)(orow + db * 32 + 8 * q4 + 4 * g) = pk;
+                }
+        }
+    }
+}
+
+static int attention_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("PIGEON_ATTN_VARIANT");
+        v = e ? atoi(e) : 2;
+        if (v != 1 && v != 2) v = 2;
+    }
+    return v;
+}
+
 int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hipStream_t s) {
     if (n_images <= 0) return PG_OK;
     const int pairs = n_images * VIT_HEADS;                  // always a multiple of 8
-    if (dtype == PG_DTYPE_F16)
-        hipLaunchKernelGGL(attention_kernel<T_F16>, dim3(pairs * ATT_NQB), dim3(256), 0, s, (const uint16_t*)qkv, (uint16_t*)out);
-    else if (dtype == PG_DTYPE_BF16)
-        hipLaunchKernelGGL(attention_kernel<T_BF16>, dim3(pairs * ATT_NQB), dim3(256), 0, s, (const uint16_t*)qkv, (uint16_t*)out);
-    else { pg_set_error("attention: dtype must be PG_DTYPE_F16 or PG_DTYPE_BF16"); return PG_EINVAL; }
+    const bool v2 = attention_variant() == 2;
+    const dim3 grid(pairs * (v2 ? ATT2_NQB : ATT_NQB)), block(256);
+    if (dtype == PG_DTYPE_F16) {
+        if (v2) hipLaunchKernelGGL(attention2_kernel<T_F16>, grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+        else hipLaunchKernelGGL(attention_kernel<T_F16>, grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+    } else if (dtype == PG_DTYPE_BF16) {
+        if (v2) hipLaunchKernelGGL(attention2_kernel<T_BF16>, grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+        else hipLaunchKernelGGL(attention_kernel<T_BF16>, grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+    } else { pg_set_error("attention: dtype must be PG_DTYPE_F16 or PG_DTYPE_BF16"); return PG_EINVAL; }
     return pg_check_launch("attention");
 }

@@ -10,6 +10,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;   // 32x32 MFMA accum
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
 #define PG_WAVE 64
 
@@ -55,6 +58,11 @@ struct T_BF16 {
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
+    // two finite floats -> one dword, round to nearest even (v_cvt_pk_bf16_f32); no NaN fix-up: for softmax weights
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+        const f32x2 v = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    }
 };
 struct T_F16 {
     typedef f16x8 v8;
@@ -64,10 +72,23 @@ struct T_F16 {
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
+    // two floats in [0, 65504] -> one dword, round to nearest even (v_cvt_pk_f16_f32); no saturation: for softmax weights
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+        const f32x2 v = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+    }
 };
 template <typename T>
 __device__ __forceinline__ uint32_t pack16x2(float lo, float hi) {
     return (uint32_t)T::bits(lo) | ((uint32_t)T::bits(hi) << 16);
+}
+
+// 3-input max as ONE instruction.  Through fmaxf() hipcc first canonicalises MFMA results (v_max_f32 x, x, x per input),
+// which tripled the instruction count of the softmax row maximum.
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
