@@ -391,12 +391,316 @@ __global__ __launch_bounds__(256, 2) void attention2_kernel(const uint16_t* __re
     }
 }
 
+// ================================================================================================================
+// v3: v2's 64-query waves with the two query blocks of a wave STAGGERED so that, inside one wave's instruction stream,
+// the matrix pipe always has work queued beside the softmax VALU work (rocprof on v2: MFMA busy 22 %, VALU active 40 %,
+// waves parked 44 % -- the two co-resident waves of a SIMD run in lock step, so nothing overlapped):
+//     QK(A) | QK(B) + softmax(A) | PV(A) + softmax(B) | PV(B)
+// QK(B)'s MFMAs do not depend on softmax(A) and PV(A)'s do not depend on softmax(B); sched_group_barrier pins the
+// interleave (1 MFMA : its share of VALU / transcendental / LDS-read instructions) the compiler would otherwise undo by
+// clustering.  K / V^T fragments are re-read per query block (the LDS was never the limit).  The O rescale is
+// unconditional (16 packed multiplies) to keep the tile body one basic block.
+// ================================================================================================================
+template <typename T, bool LAST>
+__device__ __forceinline__ void att3_softmax(f32x16 (&s)[2], f32x16 (&o)[2], float& m, float& l, typename T::v8 (&pf)[2][2],
+                                             int t, int g) {
+    if (LAST) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * ATT_KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (key >= VIT_TOKENS) s[kb][r] = -1e30f;
+            }
+    }
+    float tmax = max3f(s[0][0], s[0][1], s[0][2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) tmax = max3f(tmax, s[0][r], s[0][r + 1]);
+    tmax = max3f(tmax, s[0][15], s[1][0]);
+#pragma unroll
+    for (int r = 1; r < 15; r += 2) tmax = max3f(tmax, s[1][r], s[1][r + 1]);
+    tmax = max3f(tmax, s[1][15], s[1][15]);
+    const float m_new = max3f(tmax, __shfl_xor(tmax, 32, 64), m);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    m = m_new;
+    const f32x2 m2 = {m_new, m_new};
+    f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            u32x4 pw;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const f32x2 sv = {s[kb][8 * s2 + 2 * w], s[kb][8 * s2 + 2 * w + 1]};
+                const f32x2 d = sv - m2;
+                const f32x2 pv = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+                ps2 += pv;
+                pw[w] = T::pack2(pv[0], pv[1]);
+            }
+            pf[kb][s2] = __builtin_bit_cast(typename T::v8, pw);
+        }
+    l = l * alpha + (ps2[0] + ps2[1]);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+}
+
+template <typename T>
+__device__ __forceinline__ void att3_qk(f32x16 (&s)[2], const typename T::v8 (&qf)[4], const char* ks, const int (&kxoff)[4], int lq) {
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ksi = 0; ksi < 4; ++ksi) {
+            const typename T::v8 kf = *(const typename T::v8*)(ks + (kb * 32 + lq) * K_ROWB + kxoff[ksi]);
+            s[kb] = T::mfma(kf, qf[ksi], ksi == 0 ? zero16 : s[kb]);
+        }
+}
+
+template <typename T>
+__device__ __forceinline__ void att3_pv(f32x16 (&o)[2], const typename T::v8 (&pf)[2][2], const char* vt, int lq, int g) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const char* vrow = vt + (db * 32 + lq) * VT_STRIDE + (kb * 32 + 16 * s2 + 4 * g) * 2;
+                const u32x2 lo = *(const u32x2*)(vrow);        // keys +0..3
+                const u32x2 hi = *(const u32x2*)(vrow + 16);   // keys +8..11
+                u32x4 vw; vw[0] = lo[0]; vw[1] = lo[1]; vw[2] = hi[0]; vw[3] = hi[1];
+                o[db] = T::mfma(__builtin_bit_cast(typename T::v8, vw), pf[kb][s2], o[db]);
+            }
+}
+
+// One 64-key tile for a wave.  NQ = 2: both query blocks (staggered); NQ = 1: only the first (the wave that holds token 576).
+template <typename T, int NQ, bool LAST>
+__device__ __forceinline__ void att3_tile(const char* ks, const char* vt, const typename T::v8 (&qf)[2][4], f32x16 (&o)[2][2],
+                                          float (&m)[2], float (&l)[2], const int (&kxoff)[4], int lq, int g, int t) {
+    f32x16 sA[2], sB[2];
+    typename T::v8 pfA[2][2], pfB[2][2];
+    att3_qk<T>(sA, qf[0], ks, kxoff, lq);                                      // QK(A)
+    if (NQ == 2) att3_qk<T>(sB, qf[1], ks, kxoff, lq);                         // QK(B)      beside
+    att3_softmax<T, LAST>(sA, o[0], m[0], l[0], pfA, t, g);                    // softmax(A)
+    att3_pv<T>(o[0], pfA, vt, lq, g);                                          // PV(A)      beside
+    if (NQ == 2) {
+        att3_softmax<T, LAST>(sB, o[1], m[1], l[1], pfB, t, g);                // softmax(B)
+        att3_pv<T>(o[1], pfB, vt, lq, g);                                      // PV(B)
+    }
+    if (NQ == 2) {
+        // stage 1: QK(A) alone: 8 x {LDS read, MFMA}
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        // stage 2: QK(B) beside softmax(A): 8 x {LDS read, MFMA, 12 VALU, 4 transcendental}
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        // stage 3: PV(A) beside softmax(B): 8 x {2 LDS reads, MFMA, 12 VALU, 4 transcendental}
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        // stage 4: PV(B) alone
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attention3_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * K_TILE_BYTES + 2 * VT_TILE_BYTES];
+    char* ks0 = smem;
+    char* vt0 = smem + 2 * K_TILE_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, g = lane >> 5;
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int qb = slot % ATT2_NQB;
+    const int pair = (slot / ATT2_NQB) * 8 + xcd;
+    const int img = pair >> 4, head = pair & 15;
+    const int64_t base = (int64_t)img * VIT_TOKENS;
+
+    const int q_first = qb * ATT2_QB + wave * 64;           // wave-uniform
+    const bool act0 = q_first < VIT_TOKENS;
+    const bool act1 = q_first + 32 < VIT_TOKENS;
+
+    typename T::v8 qf[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int qrow = q_first + b * 32 + lq;
+        const int qr = qrow < VIT_TOKENS ? qrow : VIT_TOKENS - 1;
+#pragma unroll
+        for (int ksi = 0; ksi < 4; ++ksi)
+            qf[b][ksi] = *(const typename T::v8*)(qkv + (base + qr) * QKV_LD + head * 64 + ksi * 16 + g * 8);
+    }
+    f32x16 o[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[b][db][r] = 0.f;
+    float m[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f};
+    int kxoff[4];
+#pragma unroll
+    for (int ksi = 0; ksi < 4; ++ksi) kxoff[ksi] = ((ksi * 2 + g) ^ ((lq >> 1) & 7)) << 4;
+
+    StageRegs st;
+    att_load_tile(st, qkv, base, head, 0, tid);
+    att_store_tile(st, ks0, vt0, tid);
+    __syncthreads();
+
+    for (int t = 0; t < ATT_NT; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ATT_NT) att_load_tile(st, qkv, base, head, t + 1, tid);   // in flight during the math
+        const char* ks = ks0 + cur * K_TILE_BYTES;
+        const char* vt = vt0 + cur * VT_TILE_BYTES;
+        if (act1) {
+            if (t < ATT_NT - 1) att3_tile<T, 2, false>(ks, vt, qf, o, m, l, kxoff, lq, g, t);
+            else att3_tile<T, 2, true>(ks, vt, qf, o, m, l, kxoff, lq, g, t);
+        } else if (act0) {
+            if (t < ATT_NT - 1) att3_tile<T, 1, false>(ks, vt, qf, o, m, l, kxoff, lq, g, t);
+            else att3_tile<T, 1, true>(ks, vt, qf, o, m, l, kxoff, lq, g, t);
+        }
+        if (t + 1 < ATT_NT) att_store_tile(st, ks0 + (cur ^ 1) * K_TILE_BYTES, vt0 + (cur ^ 1) * VT_TILE_BYTES, tid);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (b == 0 ? !act0 : !act1) break;
+        const float ltot = l[b] + __shfl_xor(l[b], 32, 64);
+        const float inv = 1.0f / ltot;
+        const int qrow = q_first + b * 32 + lq;
+        if (qrow < VIT_TOKENS) {
+            uint16_t* orow = out + (base + qrow) * VIT_HIDDEN + head * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    u32x2 pk;
+                    pk[0] = pack16x2<T>(o[b][db][4 * q4] * inv, o[b][db][4 * q4 + 1] * inv);
+                    pk[1] = pack16x2<T>(o[b][db][4 * q4 + 2] * inv, o[b][db][4 * q4 + 3] * inv);
+                    *(u32x2*)(orow + db * 32 + 8 * q4 + 4 * g) = pk;
+                }
+        }
+    }
+}
+
+// ================================================================================================================
+// v4: v1's geometry (32 queries per wave, 128-query blocks, 5 blocks per (image, head)) with the softmax instruction diet
+// of v2/v3 (att3_softmax): the small per-wave state (O 32 + S 32 + Q 16 registers) is what lets 3-4 waves share a SIMD, and
+// with that many independent waves the hardware overlaps one wave's MFMAs with another's softmax by itself.
+// ================================================================================================================
+template <typename T, int WAVES_PER_SIMD, int ABL = 0>   // ABL (timing only, wrong results): 1 no K/V staging in the loop, 2 no softmax
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention4_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * K_TILE_BYTES + 2 * VT_TILE_BYTES];
+    char* ks0 = smem;
+    char* vt0 = smem + 2 * K_TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, g = lane >> 5;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int qb = slot % ATT_NQB;
+    const int pair = (slot / ATT_NQB) * 8 + xcd;
+    const int img = pair >> 4, head = pair & 15;
+    const int64_t base = (int64_t)img * VIT_TOKENS;
+    const int q_first = qb * ATT_QB + wave * 32;            // wave-uniform
+    const bool wave_active = q_first < VIT_TOKENS;
+    const int qrow = q_first + lq;
+    const int qr = qrow < VIT_TOKENS ? qrow : VIT_TOKENS - 1;
+
+    typename T::v8 qf[4];
+#pragma unroll
+    for (int ksi = 0; ksi < 4; ++ksi)
+        qf[ksi] = *(const typename T::v8*)(qkv + (base + qr) * QKV_LD + head * 64 + ksi * 16 + g * 8);
+    f32x16 o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m = -1e30f, l = 0.f;
+    int kxoff[4];
+#pragma unroll
+    for (int ksi = 0; ksi < 4; ++ksi) kxoff[ksi] = ((ksi * 2 + g) ^ ((lq >> 1) & 7)) << 4;
+
+    StageRegs st;
+    att_load_tile(st, qkv, base, head, 0, tid);
+    att_store_tile(st, ks0, vt0, tid);
+    __syncthreads();
+    for (int t = 0; t < ATT_NT; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ATT_NT && !(ABL & 1)) att_load_tile(st, qkv, base, head, t + 1, tid);
+        const char* ks = ks0 + cur * K_TILE_BYTES;
+        const char* vt = vt0 + cur * VT_TILE_BYTES;
+        if (wave_active) {
+            f32x16 sA[2];
+            typename T::v8 pfA[2][2];
+            att3_qk<T>(sA, qf, ks, kxoff, lq);
+            if (ABL & 2) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        u32x4 pw;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) pw[w] = __builtin_bit_cast(uint32_t, sA[kb][8 * s2 + 2 * w]);
+                        pfA[kb][s2] = __builtin_bit_cast(typename T::v8, pw);
+                    }
+            } else if (t < ATT_NT - 1) att3_softmax<T, false>(sA, o, m, l, pfA, t, g);
+            else att3_softmax<T, true>(sA, o, m, l, pfA, t, g);
+            att3_pv<T>(o, pfA, vt, lq, g);
+        }
+        if (t + 1 < ATT_NT && !(ABL & 1)) att_store_tile(st, ks0 + (cur ^ 1) * K_TILE_BYTES, vt0 + (cur ^ 1) * VT_TILE_BYTES, tid);
+        if (!(ABL & 4)) __syncthreads();
+    }
+    if (wave_active) {
+        const float ltot = l + __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / ltot;
+        if (qrow < VIT_TOKENS) {
+            uint16_t* orow = out + (base + qrow) * VIT_HIDDEN + head * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    u32x2 pk;
+                    pk[0] = pack16x2<T>(o[db][4 * q4] * inv, o[db][4 * q4 + 1] * inv);
+                    pk[1] = pack16x2<T>(o[db][4 * q4 + 2] * inv, o[db][4 * q4 + 3] * inv);
+                    *(u32x2*)(orow + db * 32 + 8 * q4 + 4 * g) = pk;
+                }
+        }
+    }
+}
+
 static int attention_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("PIGEON_ATTN_VARIANT");
-        v = e ? atoi(e) : 2;
-        if (v != 1 && v != 2) v = 2;
+        v = e ? atoi(e) : 4;
+        if (v < 1 || v > 9) v = 4;
     }
     return v;
 }
@@ -404,8 +708,31 @@ static int attention_variant() {
 int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hipStream_t s) {
     if (n_images <= 0) return PG_OK;
     const int pairs = n_images * VIT_HEADS;                  // always a multiple of 8
-    const bool v2 = attention_variant() == 2;
-    const dim3 grid(pairs * (v2 ? ATT2_NQB : ATT_NQB)), block(256);
+    const int var = attention_variant();
+    const bool v2 = var == 2;
+    const dim3 grid(pairs * ((var == 2 || var == 3) ? ATT2_NQB : ATT_NQB)), block(256);
+    if (var >= 6 && var <= 9 && dtype == PG_DTYPE_F16) {         // ablations of variant 4 (timing only)
+        if (var == 6) hipLaunchKernelGGL((attention4_kernel<T_F16, 3, 1>), grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+        if (var == 7) hipLaunchKernelGGL((attention4_kernel<T_F16, 3, 2>), grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+        if (var == 8) hipLaunchKernelGGL((attention4_kernel<T_F16, 3, 5>), grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+        if (var == 9) hipLaunchKernelGGL((attention4_kernel<T_F16, 3, 7>), grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+        return pg_check_launch("attention");
+    }
+    if ((var == 4 || var == 5) && (dtype == PG_DTYPE_F16 || dtype == PG_DTYPE_BF16)) {
+        if (var == 4) {
+            if (dtype == PG_DTYPE_F16) hipLaunchKernelGGL((attention4_kernel<T_F16, 3>), grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+            else hipLaunchKernelGGL((attention4_kernel<T_BF16, 3>), grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+        } else {
+            if (dtype == PG_DTYPE_F16) hipLaunchKernelGGL((attention4_kernel<T_F16, 4>), grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+            else hipLaunchKernelGGL((attention4_kernel<T_BF16, 4>), grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+        }
+        return pg_check_launch("attention");
+    }
+    if (var == 3 && (dtype == PG_DTYPE_F16 || dtype == PG_DTYPE_BF16)) {
+        if (dtype == PG_DTYPE_F16) hipLaunchKernelGGL(attention3_kernel<T_F16>, grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+        else hipLaunchKernelGGL(attention3_kernel<T_BF16>, grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+        return pg_check_launch("attention");
+    }
     if (dtype == PG_DTYPE_F16) {
         if (v2) hipLaunchKernelGGL(attention2_kernel<T_F16>, grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
         else hipLaunchKernelGGL(attention_kernel<T_F16>, grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);

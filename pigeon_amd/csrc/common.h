@@ -83,13 +83,11 @@ __device__ __forceinline__ uint32_t pack16x2(float lo, float hi) {
     return (uint32_t)T::bits(lo) | ((uint32_t)T::bits(hi) << 16);
 }
 
-// 3-input max as ONE instruction.  Through fmaxf() hipcc first canonicalises MFMA results (v_max_f32 x, x, x per input),
-// which tripled the instruction count of the softmax row maximum.
-__device__ __forceinline__ float max3f(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+// 3-input max: nested __builtin_fmaxf folds to one v_max3_f32 (HIP's fmaxf() wrapper first canonicalises every input with
+// a v_max_f32 x, x, x, which tripled the instruction count of the softmax row maximum).  Deliberately NOT inline asm: the
+// compiler pads the MFMA-result -> VALU-read hazard (s_nop) only for instructions it can see; an asm v_max3_f32 reading a
+// fresh accumulator gave wrong maxima as soon as the schedule placed it right behind the MFMA.
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
