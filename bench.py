@@ -99,19 +99,23 @@ def cpu_baseline(args, vit_sd, model, bank_t, pixels_dev):
             "cpu_model": _cpu_model()}, o
 
 
-def _committed_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (profiles/rNN/traffic.json;
-    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).  Counters cannot be read from inside the process; None if absent."""
+def _committed_traffic(kernel, rows):
+    """Memory-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (profiles/rNN/traffic.json:
+    2 x FETCH_SIZE -- the gfx950 correction of MI355X_MICROARCH.md -- + WRITE_SIZE, separate --pmc passes over this very
+    command, tools/prof_bench.sh).  Counters cannot be read from inside the process; (None, None) if there is no pass
+    for this launch size."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
         try:
             d = json.load(open(f))
-            if kernel in d and "hbm_bytes_per_launch_corrected" in d[kernel]:
-                return {"bytes_per_launch": d[kernel]["hbm_bytes_per_launch_corrected"],
-                        "algorithmic_bytes": d[kernel].get("algorithmic_bytes"), "source": os.path.relpath(f, ROOT)}
+            if kernel in d and "hbm_bytes_per_launch_corrected" in d[kernel] and d[kernel].get("rows") == rows:
+                return d[kernel]["hbm_bytes_per_launch_corrected"], {
+                    "algorithmic_bytes": d[kernel].get("algorithmic_bytes"), "source": os.path.relpath(f, ROOT),
+                    "note": "counts L2-miss traffic on the fabric side (Infinity Cache hits included): the 8 MB fc1 weight "
+                            "matrix does not fit the 4 MB L2 and is re-streamed by every XCD each round"}
         except (OSError, ValueError):
             pass
-    return None
+    return None, None
 
 
 def _cpu_model():
@@ -198,14 +202,15 @@ def main():
     for name, (cnt, ms) in prof.items():
         if cnt:
             kernels[name] = {"launches": cnt, "avg_ms": ms / cnt}
-    # per-launch rows: the encoder processes <= 256 images per internal pass (chunk), so a 512-image step launches
-    # every layer kernel twice with M = 256*577 rows each
+    # per-launch rows: the encoder processes <= max_chunk (512) images per internal pass, so a 512-image step launches
+    # every layer kernel once with M = 512*577 rows
     chunk_rows = min(args.panoramas * 4, enc.max_chunk) * 577
     for name in GEMM_FLOPS:
         if name in kernels:
             kernels[name]["tflops"] = GEMM_FLOPS[name] * chunk_rows / (kernels[name]["avg_ms"] * 1e-3) / 1e12
     dom = max((k for k in kernels if k in GEMM_FLOPS), key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
     achieved = kernels[dom]["tflops"]
+    traffic, traffic_detail = _committed_traffic(dom, chunk_rows)
     result = {
         "metric": "images/sec end-to-end (ViT+head+refine), 4x336x336",
         "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -219,7 +224,7 @@ def main():
         "mfma_frac_end_to_end": value * FLOP_PER_IMAGE / (world * PEAK_MFMA),
         "roofline": {"bound": "mfma", "kernel": f"gemm16 {dom}: M={chunk_rows} rows x {GEMM_FLOPS[dom]} FLOP/row per launch",
                      "achieved": achieved, "peak": PEAK_MFMA / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_MFMA / 1e12),
-                     "traffic": _committed_traffic(dom),
+                     "traffic": traffic, "traffic_detail": traffic_detail,
                      "note": "sustained MFMA ceiling on non-zero data is ~1750 TFLOP/s (DVFS, tools/mfma_peak.hip); peak is the 2.4 GHz datasheet number"},
         "kernels": kernels,
     }
