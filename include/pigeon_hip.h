@@ -209,6 +209,21 @@ int pg_op_gemm16(int dtype, const void* A, int64_t lda, const void* W, const flo
 int pg_op_gemm16_ld(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out,
                     int64_t ldc, int M, int N, int K, int epi, float qscale, int qcols, const float* aux,
                     int variant, void* stream);
+/* The "LayerNorm folded into the GEMM" building blocks the encoder uses (persistent kernel only: N % 256 == 0,
+ * K % 128 == 0; see csrc/vit.hip):
+ *   pg_op_rowstat_cast      x fp32 (rows,1024) -> x16 (rows,1024) 16-bit copy, rowstat (rows,2) = (rstd, mean*rstd)
+ *   pg_op_gemm16_resid_stat X (M,ldc) fp32 += A.W^T + bias; x16 (M,ldx) = 16-bit copy of the new rows; statpart
+ *                           (N/64, M, 2) fp32 = per-64-column (sum, sum of squares) of the new rows; ldx == ldc
+ *   pg_op_rowstat_finalize  statpart -> rowstat (rstd, mean*rstd) over `slots` slices of a 1024-wide row
+ *   pg_op_gemm16_ln         out 16-bit = epi(rowstat[m].rstd * acc - rowstat[m].mean_rstd * colsum[n] + bias[n]),
+ *                           epi 6 = QKV form (columns < qcols scaled by qscale), 7 = QuickGELU form. */
+int pg_op_rowstat_cast(const float* x, void* x16, int dtype, float* rowstat, int64_t rows, float eps, void* stream);
+int pg_op_gemm16_resid_stat(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* X,
+                            int64_t ldc, void* x16, int64_t ldx, float* statpart, int M, int N, int K, int variant, void* stream);
+int pg_op_rowstat_finalize(const float* statpart, int slots, float* rowstat, int64_t rows, float eps, void* stream);
+int pg_op_gemm16_ln(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* colsum,
+                    const float* rowstat, void* out, int64_t ldc, int M, int N, int K, int epi, float qscale, int qcols,
+                    int variant, void* stream);
 /* y = LayerNorm(x) over the last dim (1024), eps, gamma/beta fp32.  x fp32 (rows,1024).
  * out_dtype PG_DTYPE_F16/BF16 -> y 16-bit (rows,1024); PG_DTYPE_F32 -> fp32 (may alias x). */
 int pg_op_layernorm(const float* x, const float* gamma, const float* beta, void* y, int out_dtype,

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpigeon_hip.so")
 
 PG_DTYPE_F32, PG_DTYPE_BF16, PG_DTYPE_F16, PG_DTYPE_F64 = 0, 1, 2, 3
-EPI_QKV, EPI_GELU, EPI_RESID, EPI_PATCH, EPI_F32 = 0, 1, 2, 3, 4
+EPI_QKV, EPI_GELU, EPI_RESID, EPI_PATCH, EPI_F32, EPI_RESID_STAT, EPI_QKV_LN, EPI_GELU_LN = 0, 1, 2, 3, 4, 5, 6, 7
 PROF_CLASSES = ["gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2", "gemm_patch", "attention", "layernorm",
                 "im2col", "token_mean"]
 
@@ -60,6 +60,10 @@ SIGNATURES = {
     "pg_refine_forward": (_I, [C.POINTER(Bank), _P, _I, _I, _P, _P, _P, _I, _I, _F, _D, _P, _P, _P, _P, _P]),
     "pg_op_gemm16": (_I, [_I, _P, _I64, _P, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _P, _I, _P]),
     "pg_op_gemm16_ld": (_I, [_I, _P, _I64, _P, _I64, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _P, _I, _P]),
+    "pg_op_rowstat_cast": (_I, [_P, _P, _I, _P, _I64, _F, _P]),
+    "pg_op_gemm16_resid_stat": (_I, [_I, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _P, _I, _I, _I, _I, _P]),
+    "pg_op_rowstat_finalize": (_I, [_P, _I, _P, _I64, _F, _P]),
+    "pg_op_gemm16_ln": (_I, [_I, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _I, _P]),
     "pg_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I64, _F, _P]),
     "pg_op_attention": (_I, [_I, _P, _P, _I, _P]),
     "pg_op_im2col": (_I, [_P, _I, _P, _I, _I, _P]),

@@ -458,13 +458,16 @@ static int gemm_dispatch(GemmArgs& g, int epi, int variant, hipStream_t s) {
 
 int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldc,
                    int M, int N, int K, int epi, float qscale, int qcols, const float* aux, int variant,
-                   hipStream_t s) {
+                   hipStream_t s, const PgGemmExtra* extra) {
     if (M <= 0) return PG_OK;
     GemmArgs g;
     g.A = (const uint16_t*)A; g.lda = lda; g.W = (const uint16_t*)W; g.ldw = ldw > 0 ? ldw : K; g.bias = bias; g.out = out; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.qscale = qscale; g.qcols = qcols; g.aux = aux;
     g.tilesM = 0; g.tilesN = 0; g.ntiles = 0; g.gn = 0; g.stagger = 0;
-    if ((epi == EPI_GELU || epi == EPI_RESID) && !bias) { pg_set_error("gemm: epilogue %d needs a bias", epi); return PG_EINVAL; }
+    if (extra) g.ex = *extra;
+    if ((epi == EPI_GELU || epi == EPI_RESID || epi >= EPI_RESID_STAT) && !bias) { pg_set_error("gemm: epilogue %d needs a bias", epi); return PG_EINVAL; }
+    if (epi == EPI_RESID_STAT && (!g.ex.x16 || !g.ex.statpart || g.ex.ldx != ldc)) { pg_set_error("gemm: EPI_RESID_STAT needs x16 / statpart and ldx == ldc"); return PG_EINVAL; }
+    if ((epi == EPI_QKV_LN || epi == EPI_GELU_LN) && (!g.ex.colsum || !g.ex.rowstat)) { pg_set_error("gemm: LN epilogue needs colsum / rowstat"); return PG_EINVAL; }
     if (epi == EPI_PATCH && !aux) { pg_set_error("gemm: patch epilogue needs aux"); return PG_EINVAL; }
     if ((lda % 8) || (ldc % 8) || (qcols % 8) || (g.ldw % 8) || g.ldw < K) { pg_set_error("gemm: lda/ldw/ldc/qcols must be multiples of 8, ldw >= K"); return PG_EINVAL; }
     if (variant == 0) variant = pg_default_gemm_variant();
@@ -473,6 +476,7 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
         if (N % 256 == 0 && K % 128 == 0) return pg_gemm_pp_launch(dtype, g, epi, variant, s);
         variant = 8;
     }
+    if (epi >= EPI_RESID_STAT) { pg_set_error("gemm: epilogue %d exists only in the persistent kernel (variants 30..49, N %% 256 == 0, K %% 128 == 0)", epi); return PG_EINVAL; }
     if (dtype == PG_DTYPE_F16) return gemm_dispatch<T_F16>(g, epi, variant, s);
     if (dtype == PG_DTYPE_BF16) return gemm_dispatch<T_BF16>(g, epi, variant, s);
     pg_set_error("gemm: operand dtype must be PG_DTYPE_F16 or PG_DTYPE_BF16 (got %d)", dtype);

@@ -18,6 +18,7 @@ struct GemmArgs {
     int tilesM, tilesN, ntiles;
     int gn;                       // N tiles per raster group (see tile_coords)
     int stagger;                  // gemm_pp: shader cycles of one output tile (0 = blocks start together)
+    PgGemmExtra ex;               // LayerNorm-fold epilogues (EPI_RESID_STAT / EPI_QKV_LN / EPI_GELU_LN)
 };
 
 // gemm_pp.hip: persistent ping-pong kernel (variants 30..39); tilesM/tilesN/ntiles are filled in by the callee

@@ -196,32 +196,72 @@ __device__ __forceinline__ void wave_lds_fence() {
 // Bias of the lane's row-major columns, fetched at the START of an output tile (before the K loop) and forced to
 // retire there: a global_load that is still "pending" in the compiler's scoreboard when the epilogue runs would make
 // it insert vmcnt(0) in front of every use -- which also drains the epilogue's own stores and the next tile's DMA.
-template <int EPI> struct EpiBias { f32x4 lo, hi; };
+template <int EPI> constexpr bool epi_out16() { return EPI == EPI_QKV || EPI == EPI_GELU || EPI == EPI_QKV_LN || EPI == EPI_GELU_LN; }
+template <int EPI> constexpr bool epi_ln() { return EPI == EPI_QKV_LN || EPI == EPI_GELU_LN; }
+// 8 columns per lane on the store side (16-bit outputs, and the fp32 residual epilogue that also emits the 16-bit copy)
+template <int EPI> constexpr bool epi_wide() { return epi_out16<EPI>() || EPI == EPI_RESID_STAT; }
+
+// Per-tile epilogue operands fetched at the START of the tile (or, for the next tile, before the current epilogue's
+// stores): bias (lo/hi), for the LN epilogues colsum (slo/shi) and (rstd, mean*rstd) of the 16 rows this lane will store.
+template <int EPI> struct EpiBias { f32x4 lo, hi, slo, shi; };
 
 template <int EPI>
 __device__ __forceinline__ void load_bias(EpiBias<EPI>& b, const GemmArgs& g, int col) {
-    constexpr bool OUT16 = (EPI == EPI_QKV || EPI == EPI_GELU);
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    b.lo = z; b.hi = z;
+    b.lo = z; b.hi = z; b.slo = z; b.shi = z;
     if (g.bias) {
         b.lo = *(const f32x4*)(g.bias + col);
-        if (OUT16) b.hi = *(const f32x4*)(g.bias + col + 4);
+        if (epi_wide<EPI>()) b.hi = *(const f32x4*)(g.bias + col + 4);
     }
+    if constexpr (epi_ln<EPI>()) {
+        b.slo = *(const f32x4*)(g.ex.colsum + col);
+        b.shi = *(const f32x4*)(g.ex.colsum + col + 4);
+    }
+}
+// (rstd, mean*rstd) of the 16 rows this lane stores: issued right after the tile's first wait, lands under the K loop
+template <int EPI>
+__device__ __forceinline__ void load_rowstat(u32x2 (&rs)[4][4], const GemmArgs& g, int row0, int rr) {
+    int rvs = g.M - row0; rvs = rvs < 0 ? 0 : (rvs > 128 ? 128 : rvs);
+    __amdgpu_buffer_rsrc_t rr_s = make_rsrc((const char*)g.ex.rowstat + (int64_t)row0 * 8, (uint32_t)rvs * 8u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            rs[i][it] = __builtin_amdgcn_raw_buffer_load_b64(rr_s, (rr + i * 32 + it * 8) * 8, 0, 0);
 }
 template <int EPI>
 __device__ __forceinline__ void pin_bias(EpiBias<EPI>& b) {
     // a use: the compiler's wait for the loads lands here
-    if constexpr (EPI == EPI_QKV || EPI == EPI_GELU) asm volatile("" : "+v"(b.lo), "+v"(b.hi));
+    if constexpr (epi_ln<EPI>()) asm volatile("" : "+v"(b.lo), "+v"(b.hi), "+v"(b.slo), "+v"(b.shi));
+    else if constexpr (epi_wide<EPI>()) asm volatile("" : "+v"(b.lo), "+v"(b.hi));
     else asm volatile("" : "+v"(b.lo));
 }
 
-template <typename T, int EPI>
+// Sum over the 8 consecutive lanes that hold one output row on the 8-columns-per-lane store side, result in every lane;
+// fixed association order, so the row statistics depend on nothing but the data.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row8_sum(float v) {
+    v += dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);      // row_half_mirror: lane i <-> 7 - i inside each group of 8
+    return v;
+}
+
+template <typename T, int EPI, typename PREFETCH>
 __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs& g, char* smem, int wave, int lane,
-                                            int row0, int col0, const EpiBias<EPI>& bias) {
-    constexpr bool OUT16 = (EPI == EPI_QKV || EPI == EPI_GELU);
+                                            int row0, int col0, const EpiBias<EPI>& bias, const u32x2 (&rs)[4][4],
+                                            PREFETCH&& prefetch_next) {
+    constexpr bool OUT16 = epi_out16<EPI>();
+    constexpr bool LN = epi_ln<EPI>();
+    constexpr bool STAT = (EPI == EPI_RESID_STAT);
+    constexpr bool RESID = (EPI == EPI_RESID || EPI == EPI_RESID_STAT);
+    constexpr bool WIDE = epi_wide<EPI>();
     constexpr int ROWPF = PP_SLAB_ROWF;
     constexpr int ESZ = OUT16 ? 2 : 4;
-    constexpr int CPL = 16 / ESZ;                            // columns per lane on the row-major side (16-byte stores)
+    constexpr int CPL = WIDE ? 8 : 4;                        // columns per lane on the row-major side
     constexpr int LPR = 64 / CPL, RPI = 64 / LPR, ITS = 32 / RPI;
     const int lrow = lane & 31, lhalf = lane >> 5;
     float* slab = (float*)(smem + PP_SLAB_OFF + wave * PP_SLAB_BYTES);
@@ -229,6 +269,7 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs&
     const int col = col0 + cc;
 
     if constexpr (EPI == EPI_PATCH) {
+        prefetch_next();
         // rows are re-mapped (image, patch) -> token row and the position embedding is added: generic guarded path
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -251,7 +292,7 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs&
         }
         return;
     } else {
-        // Output (and, for EPI_RESID, residual input) through a buffer descriptor based at the wave's (row0, col0):
+        // Output (and, for EPI_RESID*, residual input) through a buffer descriptor based at the wave's (row0, col0):
         // rows past M fail the bounds check (stores dropped, loads return 0), so there is no exec-mask branching and
         // no per-store 64-bit address arithmetic: voffset is one VGPR, the slab/iteration row offset is an SGPR.
         int rv = g.M - row0; rv = rv < 0 ? 0 : (rv > 128 ? 128 : rv);
@@ -264,13 +305,30 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs&
         // in SGPRs across the K loop (the fp32 epilogues then spill)
         asm volatile("" : "+s"(rstep), "+s"(sstep));
 
-        // EPI_RESID: the fp32 residual rows are fetched one slab ahead of their use (two register sets)
-        u32x4 xr[2][EPI == EPI_RESID ? ITS : 1];
+        // EPI_RESID_STAT: 16-bit copy of the new rows (one 16-byte store per lane; ldx == ldc, checked on the host, so its
+        // byte offsets are half the fp32 ones) and per-row partial statistics (sum, sum of squares over this wave's 64
+        // columns), parked in the 4 padding floats of the slab rows and written slot-major -- statpart[slot][row][2] --
+        // with one coalesced 256-byte store per slab.
+        __amdgpu_buffer_rsrc_t rx16 = ro;
+        float* stat_base = nullptr;
+        if constexpr (STAT) {
+            const uint32_t nb16 = rv > 0 ? (uint32_t)(((int64_t)(rv - 1) * g.ldc + 64) * 2) : 0u;
+            rx16 = make_rsrc((const char*)g.ex.x16 + ((int64_t)row0 * g.ldc + col0) * 2, nb16);
+            stat_base = g.ex.statpart + ((int64_t)(col0 / 64) * g.M + row0) * 2;
+        }
+        // LN epilogues issue the next tile's prefetch after slab 0 (their row statistics were loaded at the tile top and
+        // must be consumed without waiting for anything younger); everything else issues it first.
+        if constexpr (!LN) prefetch_next();
+        // EPI_RESID*: the fp32 residual rows are fetched one slab ahead of their use (two register sets)
+        constexpr int XPI = WIDE ? 2 : 1;                    // 16-byte pieces per lane per iteration
+        u32x4 xr[2][RESID ? ITS : 1][RESID ? XPI : 1];
         auto fetch_x = [&](int i, int set) {
-            if constexpr (EPI == EPI_RESID) {
+            if constexpr (RESID) {
 #pragma unroll
                 for (int it = 0; it < ITS; ++it)
-                    xr[set][it] = __builtin_amdgcn_raw_buffer_load_b128(ro, voff, i * sstep + it * rstep, 0);
+#pragma unroll
+                    for (int h = 0; h < XPI; ++h)
+                        xr[set][it][h] = __builtin_amdgcn_raw_buffer_load_b128(ro, voff + 16 * h, i * sstep + it * rstep, 0);
             }
         };
         fetch_x(0, 0);
@@ -289,31 +347,69 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs&
             for (int it = 0; it < ITS; ++it) {
                 const int r = it * RPI + rr;
                 f32x4 lo = *(const f32x4*)(slab + r * ROWPF + cc);
-                u32x4 pk;
+                f32x4 hi = lo;
+                if constexpr (WIDE) hi = *(const f32x4*)(slab + r * ROWPF + cc + 4);
+                // The row offset of every store goes into the VGPR offset, NOT the SGPR soffset: with a register soffset
+                // hipcc pads no wait states after a >64-bit buffer store and lets the next VALU overwrite the data
+                // registers while the store is still reading them (measured on gfx950: dword 3 of ~3 % of such stores
+                // corrupted).
+                const int ooff = voff + (i * sstep + it * rstep);
                 if constexpr (OUT16) {
-                    f32x4 hi = *(const f32x4*)(slab + r * ROWPF + cc + 4);
-                    lo += bias.lo; hi += bias.hi;
-                    if constexpr (EPI == EPI_QKV) {
+                    if constexpr (LN) {
+                        // LayerNorm applied after the product: rstd * acc - (mean * rstd) * colsum + (beta.W^T + b).
+                        // Both scalars go through an asm move into registers of their own: with (rstd, mean*rstd) left as
+                        // the two halves of the loaded dwordx2, hipcc (ROCm 7.2) SLP-packs the fmas below into
+                        // v_pk_fma_f32 and broadcasts the LOW half for both (op_sel of the high half dropped): every row
+                        // used rstd in place of mean*rstd (caught by test_ln_fold_building_blocks).
+                        float rstd, mrs;
+                        asm("v_mov_b32 %0, %1" : "=v"(rstd) : "v"(rs[i][it][0]));
+                        asm("v_mov_b32 %0, %1" : "=v"(mrs) : "v"(rs[i][it][1]));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            lo[e] = fmaf(lo[e], rstd, fmaf(-mrs, bias.slo[e], bias.lo[e]));
+                            hi[e] = fmaf(hi[e], rstd, fmaf(-mrs, bias.shi[e], bias.hi[e]));
+                        }
+                    } else {
+                        lo += bias.lo; hi += bias.hi;
+                    }
+                    if constexpr (EPI == EPI_QKV || EPI == EPI_QKV_LN) {
                         if (col < g.qcols) { lo *= g.qscale; hi *= g.qscale; }   // qcols is a multiple of 8
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { lo[e] = quick_gelu(lo[e]); hi[e] = quick_gelu(hi[e]); }
                     }
+                    u32x4 pk;
                     pk[0] = pack16x2<T>(lo[0], lo[1]); pk[1] = pack16x2<T>(lo[2], lo[3]);
                     pk[2] = pack16x2<T>(hi[0], hi[1]); pk[3] = pack16x2<T>(hi[2], hi[3]);
-                } else if constexpr (EPI == EPI_RESID) {
-                    f32x4 x = __builtin_bit_cast(f32x4, xr[i & 1][it]);
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, ro, ooff, 0, 0);
+                } else if constexpr (RESID) {
+                    f32x4 x = __builtin_bit_cast(f32x4, xr[i & 1][it][0]);
                     x += lo + bias.lo;                       // same expression as epi_store_f32x4<EPI_RESID>
-                    pk = __builtin_bit_cast(u32x4, x);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), ro, ooff, 0, 0);
+                    if constexpr (STAT) {
+                        f32x4 y = __builtin_bit_cast(f32x4, xr[i & 1][it][1]);
+                        y += hi + bias.hi;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, ooff + 16, 0, 0);
+                        u32x4 h4;
+                        h4[0] = pack16x2<T>(x[0], x[1]); h4[1] = pack16x2<T>(x[2], x[3]);
+                        h4[2] = pack16x2<T>(y[0], y[1]); h4[3] = pack16x2<T>(y[2], y[3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(h4, rx16, ooff >> 1, 0, 0);
+                        const float s1 = row8_sum(((x[0] + x[1]) + (x[2] + x[3])) + ((y[0] + y[1]) + (y[2] + y[3])));
+                        const float s2 = row8_sum(((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3])) +
+                                                  ((y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3])));
+                        if ((lane & 7) == 0) { slab[r * ROWPF + 64] = s1; slab[r * ROWPF + 65] = s2; }
+                    }
                 } else {                                     // EPI_F32
-                    pk = __builtin_bit_cast(u32x4, lo + bias.lo);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo + bias.lo), ro, ooff, 0, 0);
                 }
-                // The row offset goes into the VGPR offset, NOT the SGPR soffset: with a register soffset hipcc pads no
-                // wait states after a >64-bit buffer store and lets the next VALU overwrite the data registers while the
-                // store is still reading them (measured on gfx950: dword 3 of ~3 % of such stores corrupted).
-                __builtin_amdgcn_raw_buffer_store_b128(pk, ro, voff + (i * sstep + it * rstep), 0, 0);
             }
             wave_lds_fence();                                // slab reads retired before the next slab overwrites it
+            if constexpr (STAT) {
+                if (lane < 32 && i * 32 + lane < rv)
+                    *(u32x2*)(stat_base + (i * 32 + lane) * 2) = *(const u32x2*)(slab + lane * ROWPF + 64);
+                wave_lds_fence();
+            }
+            if constexpr (LN) { if (i == 0) prefetch_next(); }
         }
     }
 }
@@ -346,7 +442,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     const int a_base = (wm * 128 + lrow) * ROWB;
     const int b_base = PP_W_OFF + (wn * 64 + lrow) * ROWB;
 
-    constexpr int ECPL = (EPI == EPI_QKV || EPI == EPI_GELU) ? 8 : 4;
+    constexpr int ECPL = epi_wide<EPI>() ? 8 : 4;
     const int ecc = (lane % (64 / ECPL)) * ECPL;             // the lane's first column inside the wave's 64 on the store side
     const int nt = g.K / BK;                                 // even (checked on the host)
     const int nblk = gridDim.x;
@@ -363,13 +459,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     TileCtx c = make_tile<ABL>(g, L);
     issue_dma<0, 8>(c, smem, wave, voffA, voffW, 0);         // K tile 0 of the first output tile -> stage 0
     EpiBias<EPI> bias;
+    const int err = lane / (64 / ECPL);                      // the lane's first row inside a 32-row slab on the store side
     load_bias<EPI>(bias, g, c.n0 + wn * 64 + ecc);
     pin_bias<EPI>(bias);
     // Number of global stores an epilogue issues AFTER its last load / DMA.  vmcnt retires in order, so at the top of
     // the next tile `vmcnt(NST)` means "the prefetched K tile 0 (and the next bias) has landed" while the epilogue's
     // stores are still draining to HBM underneath the first K tile.  (The patch epilogue skips stores of out-of-range
     // waves, so its count is not static: full drain.)
-    constexpr int NST = (EPI == EPI_QKV || EPI == EPI_GELU || EPI == EPI_RESID) ? 16 : (EPI == EPI_F32 ? 32 : 0);
+    // (EPI_RESID_STAT issues more; 16 is a safe lower bound.  The LN epilogues prefetch after slab 0: 12 stores follow.)
+    constexpr int NST = (EPI == EPI_PATCH) ? 0 : (EPI == EPI_F32 ? 32 : (epi_ln<EPI>() ? 12 : 16));
     bool first = true;
 
     while (true) {
@@ -389,6 +487,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         }
         wait_lgkm0();
         raw_barrier();                                       // B_0: K tile 0 visible, previous epilogue's slabs released
+        u32x2 rs[4][4];
+        if constexpr (epi_ln<EPI>()) load_rowstat<EPI>(rs, g, c.m0 + wm * 128, err);
         if constexpr (MODE == 0) {
             for (int t = 0; t < nt; t += 2) {
                 if (t > 0) { wait_vm0(); wait_lgkm0(); raw_barrier(); }
@@ -412,12 +512,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         L += nblk;
         const bool more = L < g.ntiles;
         EpiBias<EPI> bias_next = bias;
-        if (more) {
-            c = make_tile<ABL>(g, L);
-            issue_dma<0, 8>(c, smem, wave, voffA, voffW, 0);  // next output tile's K tile 0 -> stage 0 (free since K tile nt-2)
-            load_bias<EPI>(bias_next, g, c.n0 + wn * 64 + ecc);   // older than the epilogue's stores: see NST
-        }
-        pp_epilogue<T, EPI>(acc, g, smem, wave, lane, row0, col0, bias);
+        auto prefetch_next = [&]() {
+            if (more) {
+                c = make_tile<ABL>(g, L);
+                issue_dma<0, 8>(c, smem, wave, voffA, voffW, 0);  // next output tile's K tile 0 -> stage 0 (free since K tile nt-2)
+                load_bias<EPI>(bias_next, g, c.n0 + wn * 64 + ecc);   // older than the epilogue's last stores: see NST
+            }
+        };
+        pp_epilogue<T, EPI>(acc, g, smem, wave, lane, row0, col0, bias, rs, prefetch_next);
         if (!more) break;
         pin_bias<EPI>(bias_next);
         bias = bias_next;
@@ -452,6 +554,9 @@ int launch_pp_epi(const GemmArgs& g, int epi, int nblk, hipStream_t s) {
             case EPI_RESID: return launch_pp<T, EPI_RESID, MODE, D0, D1, D2, 0>(g, nblk, s);
             case EPI_PATCH: return launch_pp<T, EPI_PATCH, MODE, D0, D1, D2, 0>(g, nblk, s);
             case EPI_F32: return launch_pp<T, EPI_F32, MODE, D0, D1, D2, 0>(g, nblk, s);
+            case EPI_RESID_STAT: return launch_pp<T, EPI_RESID_STAT, MODE, D0, D1, D2, 0>(g, nblk, s);
+            case EPI_QKV_LN: return launch_pp<T, EPI_QKV_LN, MODE, D0, D1, D2, 0>(g, nblk, s);
+            case EPI_GELU_LN: return launch_pp<T, EPI_GELU_LN, MODE, D0, D1, D2, 0>(g, nblk, s);
             default: pg_set_error("gemm_pp: bad epilogue %d", epi); return PG_EINVAL;
         }
     }

@@ -4,7 +4,20 @@
 #include <stdint.h>
 #include "../../include/pigeon_hip.h"
 
-enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_F32 = 4 };
+// GEMM epilogues.  5..7 are the "LayerNorm folded into the GEMM" forms (gemm_pp.hip only, see vit.hip):
+//   EPI_RESID_STAT  fp32 residual add as EPI_RESID, plus the 16-bit copy of the new residual row (the next GEMM's A
+//                   operand) and per-(row, 64-column slice) partial sums / sums of squares for the row statistics;
+//   EPI_QKV_LN / EPI_GELU_LN  out = epi(rstd[m] * acc - (mean*rstd)[m] * colsum[n] + bias[n]) where the weight already
+//                   carries gamma and bias carries beta.W^T + b.
+enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_F32 = 4, EPI_RESID_STAT = 5, EPI_QKV_LN = 6, EPI_GELU_LN = 7 };
+
+struct PgGemmExtra {
+    const float* colsum = nullptr;     // [N]   EPI_*_LN: row sums of the (rounded) gamma-folded weight
+    const float* rowstat = nullptr;    // [M][2] EPI_*_LN: (rstd, mean*rstd) per A row
+    void* x16 = nullptr;               // [M][ldx] EPI_RESID_STAT: 16-bit copy of the updated residual rows
+    int64_t ldx = 0;
+    float* statpart = nullptr;         // [M][N/64][2] EPI_RESID_STAT: partial (sum, sum of squares) per 64-column slice
+};
 
 void pg_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 int pg_check_launch(const char* what);          // hipGetLastError -> PG_EHIP + message
@@ -22,7 +35,7 @@ int pg_default_gemm_variant();                   // env PIGEON_GEMM_VARIANT or t
 // gemm_bf16.hip
 int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldc,
                    int M, int N, int K, int epi, float qscale, int qcols, const float* aux, int variant,
-                   hipStream_t s);
+                   hipStream_t s, const PgGemmExtra* extra = nullptr);
 // rowops.hip
 int pg_layernorm_launch(const float* x, const float* gamma, const float* beta, void* y, int out_dtype,
                         int64_t rows, float eps, hipStream_t s);
@@ -31,5 +44,7 @@ int pg_preln_launch(float* x, const float* cls, const float* pos0, const float* 
 int pg_im2col_launch(const void* pixels, int pix_dtype, void* out, int out_dtype, int n_images, hipStream_t s);
 int pg_token_mean_launch(const float* x, float* out, int n_images, hipStream_t s);
 int pg_cast_f32_launch(const float* x, void* y, int out_dtype, int64_t n, hipStream_t s);
+int pg_rowstat_cast_launch(const float* x, void* x16, int out_dtype, float* rowstat, int64_t rows, float eps, hipStream_t s);
+int pg_rowstat_finalize_launch(const float* statpart, int slots, float* rowstat, int64_t rows, float eps, hipStream_t s);
 // attention.hip
 int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hipStream_t s);

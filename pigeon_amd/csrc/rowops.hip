@@ -113,6 +113,71 @@ int pg_preln_launch(float* x, const float* cls, const float* pos0, const float* 
     return pg_check_launch("pre_layernorm");
 }
 
+// ---- row statistics for the LayerNorm-folded GEMMs (vit.hip, gemm_pp.hip EPI_*_LN) -----------------------------------
+// rowstat_cast: x fp32 (rows,1024) -> 16-bit copy + (rstd, mean*rstd) per row, two-pass variance as layernorm_kernel.
+// Used once per forward (the input of layer 0's LN1); later rows get their statistics from the residual GEMM epilogues.
+template <typename T>
+__global__ __launch_bounds__(256) void rowstat_cast_kernel(const float* __restrict__ x, uint16_t* __restrict__ x16,
+                                                           float* __restrict__ rowstat, int64_t rows, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * VIT_HIDDEN;
+    f32x4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *(const f32x4*)(xr + i * 256 + lane * 4);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) * (1.0f / VIT_HIDDEN);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / VIT_HIDDEN) + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u32x2 pk;
+        pk[0] = pack16x2<T>(v[i][0], v[i][1]); pk[1] = pack16x2<T>(v[i][2], v[i][3]);
+        *(u32x2*)(x16 + row * VIT_HIDDEN + i * 256 + lane * 4) = pk;
+    }
+    if (lane == 0) { rowstat[2 * row] = rstd; rowstat[2 * row + 1] = mean * rstd; }
+}
+
+int pg_rowstat_cast_launch(const float* x, void* x16, int out_dtype, float* rowstat, int64_t rows, float eps, hipStream_t s) {
+    if (rows <= 0) return PG_OK;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (out_dtype == PG_DTYPE_F16) hipLaunchKernelGGL(rowstat_cast_kernel<T_F16>, grid, block, 0, s, x, (uint16_t*)x16, rowstat, rows, eps);
+    else if (out_dtype == PG_DTYPE_BF16) hipLaunchKernelGGL(rowstat_cast_kernel<T_BF16>, grid, block, 0, s, x, (uint16_t*)x16, rowstat, rows, eps);
+    else { pg_set_error("rowstat_cast: bad dtype %d", out_dtype); return PG_EINVAL; }
+    return pg_check_launch("rowstat_cast");
+}
+
+// rowstat_finalize: (sum, sum of squares) partials per 64-column slice, written slot-major [slot][row][2] by the
+// EPI_RESID_STAT epilogue, summed in slice order -> (rstd, mean*rstd).  One thread per row (coalesced 8-byte reads).
+__global__ __launch_bounds__(256) void rowstat_finalize_kernel(const float* __restrict__ part, int slots, float* __restrict__ rowstat,
+                                                               int64_t rows, float eps) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < slots; ++i) {
+        const f32x2 v = *(const f32x2*)(part + ((int64_t)i * rows + row) * 2);
+        s1 += v[0]; s2 += v[1];
+    }
+    const float mean = s1 * (1.0f / VIT_HIDDEN);
+    const float var = fmaxf(s2 * (1.0f / VIT_HIDDEN) - mean * mean, 0.f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    rowstat[2 * row] = rstd;
+    rowstat[2 * row + 1] = mean * rstd;
+}
+
+int pg_rowstat_finalize_launch(const float* statpart, int slots, float* rowstat, int64_t rows, float eps, hipStream_t s) {
+    if (rows <= 0) return PG_OK;
+    hipLaunchKernelGGL(rowstat_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, statpart, slots, rowstat, rows, eps);
+    return pg_check_launch("rowstat_finalize");
+}
+
 // ---- im2col of the 14x14 stride-14 patch stream -------------------------------------------------------
 // One block per (image, patch-row py).  The 42 source rows (3 channels x 14 ky) of that patch row are each
 // 336 contiguous pixels: reads are fully coalesced; every pixel lands at

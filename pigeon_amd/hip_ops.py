@@ -61,6 +61,44 @@ def gemm16(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: 
     return out
 
 
+def rowstat_cast(x: torch.Tensor, out_dtype: torch.dtype = torch.float16, eps: float = 1e-5):
+    """x fp32 (rows,1024) -> (16-bit copy, rowstat (rows,2) = (rstd, mean*rstd))."""
+    _dev(x, torch.float32)
+    rows = x.numel() // HIDDEN
+    x16 = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    rs = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    check(load().pg_op_rowstat_cast(_p(x), _p(x16), _dt16(x16), _p(rs), rows, float(eps), _stream()), "pg_op_rowstat_cast")
+    return x16, rs
+
+
+def gemm16_resid_stat(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, X: torch.Tensor, variant: int = 0):
+    """X += A.W^T + bias in place; returns (x16 copy of the new X, statpart (N/64, M, 2))."""
+    M, K = A.shape
+    N = W.shape[0]
+    x16 = torch.empty((M, N), dtype=A.dtype, device=A.device)
+    part = torch.empty((N // 64, M, 2), dtype=torch.float32, device=A.device)
+    check(load().pg_op_gemm16_resid_stat(_dt16(A), _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(X), X.stride(0), _p(x16),
+                                         x16.stride(0), _p(part), M, N, K, variant, _stream()), "pg_op_gemm16_resid_stat")
+    return x16, part
+
+
+def rowstat_finalize(part: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    slots, rows = part.shape[0], part.shape[1]
+    rs = torch.empty((rows, 2), dtype=torch.float32, device=part.device)
+    check(load().pg_op_rowstat_finalize(_p(part), slots, _p(rs), rows, float(eps), _stream()), "pg_op_rowstat_finalize")
+    return rs
+
+
+def gemm16_ln(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, colsum: torch.Tensor, rowstat: torch.Tensor, epi: int,
+              qscale: float = 1.0, qcols: int = 0, variant: int = 0) -> torch.Tensor:
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.empty((M, N), dtype=A.dtype, device=A.device)
+    check(load().pg_op_gemm16_ln(_dt16(A), _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(colsum), _p(rowstat), _p(out),
+                                 out.stride(0), M, N, K, epi, float(qscale), int(qcols), variant, _stream()), "pg_op_gemm16_ln")
+    return out
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
               out_dtype: torch.dtype = torch.float16, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _dev(x, torch.float32)

@@ -393,3 +393,76 @@ def test_full_size_step_properties(env, vit24, tmp_path):
     ref = env["orc"].super_guessr_forward(W, b, model.lla_geocells.data.cpu(), 5, embedding=out.embedding.cpu())
     assert torch.equal(out.preds_geocell.cpu(), ref["preds_geocell"])               # head argmax bit-exact on 128 rows
     assert torch.equal(out.top5_geocells.indices.cpu(), ref["topk"].indices)
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm fold
+def test_ln_fold_building_blocks(env):
+    """The pieces of the LayerNorm-folded GEMM chain, each against plain torch on the same rounded operands:
+    rowstat_cast, the residual GEMM that also emits the 16-bit row copy + partial statistics, rowstat_finalize, and the
+    GEMM whose epilogue applies rstd * acc - mean*rstd * colsum + c."""
+    ops, L = env["ops"], env["lib"]
+    g = torch.Generator().manual_seed(31)
+    M, D, K2, N2 = 700 + 13, 1024, 256, 512
+    x = (torch.randn((M, D), generator=g) * 1.7 + 0.4)
+    x[:, 5] += 30.0                                                 # an outlier channel
+    x16, rs = ops.rowstat_cast(x.to(DEV))
+    mu, var = x.mean(-1), x.var(-1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    assert torch.equal(x16.cpu(), x.to(torch.float16))
+    assert torch.allclose(rs[:, 0].cpu(), rstd, rtol=2e-6) and torch.allclose(rs[:, 1].cpu(), mu * rstd, rtol=2e-5, atol=1e-6)
+    # residual GEMM with statistics: X (M,1024) += A (M,K2) W^T
+    A = torch.randn((M, K2), generator=g).to(torch.float16)
+    W = (torch.randn((D, K2), generator=g) * 0.05).to(torch.float16)
+    b = torch.randn(D, generator=g)
+    X = x.clone().to(DEV)
+    xn16, part = ops.gemm16_resid_stat(A.to(DEV), W.to(DEV), b.to(DEV), X)
+    Xref = x.clone().to(DEV)
+    ops.gemm16(A.to(DEV), W.to(DEV), b.to(DEV), Xref, L.EPI_RESID, variant=8)
+    assert torch.equal(X, Xref)                                     # same bits as the plain residual epilogue
+    assert torch.equal(xn16.cpu(), X.cpu().to(torch.float16))
+    Xc = X.cpu()
+    ps = Xc.view(M, D // 64, 64)
+    assert torch.allclose(part[:, :, 0].cpu().T, ps.sum(-1), rtol=1e-5, atol=1e-4)         # slot-major (N/64, M, 2)
+    assert torch.allclose(part[:, :, 1].cpu().T, (ps * ps).sum(-1), rtol=1e-5, atol=1e-4)
+    rs2 = ops.rowstat_finalize(part)
+    mu2, var2 = Xc.mean(-1), Xc.var(-1, unbiased=False)
+    rstd2 = 1.0 / torch.sqrt(var2 + 1e-5)
+    assert torch.allclose(rs2[:, 0].cpu(), rstd2, rtol=2e-5) and torch.allclose(rs2[:, 1].cpu(), mu2 * rstd2, rtol=1e-4, atol=1e-5)
+    # LN-applied-in-the-epilogue GEMM against LayerNorm followed by a plain matmul on the same folded operands
+    gamma, beta = 1.0 + 0.1 * torch.randn(D, generator=g), 0.05 * torch.randn(D, generator=g)
+    Wl = torch.randn((N2, D), generator=g) * 0.03
+    bl = torch.randn(N2, generator=g) * 0.1
+    Wf = (Wl * gamma[None, :]).to(torch.float16)
+    colsum = Wf.float().sum(-1)
+    cb = (Wl.double() @ beta.double()).float() + bl
+    for epi in (L.EPI_QKV_LN, L.EPI_GELU_LN):
+        out = ops.gemm16_ln(xn16, Wf.to(DEV), cb.to(DEV), colsum.to(DEV), rs2, epi, qscale=0.25, qcols=256).float().cpu()
+        acc = xn16.cpu().float() @ Wf.float().T
+        y = rs2[:, :1].cpu() * acc - rs2[:, 1:].cpu() * colsum[None, :] + cb[None, :]
+        if epi == L.EPI_QKV_LN:
+            y[:, :256] *= 0.25
+        else:
+            y = y * torch.sigmoid(1.702 * y)
+        assert (out - y).abs().max() <= 2.0 ** -10 * y.abs().max() + 1e-3, epi
+        # and against the unfused definition LN(x) W^T + b (fp32): only the 16-bit rounding points differ
+        yref = torch.nn.functional.layer_norm(Xc, (D,), gamma, beta, 1e-5) @ Wl.T + bl
+        if epi == L.EPI_QKV_LN:
+            yref[:, :256] *= 0.25
+        else:
+            yref = yref * torch.sigmoid(1.702 * yref)
+        assert env["orc"].rel_err(out, yref) < 2e-3, epi
+
+
+def test_ln_fold_encoder_matches_reference(env, golden_dir, monkeypatch):
+    """The experimental LayerNorm-folded encoder (PIGEON_LN_FOLD=1) against the same golden vectors and tolerance as the
+    default path, and against the default path itself."""
+    from pigeon_amd.clip_embedder import HipCLIPVisionModel
+    sd = env["syn"].make_vit_weights(seed=11, layers=2, affine_jitter=True)
+    px = env["syn"].make_pixels(4, seed=77).to(DEV)
+    ref = torch.from_numpy(_gold(golden_dir, "vit2.npz")["embedding"])
+    base = HipCLIPVisionModel(sd, layers=2).to(DEV).embed(px).cpu()
+    monkeypatch.setenv("PIGEON_LN_FOLD", "1")
+    fold = HipCLIPVisionModel(sd, layers=2).to(DEV).embed(px).cpu()
+    assert env["orc"].rel_err(fold, ref) < EMB_TOL
+    assert env["orc"].rel_err(fold, base) < 5e-4
+    assert not torch.equal(fold, base)                    # it really took the other path
