@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--protos-per-cell", type=int, default=100)
     ap.add_argument("--topk", type=int, default=5)
     ap.add_argument("--layers", type=int, default=24)
-    ap.add_argument("--cpu-images", type=int, default=4, help="images in the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-images", type=int, default=16, help="images in the bounded CPU-baseline sample (0 = skip); 16 images = 4 panoramas ~ 13 s of oracle time on the 32 host cores")
     ap.add_argument("--no-refine", action="store_true")
     return ap.parse_args()
 

@@ -130,11 +130,38 @@ __device__ __forceinline__ void raw_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// EPI_RESID: addressing of the fp32 residual rows this lane adds into (store side: 16 lanes per row, 4 rows per
+// instruction, 8 instructions per 32-row slab).  The rows of slabs 0 and 1 are fetched during the SECOND-TO-LAST K tile of
+// the mainloop (their 64 registers are idle there), slabs 2 and 3 as soon as the epilogue has parked the accumulators of
+// slabs 0 / 1 in LDS: the epilogue used to pay one full memory latency per slab (~14 us per tile, rocprof ablations),
+// now roughly one per tile.
+struct XCtx {
+    __amdgpu_buffer_rsrc_t ro;
+    int voff, rstep, sstep;
+};
+__device__ __forceinline__ XCtx make_xctx(const GemmArgs& g, int row0, int col0, int lane) {
+    XCtx x;
+    int rv = g.M - row0; rv = rv < 0 ? 0 : (rv > 128 ? 128 : rv);
+    const uint32_t nbytes = rv > 0 ? (uint32_t)(((int64_t)(rv - 1) * g.ldc + 64) * 4) : 0u;
+    x.ro = make_rsrc((const char*)g.out + ((int64_t)row0 * g.ldc + col0) * 4, nbytes);
+    x.voff = ((lane >> 4) * (int)g.ldc + (lane & 15) * 4) * 4;
+    x.rstep = 4 * (int)g.ldc * 4;
+    x.sstep = 32 * (int)g.ldc * 4;
+    return x;
+}
+__device__ __forceinline__ void fetch_xrows(u32x4 (&dst)[8], const XCtx& x, int slab) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) dst[it] = __builtin_amdgcn_raw_buffer_load_b128(x.ro, x.voff, slab * x.sstep + it * x.rstep, 0);
+}
+
 // One K tile in ping-pong form.  D0..D2 = number of this wave's 8 DMAs issued in LOAD phases 0..2 (rest in phase 3).
-template <typename T, int D0, int D1, int D2, int ABL>
+// XF: this call may also issue the early residual fetch (phases 2 and 3, AFTER the tile's DMAs, so that the counted
+// vmcnt(16) at the end of phase 3 still means "my DMAs of the next K tile have landed").
+template <typename T, int D0, int D1, int D2, int ABL, bool XF = false>
 __device__ __forceinline__ void ktile_pp(f32x16 (&acc)[4][2], const char* cur, char* nxt, int a_base, int b_base,
                                          const int (&xoff)[4], const TileCtx& c, int wave, const int (&voffA)[4],
-                                         const int (&voffW)[4], int soff_next, bool has_next) {
+                                         const int (&voffW)[4], int soff_next, bool has_next, bool xf, const XCtx& xc,
+                                         u32x4 (&xq)[4][8]) {
     constexpr int D3 = 8 - D0 - D1 - D2;
     static_assert(D3 >= 0, "DMA schedule");
     Frag<T> f;
@@ -151,7 +178,14 @@ __device__ __forceinline__ void ktile_pp(f32x16 (&acc)[4][2], const char* cur, c
             if (kk == 2) issue_dma<D0 + D1, D2>(c, nxt, wave, voffA, voffW, soff_next);
             if (kk == 3) issue_dma<D0 + D1 + D2, D3>(c, nxt, wave, voffA, voffW, soff_next);
         }
-        if (kk == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (XF) {
+            if (xf && kk == 2) fetch_xrows(xq[0], xc, 0);
+            if (xf && kk == 3) fetch_xrows(xq[1], xc, 1);
+        }
+        if (kk == 3 && has_next) {
+            if (XF && xf) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         wait_lgkm0();
         raw_barrier();
         __builtin_amdgcn_s_setprio(1);
@@ -250,10 +284,10 @@ __device__ __forceinline__ float row8_sum(float v) {
     return v;
 }
 
-template <typename T, int EPI, typename PREFETCH>
+template <typename T, int EPI, bool XEARLY, typename PREFETCH>
 __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs& g, char* smem, int wave, int lane,
                                             int row0, int col0, const EpiBias<EPI>& bias, const u32x2 (&rs)[4][4],
-                                            PREFETCH&& prefetch_next) {
+                                            PREFETCH&& prefetch_next, const XCtx& xc, u32x4 (&xq)[4][8]) {
     constexpr bool OUT16 = epi_out16<EPI>();
     constexpr bool LN = epi_ln<EPI>();
     constexpr bool STAT = (EPI == EPI_RESID_STAT);
@@ -331,10 +365,10 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs&
                         xr[set][it][h] = __builtin_amdgcn_raw_buffer_load_b128(ro, voff + 16 * h, i * sstep + it * rstep, 0);
             }
         };
-        fetch_x(0, 0);
+        if constexpr (!XEARLY) fetch_x(0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (i + 1 < 4) fetch_x(i + 1, (i + 1) & 1);
+            if constexpr (!XEARLY) { if (i + 1 < 4) fetch_x(i + 1, (i + 1) & 1); }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -342,6 +376,8 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs&
                     f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
                     *(f32x4*)(slab + lrow * ROWPF + j * 32 + q * 8 + 4 * lhalf) = v;
                 }
+            // slabs 0 / 1 came in during the mainloop; with their accumulators parked, fetch the rows of slab i + 2
+            if constexpr (XEARLY) { if (i + 2 < 4) fetch_xrows(xq[i + 2], xc, i + 2); }
             wave_lds_fence();
 #pragma unroll
             for (int it = 0; it < ITS; ++it) {
@@ -383,7 +419,7 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs&
                     pk[2] = pack16x2<T>(hi[0], hi[1]); pk[3] = pack16x2<T>(hi[2], hi[3]);
                     __builtin_amdgcn_raw_buffer_store_b128(pk, ro, ooff, 0, 0);
                 } else if constexpr (RESID) {
-                    f32x4 x = __builtin_bit_cast(f32x4, xr[i & 1][it][0]);
+                    f32x4 x = __builtin_bit_cast(f32x4, XEARLY ? xq[i][it] : xr[i & 1][it][0]);
                     x += lo + bias.lo;                       // same expression as epi_store_f32x4<EPI_RESID>
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), ro, ooff, 0, 0);
                     if constexpr (STAT) {
@@ -489,6 +525,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         raw_barrier();                                       // B_0: K tile 0 visible, previous epilogue's slabs released
         u32x2 rs[4][4];
         if constexpr (epi_ln<EPI>()) load_rowstat<EPI>(rs, g, c.m0 + wm * 128, err);
+        constexpr bool XEARLY = (EPI == EPI_RESID) && (MODE != 0) && (ABL == 0);
+        XCtx xc;
+        u32x4 xq[4][8];
         if constexpr (MODE == 0) {
             for (int t = 0; t < nt; t += 2) {
                 if (t > 0) { wait_vm0(); wait_lgkm0(); raw_barrier(); }
@@ -500,10 +539,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         } else {
             if (follower) raw_barrier();
             for (int t = 0; t < nt; t += 2) {
-                ktile_pp<T, D0, D1, D2, ABL>(acc, smem, smem + PP_STAGE, a_base, b_base, xoff, c, wave, voffA, voffW,
-                                        (t + 1) * ROWB, true);
-                ktile_pp<T, D0, D1, D2, ABL>(acc, smem + PP_STAGE, smem, a_base, b_base, xoff, c, wave, voffA, voffW,
-                                        (t + 2) * ROWB, t + 2 < nt);
+                const bool xf = XEARLY && (t + 2 == nt);
+                if (XEARLY && xf) xc = make_xctx(g, c.m0 + wm * 128, c.n0 + wn * 64, lane);
+                ktile_pp<T, D0, D1, D2, ABL, XEARLY>(acc, smem, smem + PP_STAGE, a_base, b_base, xoff, c, wave, voffA, voffW,
+                                                (t + 1) * ROWB, true, xf, xc, xq);
+                ktile_pp<T, D0, D1, D2, ABL, false>(acc, smem + PP_STAGE, smem, a_base, b_base, xoff, c, wave, voffA, voffW,
+                                                (t + 2) * ROWB, t + 2 < nt, false, xc, xq);
             }
             if (MODE == 1 && !follower) raw_barrier();       // re-align: every wave has left the mainloop
         }
@@ -512,14 +553,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         L += nblk;
         const bool more = L < g.ntiles;
         EpiBias<EPI> bias_next = bias;
+        // UNCONDITIONAL on purpose (the last tile of a block re-fetches its own first K tile into the idle stage 0, 64 KB of
+        // wasted DMA per block): a VMEM block under `if (more)` between the early residual loads and their use makes hipcc
+        // count its in-order vmcnt waits along the path WITHOUT the block, i.e. on the common path it waits for ten extra
+        // (younger) operations -- a full memory latency at the start of every epilogue.
         auto prefetch_next = [&]() {
-            if (more) {
-                c = make_tile<ABL>(g, L);
-                issue_dma<0, 8>(c, smem, wave, voffA, voffW, 0);  // next output tile's K tile 0 -> stage 0 (free since K tile nt-2)
-                load_bias<EPI>(bias_next, g, c.n0 + wn * 64 + ecc);   // older than the epilogue's last stores: see NST
-            }
+            c = make_tile<ABL>(g, more ? L : L - nblk);
+            issue_dma<0, 8>(c, smem, wave, voffA, voffW, 0);      // next output tile's K tile 0 -> stage 0 (free since K tile nt-2)
+            load_bias<EPI>(bias_next, g, c.n0 + wn * 64 + ecc);   // older than the epilogue's last stores: see NST
         };
-        pp_epilogue<T, EPI>(acc, g, smem, wave, lane, row0, col0, bias, rs, prefetch_next);
+        pp_epilogue<T, EPI, XEARLY>(acc, g, smem, wave, lane, row0, col0, bias, rs, prefetch_next, xc, xq);
         if (!more) break;
         pin_bias<EPI>(bias_next);
         bias = bias_next;
@@ -554,9 +597,16 @@ int launch_pp_epi(const GemmArgs& g, int epi, int nblk, hipStream_t s) {
             case EPI_RESID: return launch_pp<T, EPI_RESID, MODE, D0, D1, D2, 0>(g, nblk, s);
             case EPI_PATCH: return launch_pp<T, EPI_PATCH, MODE, D0, D1, D2, 0>(g, nblk, s);
             case EPI_F32: return launch_pp<T, EPI_F32, MODE, D0, D1, D2, 0>(g, nblk, s);
-            case EPI_RESID_STAT: return launch_pp<T, EPI_RESID_STAT, MODE, D0, D1, D2, 0>(g, nblk, s);
-            case EPI_QKV_LN: return launch_pp<T, EPI_QKV_LN, MODE, D0, D1, D2, 0>(g, nblk, s);
-            case EPI_GELU_LN: return launch_pp<T, EPI_GELU_LN, MODE, D0, D1, D2, 0>(g, nblk, s);
+            case EPI_RESID_STAT: case EPI_QKV_LN: case EPI_GELU_LN:
+                // the LayerNorm-fold epilogues are built only for the production schedule (ping-pong, DMA 4/4/0/0)
+                if constexpr (MODE == 1 && D0 == 4 && D1 == 4 && D2 == 0) {
+                    if (epi == EPI_RESID_STAT) return launch_pp<T, EPI_RESID_STAT, MODE, D0, D1, D2, 0>(g, nblk, s);
+                    if (epi == EPI_QKV_LN) return launch_pp<T, EPI_QKV_LN, MODE, D0, D1, D2, 0>(g, nblk, s);
+                    return launch_pp<T, EPI_GELU_LN, MODE, D0, D1, D2, 0>(g, nblk, s);
+                } else {
+                    pg_set_error("gemm_pp: epilogue %d exists only in variants 33 / 36 / 38 / 39", epi);
+                    return PG_EINVAL;
+                }
             default: pg_set_error("gemm_pp: bad epilogue %d", epi); return PG_EINVAL;
         }
     }
