@@ -40,8 +40,8 @@ int pg_default_gemm_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("PIGEON_GEMM_VARIANT");
-        v = e ? atoi(e) : 33;                                // persistent ping-pong kernel (gemm_pp.hip)
-        if (v <= 0) v = 33;
+        v = e ? atoi(e) : 36;                                // persistent ping-pong kernel, 8x4 super-tile raster (gemm_pp.hip)
+        if (v <= 0) v = 36;
     }
     return v;
 }
@@ -476,7 +476,7 @@ extern "C" int pg_op_gemm16_resid_stat(int dtype, const void* A, int64_t lda, co
                                        void* stream) {
     if (!A || !W || !X || !x16 || !statpart) { pg_set_error("op_gemm16_resid_stat: null argument"); return PG_EINVAL; }
     PgGemmExtra ex; ex.x16 = x16; ex.ldx = ldx; ex.statpart = statpart;
-    return pg_gemm_launch(dtype, A, lda, W, ldw, bias, X, ldc, M, N, K, EPI_RESID_STAT, 1.f, 0, nullptr, variant ? variant : 33,
+    return pg_gemm_launch(dtype, A, lda, W, ldw, bias, X, ldc, M, N, K, EPI_RESID_STAT, 1.f, 0, nullptr, variant ? variant : 36,
                           (hipStream_t)stream, &ex);
 }
 extern "C" int pg_op_gemm16_ln(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
@@ -485,7 +485,7 @@ extern "C" int pg_op_gemm16_ln(int dtype, const void* A, int64_t lda, const void
     if (!A || !W || !out || !colsum || !rowstat) { pg_set_error("op_gemm16_ln: null argument"); return PG_EINVAL; }
     if (epi != EPI_QKV_LN && epi != EPI_GELU_LN) { pg_set_error("op_gemm16_ln: epi must be 6 or 7"); return PG_EINVAL; }
     PgGemmExtra ex; ex.colsum = colsum; ex.rowstat = rowstat;
-    return pg_gemm_launch(dtype, A, lda, W, ldw, bias, out, ldc, M, N, K, epi, qscale, qcols, nullptr, variant ? variant : 33,
+    return pg_gemm_launch(dtype, A, lda, W, ldw, bias, out, ldc, M, N, K, epi, qscale, qcols, nullptr, variant ? variant : 36,
                           (hipStream_t)stream, &ex);
 }
 extern "C" int pg_op_layernorm(const float* x, const float* gamma, const float* beta, void* y, int out_dtype,
