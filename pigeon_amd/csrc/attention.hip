@@ -614,7 +614,39 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const uint16_t* __re
 // of v2/v3 (att3_softmax): the small per-wave state (O 32 + S 32 + Q 16 registers) is what lets 3-4 waves share a SIMD, and
 // with that many independent waves the hardware overlaps one wave's MFMAs with another's softmax by itself.
 // ================================================================================================================
-template <typename T, int WAVES_PER_SIMD, int ABL = 0>   // ABL (timing only, wrong results): 1 no K/V staging in the loop, 2 no softmax
+// K tile straight into LDS (buffer_load_dwordx4 ... lds, as the GEMM stages its operands): no VGPR round trip, no
+// ds_write, the bank swizzle applied to the source address.  A wave issues 2 of the tile's 8 DMAs (8 keys x 128 B each).
+typedef __attribute__((address_space(3))) void att_lds_void;
+__device__ __forceinline__ void att_dma_k(__amdgpu_buffer_rsrc_t rk, char* ks, int wave, int lane, int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int grp = wave + 4 * i;                      // 8-key group inside the 64-key tile
+        const int row = grp * 8 + (lane >> 3);
+        int key = t * ATT_KT + row; key = key < VIT_TOKENS ? key : VIT_TOKENS - 1;
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (att_lds_void*)(ks + grp * 8 * K_ROWB), 16, key * (QKV_LD * 2) + c * 16, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void att_load_v(StageRegs& st, const uint16_t* __restrict__ qkv, int64_t base, int head, int t, int tid) {
+    const int j = tid & 31, c = tid >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int key = t * ATT_KT + 2 * j + i; key = key < VIT_TOKENS ? key : VIT_TOKENS - 1;
+        st.v[i] = *(const u32x4*)(qkv + (base + key) * QKV_LD + 2048 + head * 64 + c * 8);
+    }
+}
+__device__ __forceinline__ void att_store_v(const StageRegs& st, char* vt, int tid) {
+    const int j = tid & 31, c = tid >> 5;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t w0 = st.v[0][e >> 1], w1 = st.v[1][e >> 1];
+        const uint32_t lo = (e & 1) ? (w0 >> 16) : (w0 & 0xffffu);
+        const uint32_t hi = (e & 1) ? (w1 >> 16) : (w1 & 0xffffu);
+        *(uint32_t*)(vt + (c * 8 + e) * VT_STRIDE + j * 4) = lo | (hi << 16);
+    }
+}
+
+template <typename T, int WAVES_PER_SIMD, int ABL = 0, bool KDMA = false>   // ABL (timing only, wrong results): 1 no K/V staging in the loop, 2 no softmax
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention4_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) char smem[2 * K_TILE_BYTES + 2 * VT_TILE_BYTES];
     char* ks0 = smem;
@@ -648,12 +680,26 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention4_kernel(const u
     for (int ksi = 0; ksi < 4; ++ksi) kxoff[ksi] = ((ksi * 2 + g) ^ ((lq >> 1) & 7)) << 4;
 
     StageRegs st;
-    att_load_tile(st, qkv, base, head, 0, tid);
-    att_store_tile(st, ks0, vt0, tid);
+    __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(qkv + base * QKV_LD + 1024 + head * 64), (short)0, (int)(VIT_TOKENS * QKV_LD * 2), 0x00020000);
+    if (KDMA) {
+        att_dma_k(rk, ks0, wave, lane, 0);
+        att_load_v(st, qkv, base, head, 0, tid);
+        att_store_v(st, vt0, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        att_load_tile(st, qkv, base, head, 0, tid);
+        att_store_tile(st, ks0, vt0, tid);
+    }
     __syncthreads();
     for (int t = 0; t < ATT_NT; ++t) {
         const int cur = t & 1;
-        if (t + 1 < ATT_NT && !(ABL & 1)) att_load_tile(st, qkv, base, head, t + 1, tid);
+        if (t + 1 < ATT_NT && !(ABL & 1)) {
+            if (KDMA) {
+                att_dma_k(rk, ks0 + (cur ^ 1) * K_TILE_BYTES, wave, lane, t + 1);     // lands under this tile's math
+                att_load_v(st, qkv, base, head, t + 1, tid);
+            } else att_load_tile(st, qkv, base, head, t + 1, tid);
+        }
         const char* ks = ks0 + cur * K_TILE_BYTES;
         const char* vt = vt0 + cur * VT_TILE_BYTES;
         if (wave_active) {
@@ -674,7 +720,12 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention4_kernel(const u
             else att3_softmax<T, true>(sA, o, m, l, pfA, t, g);
             att3_pv<T>(o, pfA, vt, lq, g);
         }
-        if (t + 1 < ATT_NT && !(ABL & 1)) att_store_tile(st, ks0 + (cur ^ 1) * K_TILE_BYTES, vt0 + (cur ^ 1) * VT_TILE_BYTES, tid);
+        if (t + 1 < ATT_NT && !(ABL & 1)) {
+            if (KDMA) {
+                att_store_v(st, vt0 + (cur ^ 1) * VT_TILE_BYTES, tid);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // this wave's K DMAs have landed
+            } else att_store_tile(st, ks0 + (cur ^ 1) * K_TILE_BYTES, vt0 + (cur ^ 1) * VT_TILE_BYTES, tid);
+        }
         if (!(ABL & 4)) __syncthreads();
     }
     if (wave_active) {
@@ -699,8 +750,8 @@ static int attention_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("PIGEON_ATTN_VARIANT");
-        v = e ? atoi(e) : 4;
-        if (v < 1 || v > 9) v = 4;
+        v = e ? atoi(e) : 10;
+        if (v < 1 || v > 10) v = 10;
     }
     return v;
 }
@@ -711,6 +762,11 @@ int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hip
     const int var = attention_variant();
     const bool v2 = var == 2;
     const dim3 grid(pairs * ((var == 2 || var == 3) ? ATT2_NQB : ATT_NQB)), block(256);
+    if (var == 10 && (dtype == PG_DTYPE_F16 || dtype == PG_DTYPE_BF16)) {     // variant 4 with the K tile by direct-to-LDS DMA
+        if (dtype == PG_DTYPE_F16) hipLaunchKernelGGL((attention4_kernel<T_F16, 3, 0, true>), grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+        else hipLaunchKernelGGL((attention4_kernel<T_BF16, 3, 0, true>), grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+        return pg_check_launch("attention");
+    }
     if (var >= 6 && var <= 9 && dtype == PG_DTYPE_F16) {         // ablations of variant 4 (timing only)
         if (var == 6) hipLaunchKernelGGL((attention4_kernel<T_F16, 3, 1>), grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
         if (var == 7) hipLaunchKernelGGL((attention4_kernel<T_F16, 3, 2>), grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
