@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void attention2_kernel(const uint16_t* __re
 // clustering.  K / V^T fragments are re-read per query block (the LDS was never the limit).  The O rescale is
 // unconditional (16 packed multiplies) to keep the tile body one basic block.
 // ================================================================================================================
-template <typename T, bool LAST>
+template <typename T, bool LAST, bool COND_RESCALE = false>
 __device__ __forceinline__ void att3_softmax(f32x16 (&s)[2], f32x16 (&o)[2], float& m, float& l, typename T::v8 (&pf)[2][2],
                                              int t, int g) {
     if (LAST) {
@@ -422,6 +422,8 @@ __device__ __forceinline__ void att3_softmax(f32x16 (&s)[2], f32x16 (&o)[2], flo
     tmax = max3f(tmax, s[1][15], s[1][15]);
     const float m_new = max3f(tmax, __shfl_xor(tmax, 32, 64), m);
     const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    // wave-uniform: did any row maximum of this wave move?  (alpha == 1.0 exactly for the rows that did not)
+    const bool moved = !COND_RESCALE || __builtin_amdgcn_ballot_w64(m_new > m) != 0;
     m = m_new;
     const f32x2 m2 = {m_new, m_new};
     f32x2 ps2 = {0.f, 0.f};
@@ -441,10 +443,12 @@ __device__ __forceinline__ void att3_softmax(f32x16 (&s)[2], f32x16 (&o)[2], flo
             pf[kb][s2] = __builtin_bit_cast(typename T::v8, pw);
         }
     l = l * alpha + (ps2[0] + ps2[1]);
+    if (moved) {                                             // multiplying by exactly 1.0 otherwise: skipping is bit-identical
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
 }
 
 template <typename T>
@@ -746,12 +750,160 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention4_kernel(const u
     }
 }
 
+// ================================================================================================================
+// v5 (variant 11): both K and V tiles arrive by direct-to-LDS DMA, V stays ROW-major in LDS and the PV operand is read with
+// the transposing LDS load.  Staging V through registers (2 global loads, 16 VALU unpacks, 8 ds_write_b32 per thread and
+// tile, to build V^T) was the largest removable part of v4 (ablation: 0.37 of 1.35 ms).
+//
+// ds_read_b64_tr_b16 (measured with tools/tr_probe.hip): inside a 16-lane group, input lane j = 4k + r supplies 4 contiguous
+// 16-bit values In[j][0..3]; output lane i receives In[4k + i/4][i%4] for k = 0..3.  Pointing lane j at
+// V[key0 + j/4][d0 + 4 (j%4) ..+3] therefore hands lane i the four keys key0..key0+3 of column d0 + i -- the k-contiguous
+// A fragment of O^T += V^T P^T -- from a row-major image.  The PV contraction order of a 16-key step is keys
+// {4g..4g+3, 8+4g..8+4g+3} (what the lane's P registers hold), i.e. two such reads per MFMA, as many as v4 issued.
+// Bank conflicts: one ds_read_b64 pass covers 32 lanes = 4 key rows x 64 B; rows are 128 B apart, so rows r and r+2 would
+// share banks; 64-byte halves of a row are swapped when bit 1 of the key index is set (applied on the DMA source).
+// ================================================================================================================
+typedef __attribute__((ext_vector_type(4))) short att_s16x4;
+
+__device__ __forceinline__ void att_dma_v(__amdgpu_buffer_rsrc_t rv, char* vs, int wave, int lane, int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int grp = wave + 4 * i;
+        const int row = grp * 8 + (lane >> 3);
+        int key = t * ATT_KT + row; key = key < VIT_TOKENS ? key : VIT_TOKENS - 1;
+        const int c = (lane & 7) ^ (((row >> 1) & 1) << 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (att_lds_void*)(vs + grp * 8 * K_ROWB), 16, key * (QKV_LD * 2) + c * 16, 0, 0, 0);
+    }
+}
+
+// v5 staging: the lane's byte offset inside a 64-key tile is loop-invariant (dvo[i], i = the wave's two 8-key groups), the
+// tile advance is an SGPR offset, and keys past token 576 need no clamp: the descriptor ends at the image's last row, the
+// DMA writes zeros there (their scores are masked to -1e30 before the softmax anyway).
+__device__ __forceinline__ void att5_dma(__amdgpu_buffer_rsrc_t r, char* dst, int wave, const int (&dvo)[2], int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (att_lds_void*)(dst + (wave + 4 * i) * 8 * K_ROWB), 16, dvo[i],
+                                                 t * (ATT_KT * QKV_LD * 2), 0, 0);
+}
+
+// All 16 transposing reads of a tile are two per-lane base addresses plus compile-time offsets: the 64-byte swizzle bit of
+// a key row ((key >> 1) & 1) depends only on the lane (bit 3 of its index in the 16-lane group), so it just selects which
+// of the two 32-column blocks (db) sits in which 64-byte half.
+template <typename T>
+__device__ __forceinline__ void att5_pv(f32x16 (&o)[2], const typename T::v8 (&pf)[2][2], const char* vs, const int (&vbase)[2]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const char* p = vs + vbase[db] + (kb * 32 + 16 * s2) * K_ROWB;
+                const att_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) att_s16x4*)(p));
+                const att_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) att_s16x4*)(p + 8 * K_ROWB));
+                const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                u32x4 vw; vw[0] = l2[0]; vw[1] = l2[1]; vw[2] = h2[0]; vw[3] = h2[1];
+                o[db] = T::mfma(__builtin_bit_cast(typename T::v8, vw), pf[kb][s2], o[db]);
+            }
+}
+
+template <typename T, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention5_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * K_TILE_BYTES];              // K0 K1 V0 V1, 8 KB each
+    char* ks0 = smem;
+    char* vs0 = smem + 2 * K_TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, g = lane >> 5;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int qb = slot % ATT_NQB;
+    const int pair = (slot / ATT_NQB) * 8 + xcd;
+    const int img = pair >> 4, head = pair & 15;
+    const int64_t base = (int64_t)img * VIT_TOKENS;
+    const int q_first = qb * ATT_QB + wave * 32;            // wave-uniform
+    const bool wave_active = q_first < VIT_TOKENS;
+    const int qrow = q_first + lq;
+    const int qr = qrow < VIT_TOKENS ? qrow : VIT_TOKENS - 1;
+
+    typename T::v8 qf[4];
+#pragma unroll
+    for (int ksi = 0; ksi < 4; ++ksi)
+        qf[ksi] = *(const typename T::v8*)(qkv + (base + qr) * QKV_LD + head * 64 + ksi * 16 + g * 8);
+    f32x16 o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m = -1e30f, l = 0.f;
+    int kxoff[4];
+#pragma unroll
+    for (int ksi = 0; ksi < 4; ++ksi) kxoff[ksi] = ((ksi * 2 + g) ^ ((lq >> 1) & 7)) << 4;
+
+    __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(qkv + base * QKV_LD + 1024 + head * 64), (short)0, (int)(VIT_TOKENS * QKV_LD * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(qkv + base * QKV_LD + 2048 + head * 64), (short)0, (int)(VIT_TOKENS * QKV_LD * 2), 0x00020000);
+    int dvo_k[2], dvo_v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave + 4 * i) * 8 + (lane >> 3);
+        dvo_k[i] = row * (QKV_LD * 2) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        dvo_v[i] = row * (QKV_LD * 2) + (((lane & 7) ^ (((row >> 1) & 1) << 2)) << 4);
+    }
+    int vbase[2];
+    {
+        const int j = lane & 15, dh = (lane >> 4) & 1, sw = (j >> 3) & 1;
+        const int lane_off = (4 * g + (j >> 2)) * K_ROWB + (dh * 16 + 4 * (j & 3)) * 2;
+        vbase[0] = lane_off + (sw ? 64 : 0);
+        vbase[1] = lane_off + (sw ? 0 : 64);
+    }
+    att5_dma(rk, ks0, wave, dvo_k, 0);
+    att5_dma(rv, vs0, wave, dvo_v, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < ATT_NT; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ATT_NT) {                                 // both tiles of step t+1 land under this tile's math
+            att5_dma(rk, ks0 + (cur ^ 1) * K_TILE_BYTES, wave, dvo_k, t + 1);
+            att5_dma(rv, vs0 + (cur ^ 1) * K_TILE_BYTES, wave, dvo_v, t + 1);
+        }
+        const char* ks = ks0 + cur * K_TILE_BYTES;
+        const char* vs = vs0 + cur * K_TILE_BYTES;
+        if (wave_active) {
+            f32x16 sA[2];
+            typename T::v8 pfA[2][2];
+            att3_qk<T>(sA, qf, ks, kxoff, lq);
+            if (t < ATT_NT - 1) att3_softmax<T, false, true>(sA, o, m, l, pfA, t, g);
+            else att3_softmax<T, true, true>(sA, o, m, l, pfA, t, g);
+            att5_pv<T>(o, pfA, vs, vbase);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMAs of step t+1 have landed
+        __syncthreads();
+    }
+    if (wave_active) {
+        const float ltot = l + __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / ltot;
+        if (qrow < VIT_TOKENS) {
+            uint16_t* orow = out + (base + qrow) * VIT_HIDDEN + head * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    u32x2 pk;
+                    pk[0] = pack16x2<T>(o[db][4 * q4] * inv, o[db][4 * q4 + 1] * inv);
+                    pk[1] = pack16x2<T>(o[db][4 * q4 + 2] * inv, o[db][4 * q4 + 3] * inv);
+                    *(u32x2*)(orow + db * 32 + 8 * q4 + 4 * g) = pk;
+                }
+        }
+    }
+}
+
 static int attention_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("PIGEON_ATTN_VARIANT");
-        v = e ? atoi(e) : 10;
-        if (v < 1 || v > 10) v = 10;
+        v = e ? atoi(e) : 11;
+        if (v < 1 || v > 12) v = 11;
     }
     return v;
 }
@@ -762,6 +914,16 @@ int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hip
     const int var = attention_variant();
     const bool v2 = var == 2;
     const dim3 grid(pairs * ((var == 2 || var == 3) ? ATT2_NQB : ATT_NQB)), block(256);
+    if ((var == 11 || var == 12) && (dtype == PG_DTYPE_F16 || dtype == PG_DTYPE_BF16)) {   // K and V by DMA, transposing LDS reads
+        if (var == 11) {
+            if (dtype == PG_DTYPE_F16) hipLaunchKernelGGL((attention5_kernel<T_F16, 3>), grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+            else hipLaunchKernelGGL((attention5_kernel<T_BF16, 3>), grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+        } else {
+            if (dtype == PG_DTYPE_F16) hipLaunchKernelGGL((attention5_kernel<T_F16, 4>), grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+            else hipLaunchKernelGGL((attention5_kernel<T_BF16, 4>), grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+        }
+        return pg_check_launch("attention");
+    }
     if (var == 10 && (dtype == PG_DTYPE_F16 || dtype == PG_DTYPE_BF16)) {     // variant 4 with the K tile by direct-to-LDS DMA
         if (dtype == PG_DTYPE_F16) hipLaunchKernelGGL((attention4_kernel<T_F16, 3, 0, true>), grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
         else hipLaunchKernelGGL((attention4_kernel<T_BF16, 3, 0, true>), grid, block, 0, s, (const uint16_t*)qkv, (uint16_t*)out);
