@@ -873,8 +873,8 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention5_kernel(const u
             f32x16 sA[2];
             typename T::v8 pfA[2][2];
             att3_qk<T>(sA, qf, ks, kxoff, lq);
-            if (t < ATT_NT - 1) att3_softmax<T, false, true>(sA, o, m, l, pfA, t, g);
-            else att3_softmax<T, true, true>(sA, o, m, l, pfA, t, g);
+            if (t < ATT_NT - 1) att3_softmax<T, false>(sA, o, m, l, pfA, t, g);   // (conditional O rescale: no gain measured)
+            else att3_softmax<T, true>(sA, o, m, l, pfA, t, g);
             att5_pv<T>(o, pfA, vs, vbase);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMAs of step t+1 have landed
