@@ -624,6 +624,7 @@ int dispatch_pp(GemmArgs& g, int epi, int variant, int nblk, hipStream_t s) {
         case 37: if (g.tilesN % 4 == 0) g.gn = 4; return launch_pp_epi<T, 1, 3, 3, 2>(g, epi, nblk, s);   // 31 + 8x4 super-tile raster
         case 38: g.stagger = (g.K / BK) * 2600 + 6000; return launch_pp_epi<T, 1, 4, 4, 0>(g, epi, nblk, s);   // 33 + staggered start
         case 39: g.stagger = (g.K / BK) * 1300 + 3000; return launch_pp_epi<T, 1, 4, 4, 0>(g, epi, nblk, s);   // 33 + half-period stagger
+        // (DMA schedules 8/0/0/0, 6/2/0/0, 5/3/0/0, 4/2/2/0 measured within +-3 % of 4/4/0/0 -- box-to-box noise -- and removed)
         // ablations of 33 (timing only, wrong results)
         case 40: return launch_pp_epi<T, 1, 4, 4, 0, 1>(g, epi, nblk, s);          // no DMA in the K loop
         case 41: return launch_pp_epi<T, 1, 4, 4, 0, 2>(g, epi, nblk, s);          // every DMA hits panel 0 (L2 resident)
