@@ -58,6 +58,10 @@ struct T_BF16 {
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
+    // c + a.lo*b.lo + a.hi*b.hi on packed 16-bit pairs (v_dot2c_f32_bf16)
+    static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+    }
     // two finite floats -> one dword, round to nearest even (v_cvt_pk_bf16_f32); no NaN fix-up: for softmax weights
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
         const f32x2 v = {lo, hi};
@@ -71,6 +75,9 @@ struct T_F16 {
     static __device__ __forceinline__ float val(uint16_t b) { return f16_bits_to_f32(b); }
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), c, false);
     }
     // two floats in [0, 65504] -> one dword, round to nearest even (v_cvt_pk_f16_f32); no saturation: for softmax weights
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
