@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpigeon_hip.so")
+# PIGEON_HIP_LIB lets a developer A/B two builds of the library in one process launch (tools/); default = in-tree build
+LIB_PATH = os.environ.get("PIGEON_HIP_LIB") or os.path.join(_HERE, "libpigeon_hip.so")
 
 PG_DTYPE_F32, PG_DTYPE_BF16, PG_DTYPE_F16, PG_DTYPE_F64 = 0, 1, 2, 3
 EPI_QKV, EPI_GELU, EPI_RESID, EPI_PATCH, EPI_F32, EPI_RESID_STAT, EPI_QKV_LN, EPI_GELU_LN = 0, 1, 2, 3, 4, 5, 6, 7

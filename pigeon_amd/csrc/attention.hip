@@ -272,16 +272,25 @@ __device__ __forceinline__ void att3_softmax(f32x16 (&s)[2], f32x16 (&o)[2], flo
     }
 }
 
+// S^T = K Q^T for one 32-query block.  All eight K fragments are fetched first (32 VGPRs) and the two 32-key accumulator
+// chains are INTERLEAVED: as the compiler scheduled the naive loop it issued {ds_read, s_waitcnt, mfma} eight times with
+// four dependent MFMAs in a row per chain -- every MFMA paid an LDS latency plus the 64-cycle dependent-accumulator
+// latency instead of the 32-cycle issue rate.
 template <typename T>
 __device__ __forceinline__ void att3_qk(f32x16 (&s)[2], const typename T::v8 (&qf)[4], const char* ks, const int (&kxoff)[4], int lq) {
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    typename T::v8 kf[4][2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int ksi = 0; ksi < 4; ++ksi)
 #pragma unroll
-        for (int ksi = 0; ksi < 4; ++ksi) {
-            const typename T::v8 kf = *(const typename T::v8*)(ks + (kb * 32 + lq) * K_ROWB + kxoff[ksi]);
-            s[kb] = T::mfma(kf, qf[ksi], ksi == 0 ? zero16 : s[kb]);
-        }
+        for (int kb = 0; kb < 2; ++kb)
+            kf[ksi][kb] = *(const typename T::v8*)(ks + (kb * 32 + lq) * K_ROWB + kxoff[ksi]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ksi = 0; ksi < 4; ++ksi)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+            s[kb] = T::mfma(kf[ksi][kb], qf[ksi], ksi == 0 ? zero16 : s[kb]);
 }
 
 template <typename T>
@@ -465,24 +474,146 @@ __device__ __forceinline__ void att5_dma(__amdgpu_buffer_rsrc_t r, char* dst, in
 // All 16 transposing reads of a tile are two per-lane base addresses plus compile-time offsets: the 64-byte swizzle bit of
 // a key row ((key >> 1) & 1) depends only on the lane (bit 3 of its index in the 16-lane group), so it just selects which
 // of the two 32-column blocks (db) sits in which 64-byte half.
+// The 16 transposing V reads of a tile are issued as inline asm, right after the QK^T MFMAs and before the softmax, and
+// waited for (att5_wait_v) just before the PV MFMAs.  Written with the ds_read_tr builtin, hipcc puts an `s_waitcnt
+// vmcnt(0)` in front of the first read: it assumes the read may alias the direct-to-LDS DMA of the NEXT tile issued at the
+// top of the loop (other stage, never the same bytes), which parks the wave until that DMA has landed.
+template <int OFF>
+__device__ __forceinline__ u32x2 att_tr_read(uint32_t addr) {
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
 template <typename T>
-__device__ __forceinline__ void att5_pv(f32x16 (&o)[2], const typename T::v8 (&pf)[2][2], const char* vs, const int (&vbase)[2]) {
+__device__ __forceinline__ void att5_load_v(u32x4 (&vf)[2][2][2], const char* vs, const int (&vbase)[2]) {
+    const uint32_t vs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)vs;
+    const uint32_t a0 = vs_lds + vbase[0], a1 = vs_lds + vbase[1];
+    __builtin_amdgcn_sched_barrier(0);                       // after the last QK^T MFMA: its lgkmcnt waits must not see these
+#if ATT_EXP == 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#elif ATT_EXP == 2
+    asm volatile("s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7" ::: "memory");
+#elif ATT_EXP == 3
+    asm volatile("s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7" ::: "memory");
+#endif
+#define ATT_TR2(kb, s2)                                                                                       \
+    {                                                                                                         \
+        const u32x2 l0 = att_tr_read<((kb) * 32 + 16 * (s2)) * K_ROWB>(a0);                                   \
+        const u32x2 h0 = att_tr_read<((kb) * 32 + 16 * (s2) + 8) * K_ROWB>(a0);                               \
+        const u32x2 l1 = att_tr_read<((kb) * 32 + 16 * (s2)) * K_ROWB>(a1);                                   \
+        const u32x2 h1 = att_tr_read<((kb) * 32 + 16 * (s2) + 8) * K_ROWB>(a1);                               \
+        vf[kb][s2][0] = u32x4{l0[0], l0[1], h0[0], h0[1]};                                                    \
+        vf[kb][s2][1] = u32x4{l1[0], l1[1], h1[0], h1[1]};                                                    \
+    }
+    ATT_TR2(0, 0) ATT_TR2(0, 1) ATT_TR2(1, 0) ATT_TR2(1, 1)
+#undef ATT_TR2
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void att5_wait_v(u32x4 (&vf)[2][2][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(vf[0][0][0]), "+v"(vf[0][0][1]), "+v"(vf[0][1][0]), "+v"(vf[0][1][1]),
+                   "+v"(vf[1][0][0]), "+v"(vf[1][0][1]), "+v"(vf[1][1][0]), "+v"(vf[1][1][1])
+                 :: "memory");
+}
+// O^T += V^T P^T with the fragments already in registers; consecutive MFMAs alternate the two accumulators (db)
+template <typename T>
+__device__ __forceinline__ void att5_pv(f32x16 (&o)[2], const typename T::v8 (&pf)[2][2], const u32x4 (&vf)[2][2][2]) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const char* p = vs + vbase[db] + (kb * 32 + 16 * s2) * K_ROWB;
-                const att_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) att_s16x4*)(p));
-                const att_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) att_s16x4*)(p + 8 * K_ROWB));
-                const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-                u32x4 vw; vw[0] = l2[0]; vw[1] = l2[1]; vw[2] = h2[0]; vw[3] = h2[1];
-                o[db] = T::mfma(__builtin_bit_cast(typename T::v8, vw), pf[kb][s2], o[db]);
-            }
+            for (int db = 0; db < 2; ++db)
+                o[db] = T::mfma(__builtin_bit_cast(typename T::v8, vf[kb][s2][db]), pf[kb][s2], o[db]);
 }
 
-template <typename T, int WAVES_PER_SIMD, bool KTAIL = true>   // KTAIL false: ten 64-key tiles, the last one masked (A/B arm)
+// ---- v6 softmax ("lazy" running maximum).  tools/pipe_rate.hip shows what the v5 softmax costs on gfx950:
+//   * v_pk_{add,mul}_f32 do NOT co-issue with MFMA (37 cycles per instruction while another wave streams MFMAs, 5 alone),
+//     so the 41 packed ops per tile serialised the softmax of one wave with the MFMA phase of its SIMD neighbours;
+//   * v_exp_f32 is 8.75 cycles, v_cvt_pk_f16_f32 8, plain fp32 VALU 4.8 and these DO overlap MFMA.
+// So: no packed-fp32 ops, and fewer VALU ops altogether:
+//   * the QK^T accumulator starts from -m (a 16-register block kept equal to minus the lane's reference maximum), so the
+//     MFMA delivers s - m and the 32 subtractions disappear;
+//   * m is only raised when a tile's maximum exceeds it by more than ATT_LAZY_THR (2^8: P <= 256 is exact range for both
+//     16-bit formats, l and O are fp32) -- after the first tiles that is rare, so the 32-multiply O rescale, the l rescale
+//     and the alpha exp are skipped (wave-uniform branch);
+//   * the row sum is accumulated with v_dot2c (P pair . (1,1) + l): 16 ops instead of 31 adds, and it sums the ROUNDED P,
+//     the same values the PV MFMA uses as numerator.
+// exp2(s - m_ref) / sum is invariant under the choice of m_ref, so the result only differs from v5 in rounding.
+#define ATT_LAZY_THR 8.0f
+#ifndef ATT_EXP
+#define ATT_EXP 0
+#endif
+template <typename T> struct AttOnes;
+template <> struct AttOnes<T_F16> { static constexpr uint32_t v = 0x3C003C00u; };
+template <> struct AttOnes<T_BF16> { static constexpr uint32_t v = 0x3F803F80u; };
+
+template <typename T>
+__device__ __forceinline__ void att6_qk(f32x16 (&s)[2], const typename T::v8 (&qf)[4], const f32x16& negm, const char* ks,
+                                        const int (&kxoff)[4], int lq) {
+    typename T::v8 kf[4][2];
+#pragma unroll
+    for (int ksi = 0; ksi < 4; ++ksi)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+            kf[ksi][kb] = *(const typename T::v8*)(ks + (kb * 32 + lq) * K_ROWB + kxoff[ksi]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ksi = 0; ksi < 4; ++ksi)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+            s[kb] = T::mfma(kf[ksi][kb], qf[ksi], ksi == 0 ? negm : s[kb]);
+}
+
+template <typename T>
+__device__ __forceinline__ void att6_softmax(f32x16 (&s)[2], f32x16 (&o)[2], f32x16& negm, float& l, typename T::v8 (&pf)[2][2],
+                                             bool first) {
+    float tmax = max3f(s[0][0], s[0][1], s[0][2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) tmax = max3f(tmax, s[0][r], s[0][r + 1]);
+    tmax = max3f(tmax, s[0][15], s[1][0]);
+#pragma unroll
+    for (int r = 1; r < 15; r += 2) tmax = max3f(tmax, s[1][r], s[1][r + 1]);
+    tmax = __builtin_fmaxf(tmax, s[1][15]);
+    tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 32, 64));  // the partner lane holds the other 32 keys of this query: the
+                                                             // two lanes MUST agree on the reference (their P meet in one MFMA)
+    // tmax is relative to the reference maximum already (s = q.k - m)
+    if (first || __builtin_amdgcn_ballot_w64(tmax > ATT_LAZY_THR) != 0) {
+        const float delta = (first || tmax > ATT_LAZY_THR) ? tmax : 0.f;
+        const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);       // O = l = 0 before the first tile
+        const float nm = negm[0] - delta;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = nm;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        l *= alpha;
+    }
+    float l0 = l, l1 = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            u32x4 pw;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                pw[w] = T::pack2(__builtin_amdgcn_exp2f(s[kb][8 * s2 + 2 * w]), __builtin_amdgcn_exp2f(s[kb][8 * s2 + 2 * w + 1]));
+                if (w & 1) l1 = T::dot2(pw[w], AttOnes<T>::v, l1);
+                else l0 = T::dot2(pw[w], AttOnes<T>::v, l0);
+            }
+            pf[kb][s2] = __builtin_bit_cast(typename T::v8, pw);
+        }
+    l = l0 + l1;
+}
+
+// KTAIL false: ten 64-key tiles, the last one masked (A/B arm).  ABL (timing-only ablations, results are garbage):
+// 1 no K/V DMA inside the tile loop, 2 no per-tile vmcnt wait / barrier.
+template <typename T, int WAVES_PER_SIMD, bool KTAIL = true, bool LAZY = true, int ABL = 0>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention5_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) char smem[4 * K_TILE_BYTES];              // K0 K1 V0 V1, 8 KB each
     char* ks0 = smem;
@@ -511,6 +642,9 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention5_kernel(const u
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
     float m = -1e30f, l = 0.f;
+    f32x16 negm;                                            // LAZY: minus the reference maximum, the QK^T accumulator seed
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
     int kxoff[4];
 #pragma unroll
     for (int ksi = 0; ksi < 4; ++ksi) kxoff[ksi] = ((ksi * 2 + g) ^ ((lq >> 1) & 7)) << 4;
@@ -536,6 +670,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention5_kernel(const u
     // 577 = 9 x 64 + 1: nine full key tiles go through the MFMA loop, the last key (token 576) is a VALU tail (a tenth
     // tile would spend a whole tile's MFMA, softmax and DMA work on one valid key: 9 % of the kernel).
     static_assert(VIT_TOKENS == 9 * ATT_KT + 1, "key tail assumes 577 tokens");
+    static_assert(KTAIL || !LAZY, "the lazy softmax has no masked-tile path");
     constexpr int NFULL = KTAIL ? 9 : ATT_NT;
     att5_dma(rk, ks0, wave, dvo_k, 0);
     att5_dma(rv, vs0, wave, dvo_v, 0);
@@ -543,7 +678,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention5_kernel(const u
     __syncthreads();
     for (int t = 0; t < NFULL; ++t) {
         const int cur = t & 1;
-        if (t + 1 < NFULL) {                                  // both tiles of step t+1 land under this tile's math
+        if (ABL != 1 && t + 1 < NFULL) {                      // both tiles of step t+1 land under this tile's math
             att5_dma(rk, ks0 + (cur ^ 1) * K_TILE_BYTES, wave, dvo_k, t + 1);
             att5_dma(rv, vs0 + (cur ^ 1) * K_TILE_BYTES, wave, dvo_v, t + 1);
         }
@@ -552,13 +687,25 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention5_kernel(const u
         if (wave_active) {
             f32x16 sA[2];
             typename T::v8 pfA[2][2];
-            att3_qk<T>(sA, qf, ks, kxoff, lq);
-            if (KTAIL || t < ATT_NT - 1) att3_softmax<T, false>(sA, o, m, l, pfA, t, g);   // (conditional O rescale: no gain measured)
-            else att3_softmax<T, true>(sA, o, m, l, pfA, t, g);
-            att5_pv<T>(o, pfA, vs, vbase);
+            u32x4 vf[2][2][2];
+            if (LAZY) {
+                att6_qk<T>(sA, qf, negm, ks, kxoff, lq);
+                att5_load_v<T>(vf, vs, vbase);                // 16 transposing reads in flight under the softmax
+                att6_softmax<T>(sA, o, negm, l, pfA, t == 0);
+                att5_wait_v(vf);
+            } else {
+                att3_qk<T>(sA, qf, ks, kxoff, lq);
+                att5_load_v<T>(vf, vs, vbase);
+                if (KTAIL || t < ATT_NT - 1) att3_softmax<T, false>(sA, o, m, l, pfA, t, g);
+                else att3_softmax<T, true>(sA, o, m, l, pfA, t, g);
+                att5_wait_v(vf);
+            }
+            att5_pv<T>(o, pfA, vf);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMAs of step t+1 have landed
-        __syncthreads();
+        if (ABL != 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's DMAs of step t+1 have landed
+            __syncthreads();
+        }
     }
     if (KTAIL && wave_active) {
         // ---- key 576: s = q . k (this lane holds 32 of the 64 dims, its lane^32 partner the rest), one online-softmax step,
@@ -574,6 +721,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention5_kernel(const u
             for (int w = 0; w < 4; ++w) sp = T::dot2(qq[w], kq[w], sp);
         }
         const float sc = sp + __shfl_xor(sp, 32, 64);
+        if (LAZY) m = -negm[0];
         const float m_new = fmaxf(m, sc);
         const float alpha = __builtin_amdgcn_exp2f(m - m_new);
         const float pk = __builtin_amdgcn_exp2f(sc - m_new);
@@ -614,13 +762,14 @@ static int attention_variant() {
     if (v < 0) {
         const char* e = getenv("PIGEON_ATTN_VARIANT");
         v = e ? atoi(e) : 11;
-        if (v < 1 || v > 12) v = 11;
+        if (v < 1 || v > 15) v = 11;
     }
     return v;
 }
 
-// Variants (env PIGEON_ATTN_VARIANT): 11 (default) v5 = K and V by DMA, transposing LDS reads, single-key tail;
-// 12 the same with a masked tenth key tile instead of the tail (A/B arm); 4 / 10 v4 register-staged / K by DMA;
+// Variants (env PIGEON_ATTN_VARIANT): 11 (default) v6 = K and V by DMA, transposing LDS reads, single-key tail, lazy softmax;
+// 13 the same with the v5 softmax (running maximum updated every tile, packed fp32 ops); 12 = 13 with a masked tenth key
+// tile instead of the tail (A/B arms); 14 / 15 timing-only ablations of 11 (no DMA in the loop / no per-tile barrier); 4 / 10 v4 register-staged / K by DMA;
 // 5 v4 forced to 4 waves per SIMD (spills); 6..9 timing-only ablations of v4; 1 the first kernel.
 template <typename KF, typename KB>
 static int att_launch2(int dtype, KF kf, KB kb, dim3 grid, const void* qkv, void* out, hipStream_t s) {
@@ -643,7 +792,10 @@ int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hip
         case 8: return att_launch2(dtype, attention4_kernel<T_F16, 3, 5>, attention4_kernel<T_BF16, 3, 5>, grid, qkv, out, s);
         case 9: return att_launch2(dtype, attention4_kernel<T_F16, 3, 7>, attention4_kernel<T_BF16, 3, 7>, grid, qkv, out, s);
         case 10: return att_launch2(dtype, attention4_kernel<T_F16, 3, 0, true>, attention4_kernel<T_BF16, 3, 0, true>, grid, qkv, out, s);
-        case 12: return att_launch2(dtype, attention5_kernel<T_F16, 3, false>, attention5_kernel<T_BF16, 3, false>, grid, qkv, out, s);
+        case 12: return att_launch2(dtype, attention5_kernel<T_F16, 3, false, false>, attention5_kernel<T_BF16, 3, false, false>, grid, qkv, out, s);
+        case 14: return att_launch2(dtype, attention5_kernel<T_F16, 3, true, true, 1>, attention5_kernel<T_BF16, 3, true, true, 1>, grid, qkv, out, s);
+        case 15: return att_launch2(dtype, attention5_kernel<T_F16, 3, true, true, 2>, attention5_kernel<T_BF16, 3, true, true, 2>, grid, qkv, out, s);
+        case 13: return att_launch2(dtype, attention5_kernel<T_F16, 3, true, false>, attention5_kernel<T_BF16, 3, true, false>, grid, qkv, out, s);
         default: return att_launch2(dtype, attention5_kernel<T_F16, 3>, attention5_kernel<T_BF16, 3>, grid, qkv, out, s);
     }
 }

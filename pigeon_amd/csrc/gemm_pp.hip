@@ -43,6 +43,9 @@ constexpr int PP_SLAB_OFF = PP_STAGE;                      // epilogue slabs ove
 constexpr int PP_SLAB_ROWF = 64 + 4;                       // padded slab row, floats
 constexpr int PP_SLAB_BYTES = 32 * PP_SLAB_ROWF * 4;       // 8704 B per wave
 constexpr int PP_LDS = 160 * 1024;
+#ifndef PP_STORE_AUX
+#define PP_STORE_AUX 0                                   // cache policy of the epilogue stores (bit 0 sc0, bit 1 nt, bit 4 sc1)
+#endif
 
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -108,12 +111,15 @@ __device__ __forceinline__ void load_frag(Frag<T>& f, const char* sa, const char
 }
 
 // swapped operands (weights as "A"): D[n][m] -> a lane owns output row m = lane&31 and column quads
-template <typename T>
+// ZERO: first k-step of an output tile -- the accumulator operand is the inline constant 0, so the tile loop does not
+// spend 128 v_mov per wave (~512 cycles, 2.5 % of a K = 1024 tile) clearing registers between the epilogue and the mainloop.
+template <typename T, bool ZERO = false>
 __device__ __forceinline__ void mma8(f32x16 (&acc)[4][2], const Frag<T>& f) {
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma(f.b[j], f.a[i], acc[i][j]);
+        for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma(f.b[j], f.a[i], ZERO ? zero16 : acc[i][j]);
 }
 
 __device__ __forceinline__ void wait_lgkm0() {
@@ -157,7 +163,7 @@ __device__ __forceinline__ void fetch_xrows(u32x4 (&dst)[8], const XCtx& x, int 
 // One K tile in ping-pong form.  D0..D2 = number of this wave's 8 DMAs issued in LOAD phases 0..2 (rest in phase 3).
 // XF: this call may also issue the early residual fetch (phases 2 and 3, AFTER the tile's DMAs, so that the counted
 // vmcnt(16) at the end of phase 3 still means "my DMAs of the next K tile have landed").
-template <typename T, int D0, int D1, int D2, int ABL, bool XF = false>
+template <typename T, int D0, int D1, int D2, int ABL, bool XF = false, bool ZERO = false>
 __device__ __forceinline__ void ktile_pp(f32x16 (&acc)[4][2], const char* cur, char* nxt, int a_base, int b_base,
                                          const int (&xoff)[4], const TileCtx& c, int wave, const int (&voffA)[4],
                                          const int (&voffW)[4], int soff_next, bool has_next, bool xf, const XCtx& xc,
@@ -189,7 +195,8 @@ __device__ __forceinline__ void ktile_pp(f32x16 (&acc)[4][2], const char* cur, c
         wait_lgkm0();
         raw_barrier();
         __builtin_amdgcn_s_setprio(1);
-        mma8<T>(acc, f);
+        if (ZERO && kk == 0) mma8<T, true>(acc, f);
+        else mma8<T>(acc, f);
         __builtin_amdgcn_s_setprio(0);
         raw_barrier();
     }
@@ -197,7 +204,7 @@ __device__ __forceinline__ void ktile_pp(f32x16 (&acc)[4][2], const char* cur, c
 
 // Free-running form of the same K tile (MODE 0): one barrier per K tile (taken by the caller), fragments double
 // buffered in registers, the DMAs of the next tile spread 2 per k-step between the MFMA groups (= gemm_bf16 variant 8).
-template <typename T>
+template <typename T, bool ZERO = false>
 __device__ __forceinline__ void ktile_free(f32x16 (&acc)[4][2], const char* cur, char* nxt, int a_base, int b_base,
                                            const int (&xoff)[4], const TileCtx& c, int wave, const int (&voffA)[4],
                                            const int (&voffW)[4], int soff_next, bool has_next) {
@@ -213,7 +220,8 @@ __device__ __forceinline__ void ktile_free(f32x16 (&acc)[4][2], const char* cur,
             if (kk == 3) issue_dma<6, 2>(c, nxt, wave, voffA, voffW, soff_next);
         }
         __builtin_amdgcn_s_setprio(1);
-        mma8<T>(acc, f[kk & 1]);
+        if (ZERO && kk == 0) mma8<T, true>(acc, f[0]);
+        else mma8<T>(acc, f[kk & 1]);
         __builtin_amdgcn_s_setprio(0);
     }
 }
@@ -301,6 +309,7 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs&
     float* slab = (float*)(smem + PP_SLAB_OFF + wave * PP_SLAB_BYTES);
     const int rr = lane / LPR, cc = (lane % LPR) * CPL;
     const int col = col0 + cc;
+    const float qsc = (EPI == EPI_QKV || EPI == EPI_QKV_LN) && col < g.qcols ? g.qscale : 1.f;
 
     if constexpr (EPI == EPI_PATCH) {
         prefetch_next();
@@ -409,7 +418,9 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs&
                         lo += bias.lo; hi += bias.hi;
                     }
                     if constexpr (EPI == EPI_QKV || EPI == EPI_QKV_LN) {
-                        if (col < g.qcols) { lo *= g.qscale; hi *= g.qscale; }   // qcols is a multiple of 8
+                        // qcols is a multiple of 8, so a lane's 8 columns are all inside or all outside; the factor is a
+                        // per-lane constant of the tile (x * 1.0f is exact) and K / V strips skip the multiply altogether
+                        if (col0 < g.qcols) { lo *= qsc; hi *= qsc; }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { lo[e] = quick_gelu(lo[e]); hi[e] = quick_gelu(hi[e]); }
@@ -417,11 +428,11 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs&
                     u32x4 pk;
                     pk[0] = pack16x2<T>(lo[0], lo[1]); pk[1] = pack16x2<T>(lo[2], lo[3]);
                     pk[2] = pack16x2<T>(hi[0], hi[1]); pk[3] = pack16x2<T>(hi[2], hi[3]);
-                    __builtin_amdgcn_raw_buffer_store_b128(pk, ro, ooff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, ro, ooff, 0, PP_STORE_AUX);
                 } else if constexpr (RESID) {
                     f32x4 x = __builtin_bit_cast(f32x4, XEARLY ? xq[i][it] : xr[i & 1][it][0]);
                     x += lo + bias.lo;                       // same expression as epi_store_f32x4<EPI_RESID>
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), ro, ooff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), ro, ooff, 0, PP_STORE_AUX);
                     if constexpr (STAT) {
                         f32x4 y = __builtin_bit_cast(f32x4, xr[i & 1][it][1]);
                         y += hi + bias.hi;
@@ -507,13 +518,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     bool first = true;
 
     while (true) {
-        f32x16 acc[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        f32x16 acc[4][2];                                    // not cleared: the first k-step of the tile runs with C = 0
 
         if (first || NST == 0) {
             wait_vm0();
@@ -531,20 +536,36 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         if constexpr (MODE == 0) {
             for (int t = 0; t < nt; t += 2) {
                 if (t > 0) { wait_vm0(); wait_lgkm0(); raw_barrier(); }
-                ktile_free<T>(acc, smem, smem + PP_STAGE, a_base, b_base, xoff, c, wave, voffA, voffW, (t + 1) * ROWB, true);
+                if (t == 0) ktile_free<T, true>(acc, smem, smem + PP_STAGE, a_base, b_base, xoff, c, wave, voffA, voffW, ROWB, true);
+                else ktile_free<T>(acc, smem, smem + PP_STAGE, a_base, b_base, xoff, c, wave, voffA, voffW, (t + 1) * ROWB, true);
                 wait_vm0(); wait_lgkm0(); raw_barrier();
                 ktile_free<T>(acc, smem + PP_STAGE, smem, a_base, b_base, xoff, c, wave, voffA, voffW, (t + 2) * ROWB, t + 2 < nt);
             }
             wait_lgkm0(); raw_barrier();
         } else {
             if (follower) raw_barrier();
-            for (int t = 0; t < nt; t += 2) {
+            int t0 = 0;
+            if (nt > 2) {                                     // first K-tile pair peeled: its first k-step runs with C = 0
+                ktile_pp<T, D0, D1, D2, ABL, false, true>(acc, smem, smem + PP_STAGE, a_base, b_base, xoff, c, wave, voffA, voffW,
+                                                          ROWB, true, false, xc, xq);
+                ktile_pp<T, D0, D1, D2, ABL, false>(acc, smem + PP_STAGE, smem, a_base, b_base, xoff, c, wave, voffA, voffW,
+                                                    2 * ROWB, true, false, xc, xq);
+                t0 = 2;
+            } else {                                          // K = 128: one pair, which may carry the early residual fetch
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+            for (int t = t0; t < nt; t += 2) {
                 const bool xf = XEARLY && (t + 2 == nt);
                 if (XEARLY && xf) xc = make_xctx(g, c.m0 + wm * 128, c.n0 + wn * 64, lane);
                 ktile_pp<T, D0, D1, D2, ABL, XEARLY>(acc, smem, smem + PP_STAGE, a_base, b_base, xoff, c, wave, voffA, voffW,
-                                                (t + 1) * ROWB, true, xf, xc, xq);
+                                                     (t + 1) * ROWB, true, xf, xc, xq);
                 ktile_pp<T, D0, D1, D2, ABL, false>(acc, smem + PP_STAGE, smem, a_base, b_base, xoff, c, wave, voffA, voffW,
-                                                (t + 2) * ROWB, t + 2 < nt, false, xc, xq);
+                                                    (t + 2) * ROWB, t + 2 < nt, false, xc, xq);
             }
             if (MODE == 1 && !follower) raw_barrier();       // re-align: every wave has left the mainloop
         }
