@@ -489,13 +489,6 @@ __device__ __forceinline__ void att5_load_v(u32x4 (&vf)[2][2][2], const char* vs
     const uint32_t vs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)vs;
     const uint32_t a0 = vs_lds + vbase[0], a1 = vs_lds + vbase[1];
     __builtin_amdgcn_sched_barrier(0);                       // after the last QK^T MFMA: its lgkmcnt waits must not see these
-#if ATT_EXP == 1
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#elif ATT_EXP == 2
-    asm volatile("s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7" ::: "memory");
-#elif ATT_EXP == 3
-    asm volatile("s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7" ::: "memory");
-#endif
 #define ATT_TR2(kb, s2)                                                                                       \
     {                                                                                                         \
         const u32x2 l0 = att_tr_read<((kb) * 32 + 16 * (s2)) * K_ROWB>(a0);                                   \
@@ -539,11 +532,11 @@ __device__ __forceinline__ void att5_pv(f32x16 (&o)[2], const typename T::v8 (&p
 //     and the alpha exp are skipped (wave-uniform branch);
 //   * the row sum is accumulated with v_dot2c (P pair . (1,1) + l): 16 ops instead of 31 adds, and it sums the ROUNDED P,
 //     the same values the PV MFMA uses as numerator.
+//     (v_dot2c does not co-issue with MFMA either; 32 plain v_add_f32 instead measured 2.5 % SLOWER on the full chip --
+//     the GPU runs this kernel at its 1400 W power cap, where instruction count matters more than pipe overlap; raising
+//     the MFMA phases with s_setprio changed nothing.)
 // exp2(s - m_ref) / sum is invariant under the choice of m_ref, so the result only differs from v5 in rounding.
 #define ATT_LAZY_THR 8.0f
-#ifndef ATT_EXP
-#define ATT_EXP 0
-#endif
 template <typename T> struct AttOnes;
 template <> struct AttOnes<T_F16> { static constexpr uint32_t v = 0x3C003C00u; };
 template <> struct AttOnes<T_BF16> { static constexpr uint32_t v = 0x3F803F80u; };

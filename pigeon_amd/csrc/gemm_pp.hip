@@ -145,15 +145,29 @@ struct XCtx {
     __amdgpu_buffer_rsrc_t ro;
     int voff, rstep, sstep;
 };
+// WIDE: the 8-columns-per-lane geometry of EPI_RESID_STAT (8 lanes per row, 8 rows per instruction, two 16-byte pieces)
+template <bool WIDE = false>
 __device__ __forceinline__ XCtx make_xctx(const GemmArgs& g, int row0, int col0, int lane) {
     XCtx x;
     int rv = g.M - row0; rv = rv < 0 ? 0 : (rv > 128 ? 128 : rv);
     const uint32_t nbytes = rv > 0 ? (uint32_t)(((int64_t)(rv - 1) * g.ldc + 64) * 4) : 0u;
     x.ro = make_rsrc((const char*)g.out + ((int64_t)row0 * g.ldc + col0) * 4, nbytes);
-    x.voff = ((lane >> 4) * (int)g.ldc + (lane & 15) * 4) * 4;
-    x.rstep = 4 * (int)g.ldc * 4;
+    if (WIDE) {
+        x.voff = ((lane >> 3) * (int)g.ldc + (lane & 7) * 8) * 4;
+        x.rstep = 8 * (int)g.ldc * 4;
+    } else {
+        x.voff = ((lane >> 4) * (int)g.ldc + (lane & 15) * 4) * 4;
+        x.rstep = 4 * (int)g.ldc * 4;
+    }
     x.sstep = 32 * (int)g.ldc * 4;
     return x;
+}
+// slab 0 of the wide geometry: dst[it * 2 + h]
+__device__ __forceinline__ void fetch_xrows_wide(u32x4 (&dst)[8], const XCtx& x) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) dst[it * 2 + h] = __builtin_amdgcn_raw_buffer_load_b128(x.ro, x.voff + 16 * h, it * x.rstep, 0);
 }
 __device__ __forceinline__ void fetch_xrows(u32x4 (&dst)[8], const XCtx& x, int slab) {
 #pragma unroll
@@ -163,7 +177,8 @@ __device__ __forceinline__ void fetch_xrows(u32x4 (&dst)[8], const XCtx& x, int 
 // One K tile in ping-pong form.  D0..D2 = number of this wave's 8 DMAs issued in LOAD phases 0..2 (rest in phase 3).
 // XF: this call may also issue the early residual fetch (phases 2 and 3, AFTER the tile's DMAs, so that the counted
 // vmcnt(16) at the end of phase 3 still means "my DMAs of the next K tile have landed").
-template <typename T, int D0, int D1, int D2, int ABL, bool XF = false, bool ZERO = false>
+// XF 2: EPI_RESID_STAT fetches slab 0 only (eight loads in phase 3; its slab-ahead double buffer covers the rest).
+template <typename T, int D0, int D1, int D2, int ABL, int XF = 0, bool ZERO = false>
 __device__ __forceinline__ void ktile_pp(f32x16 (&acc)[4][2], const char* cur, char* nxt, int a_base, int b_base,
                                          const int (&xoff)[4], const TileCtx& c, int wave, const int (&voffA)[4],
                                          const int (&voffW)[4], int soff_next, bool has_next, bool xf, const XCtx& xc,
@@ -184,12 +199,16 @@ __device__ __forceinline__ void ktile_pp(f32x16 (&acc)[4][2], const char* cur, c
             if (kk == 2) issue_dma<D0 + D1, D2>(c, nxt, wave, voffA, voffW, soff_next);
             if (kk == 3) issue_dma<D0 + D1 + D2, D3>(c, nxt, wave, voffA, voffW, soff_next);
         }
-        if constexpr (XF) {
+        if constexpr (XF == 1) {
             if (xf && kk == 2) fetch_xrows(xq[0], xc, 0);
             if (xf && kk == 3) fetch_xrows(xq[1], xc, 1);
         }
+        if constexpr (XF == 2) {
+            if (xf && kk == 3) fetch_xrows_wide(xq[0], xc);
+        }
         if (kk == 3 && has_next) {
-            if (XF && xf) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if (XF == 1 && xf) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (XF == 2 && xf) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         wait_lgkm0();
@@ -292,7 +311,7 @@ __device__ __forceinline__ float row8_sum(float v) {
     return v;
 }
 
-template <typename T, int EPI, bool XEARLY, typename PREFETCH>
+template <typename T, int EPI, int XEARLY, typename PREFETCH>
 __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs& g, char* smem, int wave, int lane,
                                             int row0, int col0, const EpiBias<EPI>& bias, const u32x2 (&rs)[4][4],
                                             PREFETCH&& prefetch_next, const XCtx& xc, u32x4 (&xq)[4][8]) {
@@ -374,10 +393,16 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs&
                         xr[set][it][h] = __builtin_amdgcn_raw_buffer_load_b128(ro, voff + 16 * h, i * sstep + it * rstep, 0);
             }
         };
-        if constexpr (!XEARLY) fetch_x(0, 0);
+        if constexpr (XEARLY == 0) fetch_x(0, 0);
+        if constexpr (XEARLY == 2) {                         // slab 0 came in during the last K-tile pair
+#pragma unroll
+            for (int it = 0; it < ITS; ++it)
+#pragma unroll
+                for (int h = 0; h < XPI; ++h) xr[0][it][h] = xq[0][it * 2 + h];
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if constexpr (!XEARLY) { if (i + 1 < 4) fetch_x(i + 1, (i + 1) & 1); }
+            if constexpr (XEARLY != 1) { if (i + 1 < 4) fetch_x(i + 1, (i + 1) & 1); }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -386,7 +411,7 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs&
                     *(f32x4*)(slab + lrow * ROWPF + j * 32 + q * 8 + 4 * lhalf) = v;
                 }
             // slabs 0 / 1 came in during the mainloop; with their accumulators parked, fetch the rows of slab i + 2
-            if constexpr (XEARLY) { if (i + 2 < 4) fetch_xrows(xq[i + 2], xc, i + 2); }
+            if constexpr (XEARLY == 1) { if (i + 2 < 4) fetch_xrows(xq[i + 2], xc, i + 2); }
             wave_lds_fence();
 #pragma unroll
             for (int it = 0; it < ITS; ++it) {
@@ -430,7 +455,7 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs&
                     pk[2] = pack16x2<T>(hi[0], hi[1]); pk[3] = pack16x2<T>(hi[2], hi[3]);
                     __builtin_amdgcn_raw_buffer_store_b128(pk, ro, ooff, 0, PP_STORE_AUX);
                 } else if constexpr (RESID) {
-                    f32x4 x = __builtin_bit_cast(f32x4, XEARLY ? xq[i][it] : xr[i & 1][it][0]);
+                    f32x4 x = __builtin_bit_cast(f32x4, XEARLY == 1 ? xq[i][it] : xr[i & 1][it][0]);
                     x += lo + bias.lo;                       // same expression as epi_store_f32x4<EPI_RESID>
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), ro, ooff, 0, PP_STORE_AUX);
                     if constexpr (STAT) {
@@ -530,7 +555,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         raw_barrier();                                       // B_0: K tile 0 visible, previous epilogue's slabs released
         u32x2 rs[4][4];
         if constexpr (epi_ln<EPI>()) load_rowstat<EPI>(rs, g, c.m0 + wm * 128, err);
-        constexpr bool XEARLY = (EPI == EPI_RESID) && (MODE != 0) && (ABL == 0);
+        constexpr int XEARLY = (MODE == 0 || ABL != 0) ? 0 : (EPI == EPI_RESID ? 1 : (EPI == EPI_RESID_STAT ? 2 : 0));
         XCtx xc;
         u32x4 xq[4][8];
         if constexpr (MODE == 0) {
@@ -546,9 +571,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
             if (follower) raw_barrier();
             int t0 = 0;
             if (nt > 2) {                                     // first K-tile pair peeled: its first k-step runs with C = 0
-                ktile_pp<T, D0, D1, D2, ABL, false, true>(acc, smem, smem + PP_STAGE, a_base, b_base, xoff, c, wave, voffA, voffW,
+                ktile_pp<T, D0, D1, D2, ABL, 0, true>(acc, smem, smem + PP_STAGE, a_base, b_base, xoff, c, wave, voffA, voffW,
                                                           ROWB, true, false, xc, xq);
-                ktile_pp<T, D0, D1, D2, ABL, false>(acc, smem + PP_STAGE, smem, a_base, b_base, xoff, c, wave, voffA, voffW,
+                ktile_pp<T, D0, D1, D2, ABL, 0>(acc, smem + PP_STAGE, smem, a_base, b_base, xoff, c, wave, voffA, voffW,
                                                     2 * ROWB, true, false, xc, xq);
                 t0 = 2;
             } else {                                          // K = 128: one pair, which may carry the early residual fetch
@@ -560,11 +585,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
                         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
             }
             for (int t = t0; t < nt; t += 2) {
-                const bool xf = XEARLY && (t + 2 == nt);
-                if (XEARLY && xf) xc = make_xctx(g, c.m0 + wm * 128, c.n0 + wn * 64, lane);
+                const bool xf = XEARLY != 0 && (t + 2 == nt);
+                if (XEARLY != 0 && xf) xc = make_xctx<XEARLY == 2>(g, c.m0 + wm * 128, c.n0 + wn * 64, lane);
                 ktile_pp<T, D0, D1, D2, ABL, XEARLY>(acc, smem, smem + PP_STAGE, a_base, b_base, xoff, c, wave, voffA, voffW,
                                                      (t + 1) * ROWB, true, xf, xc, xq);
-                ktile_pp<T, D0, D1, D2, ABL, false>(acc, smem + PP_STAGE, smem, a_base, b_base, xoff, c, wave, voffA, voffW,
+                ktile_pp<T, D0, D1, D2, ABL, 0>(acc, smem + PP_STAGE, smem, a_base, b_base, xoff, c, wave, voffA, voffW,
                                                     (t + 2) * ROWB, t + 2 < nt, false, xc, xq);
             }
             if (MODE == 1 && !follower) raw_barrier();       // re-align: every wave has left the mainloop

@@ -105,8 +105,9 @@ def test_gemm_persistent_many_tiles_bit_identical(env):
             ops.gemm16(A, W, bias, o, epi, qscale=0.25, qcols=256, variant=var, M=M)
             outs.append(o)
         torch.cuda.synchronize()
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), f"epilogue {epi}"
-        assert bool((outs[1][M:].float() == 7.0).all()) and bool((outs[2][M:].float() == 7.0).all())
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o), f"epilogue {epi}"
+            assert bool((o[M:].float() == 7.0).all())
 
 
 def test_gemm_identity_is_not_transposed(env):
@@ -454,15 +455,17 @@ def test_ln_fold_building_blocks(env):
 
 
 def test_ln_fold_encoder_matches_reference(env, golden_dir, monkeypatch):
-    """The experimental LayerNorm-folded encoder (PIGEON_LN_FOLD=1) against the same golden vectors and tolerance as the
-    default path, and against the default path itself."""
+    """The LayerNorm-folded encoder (the default) and the separate-LayerNorm chain (PIGEON_LN_FOLD=0) against the same golden
+    vectors and tolerance, and against each other."""
     from pigeon_amd.clip_embedder import HipCLIPVisionModel
     sd = env["syn"].make_vit_weights(seed=11, layers=2, affine_jitter=True)
     px = env["syn"].make_pixels(4, seed=77).to(DEV)
     ref = torch.from_numpy(_gold(golden_dir, "vit2.npz")["embedding"])
-    base = HipCLIPVisionModel(sd, layers=2).to(DEV).embed(px).cpu()
     monkeypatch.setenv("PIGEON_LN_FOLD", "1")
     fold = HipCLIPVisionModel(sd, layers=2).to(DEV).embed(px).cpu()
+    monkeypatch.setenv("PIGEON_LN_FOLD", "0")
+    base = HipCLIPVisionModel(sd, layers=2).to(DEV).embed(px).cpu()
     assert env["orc"].rel_err(fold, ref) < EMB_TOL
+    assert env["orc"].rel_err(base, ref) < EMB_TOL
     assert env["orc"].rel_err(fold, base) < 5e-4
-    assert not torch.equal(fold, base)                    # it really took the other path
+    assert not torch.equal(fold, base)                    # two different chains really ran

@@ -18,15 +18,22 @@ def collect(sub, counter):
 
 
 fetch, write = collect("pmc_fetch", "FETCH_SIZE"), collect("pmc_write", "WRITE_SIZE")
-CLASSES = {"gemm_qkv": ("gemm_pp_kernel<T_F16, 0,", 2 * 1024 + 2 * 3072), "gemm_fc1": ("gemm_pp_kernel<T_F16, 1,", 2 * 1024 + 2 * 4096),
-           "gemm_out_fc2_mixed": ("gemm_pp_kernel<T_F16, 2,", None), "attention": ("attention", 2 * 3072 + 2 * 1024),
-           "layernorm": ("layernorm_kernel", 4 * 1024 + 2 * 1024)}
+# kernel-name patterns per class: the LayerNorm-folded chain (default) uses epilogues 6 / 7 / 5, the separate-LayerNorm chain 0 / 1 / 2
+CLASSES = {"gemm_qkv": (("gemm_pp_kernel<T_F16, 6,", "gemm_pp_kernel<T_F16, 0,"), 2 * 1024 + 2 * 3072),
+           "gemm_fc1": (("gemm_pp_kernel<T_F16, 7,", "gemm_pp_kernel<T_F16, 1,"), 2 * 1024 + 2 * 4096),
+           "gemm_out_fc2_mixed": (("gemm_pp_kernel<T_F16, 5,", "gemm_pp_kernel<T_F16, 2,"), None),
+           "attention": (("attention",), 2 * 3072 + 2 * 1024),
+           "layernorm": (("layernorm_kernel",), 4 * 1024 + 2 * 1024)}
 res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py, one launch = %d token rows; KiB as "
                "reported; hbm_bytes_per_launch_corrected = 2 x FETCH_SIZE (gfx950 under-report of wide coalesced reads, "
                "MI355X_MICROARCH.md) + WRITE_SIZE; algorithmic_bytes = activation rows in + out (+ weights once)" % rows}
-for cls, (pat, bytes_per_row) in CLASSES.items():
-    f = [v for k, v in fetch.items() if pat in k]
-    w = [v for k, v in write.items() if pat in k]
+for cls, (pats, bytes_per_row) in CLASSES.items():
+    f, w = [], []
+    for pat in pats:                                   # first pattern with data wins
+        f = [v for k, v in fetch.items() if pat in k]
+        w = [v for k, v in write.items() if pat in k]
+        if f and w:
+            break
     if not f or not w:
         continue
     e = {"rows": rows, "fetch_size_kib_raw": f[0], "write_size_kib": w[0],

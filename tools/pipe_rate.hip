@@ -117,7 +117,7 @@ __device__ __forceinline__ float run_job(float seed, char* lds) {
 // over the results, 32 exp, 16 cvt_pk, 16 dot2c, then 8 MFMAs consuming the packed values.  MODE 1 replaces the VALU part
 // by nothing (MFMA only), MODE 2 drops the MFMAs (VALU only).  Run with 1..3 waves per SIMD to see how far the MFMA and
 // VALU phases of different waves overlap.
-template <int MODE>
+template <int MODE, int PRIO = 0>
 __global__ __launch_bounds__(768) void attn_like_kernel(float seed, long long* cyc, float* sink) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     f16x8 q, k;
@@ -130,11 +130,15 @@ __global__ __launch_bounds__(768) void attn_like_kernel(float seed, long long* c
         f32x16 s0 = zero, s1 = zero;
         asm volatile("" : "+v"(q), "+v"(k));                 // not loop-invariant for the compiler
         if (MODE != 2) {
+            if (PRIO == 1) __builtin_amdgcn_s_setprio(3);
+            if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k, q, s0, 0, 0, 0);
                 s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(q, k, s1, 0, 0, 0);
             }
+            if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+            if (PRIO == 2) __builtin_amdgcn_s_setprio(3);
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s0[r] = o0[r] * 0.5f; s1[r] = o1[r] * 0.25f; }
@@ -168,6 +172,8 @@ __global__ __launch_bounds__(768) void attn_like_kernel(float seed, long long* c
             for (int r = 0; r < 16; ++r) pw[r] = __builtin_bit_cast(uint32_t, s0[r]) ^ __builtin_bit_cast(uint32_t, s1[r]);
         }
         if (MODE != 2) {
+            if (PRIO == 1) __builtin_amdgcn_s_setprio(3);
+            if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const u32x4 pv = {pw[4 * u], pw[4 * u + 1], pw[4 * u + 2], pw[4 * u + 3]};
@@ -186,12 +192,12 @@ __global__ __launch_bounds__(768) void attn_like_kernel(float seed, long long* c
     sink[threadIdx.x] = acc;
 }
 
-template <int MODE>
+template <int MODE, int PRIO = 0>
 static void run_attn_like(const char* name) {
     long long* cyc; float* sink;
     hipMalloc(&cyc, 128); hipMalloc(&sink, 4096);
     for (int wps = 1; wps <= 3; ++wps) {
-        for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((attn_like_kernel<MODE>), dim3(1), dim3(256 * wps), 0, 0, 1.0001f, cyc, sink);
+        for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((attn_like_kernel<MODE, PRIO>), dim3(1), dim3(256 * wps), 0, 0, 1.0001f, cyc, sink);
         hipDeviceSynchronize();
         long long c[12];
         hipMemcpy(c, cyc, 8 * 4 * wps, hipMemcpyDeviceToHost);
@@ -264,6 +270,8 @@ int main() {
     run<2, 4>("v_pk_mul_f32 + mfma", n32, n32);
     run_attn_like<0>("attention-like");
     run_attn_like<3>("attn-like, v_add for dot2c");
+    run_attn_like<3, 1>("v_add, MFMA phases prio 3");
+    run_attn_like<3, 2>("v_add, VALU phase prio 3");
     run_attn_like<1>("attention-like MFMA only");
     run_attn_like<2>("attention-like VALU only");
     return 0;
