@@ -89,12 +89,14 @@ __device__ __forceinline__ TileCtx make_tile(const GemmArgs& g, int L) {
 }
 
 // DMA d of a K tile: d 0..3 = this wave's four 8-row groups of A, d 4..7 = of W.
-template <int FROM, int CNT>
+// SKIP (timing-only ablations 44 / 45): bit mask of DMAs left out -- what would 12.5 % / 25 % fewer operand bytes per tile buy?
+template <int FROM, int CNT, int SKIP = 0>
 __device__ __forceinline__ void issue_dma(const TileCtx& c, char* stage, int wave, const int (&voffA)[4], const int (&voffW)[4],
                                           int soff) {
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
         if (d < FROM || d >= FROM + CNT) continue;
+        if ((SKIP >> d) & 1) continue;
         if (d < 4) dma16(c.ra, stage + (wave + 8 * d) * 8 * ROWB, voffA[d], soff);
         else dma16(c.rw, stage + PP_W_OFF + (wave + 8 * (d - 4)) * 8 * ROWB, voffW[d - 4], soff);
     }
@@ -194,10 +196,11 @@ __device__ __forceinline__ void ktile_pp(f32x16 (&acc)[4][2], const char* cur, c
     for (int kk = 0; kk < 4; ++kk) {
         if constexpr ((ABL & 4) == 0) load_frag<T>(f, cur + a_base, cur + b_base, xoff[kk]);
         if (has_next && (ABL & 1) == 0) {                    // ABL&1: ablation, no DMA inside the K loop (wrong results)
-            if (kk == 0) issue_dma<0, D0>(c, nxt, wave, voffA, voffW, soff_next);
-            if (kk == 1) issue_dma<D0, D1>(c, nxt, wave, voffA, voffW, soff_next);
-            if (kk == 2) issue_dma<D0 + D1, D2>(c, nxt, wave, voffA, voffW, soff_next);
-            if (kk == 3) issue_dma<D0 + D1 + D2, D3>(c, nxt, wave, voffA, voffW, soff_next);
+            constexpr int SKIP = (ABL & 8) ? 0x80 : ((ABL & 16) ? 0x88 : 0);
+            if (kk == 0) issue_dma<0, D0, SKIP>(c, nxt, wave, voffA, voffW, soff_next);
+            if (kk == 1) issue_dma<D0, D1, SKIP>(c, nxt, wave, voffA, voffW, soff_next);
+            if (kk == 2) issue_dma<D0 + D1, D2, SKIP>(c, nxt, wave, voffA, voffW, soff_next);
+            if (kk == 3) issue_dma<D0 + D1 + D2, D3, SKIP>(c, nxt, wave, voffA, voffW, soff_next);
         }
         if constexpr (XF == 1) {
             if (xf && kk == 2) fetch_xrows(xq[0], xc, 0);
@@ -676,6 +679,8 @@ int dispatch_pp(GemmArgs& g, int epi, int variant, int nblk, hipStream_t s) {
         case 41: return launch_pp_epi<T, 1, 4, 4, 0, 2>(g, epi, nblk, s);          // every DMA hits panel 0 (L2 resident)
         case 42: return launch_pp_epi<T, 1, 4, 4, 0, 4>(g, epi, nblk, s);          // no fragment ds_reads
         case 43: return launch_pp_epi<T, 1, 4, 4, 0, 5>(g, epi, nblk, s);          // MFMA + barriers only
+        case 44: return launch_pp_epi<T, 1, 4, 4, 0, 8>(g, epi, nblk, s);          // 7 of 8 operand DMAs (-12.5 % bytes)
+        case 45: return launch_pp_epi<T, 1, 4, 4, 0, 16>(g, epi, nblk, s);         // 6 of 8 operand DMAs (-25 % bytes)
         default: pg_set_error("gemm_pp: unknown variant %d", variant); return PG_EINVAL;
     }
 }
