@@ -43,6 +43,9 @@ constexpr int PP_SLAB_OFF = PP_STAGE;                      // epilogue slabs ove
 constexpr int PP_SLAB_ROWF = 64 + 4;                       // padded slab row, floats
 constexpr int PP_SLAB_BYTES = 32 * PP_SLAB_ROWF * 4;       // 8704 B per wave
 constexpr int PP_LDS = 160 * 1024;
+#ifndef PP_DMA_AUX
+#define PP_DMA_AUX 0                                     // cache policy of the operand DMAs (bit 0 sc0, bit 1 nt, bit 4 sc1)
+#endif
 #ifndef PP_STORE_AUX
 #define PP_STORE_AUX 0                                   // cache policy of the epilogue stores (bit 0 sc0, bit 1 nt, bit 4 sc1)
 #endif
@@ -50,7 +53,7 @@ constexpr int PP_LDS = 160 * 1024;
 typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_uniform, int voff, int soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_wave_uniform, 16, voff, soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_wave_uniform, 16, voff, soff, 0, PP_DMA_AUX);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
