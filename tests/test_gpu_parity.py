@@ -469,3 +469,33 @@ def test_ln_fold_encoder_matches_reference(env, golden_dir, monkeypatch):
     assert env["orc"].rel_err(base, ref) < EMB_TOL
     assert env["orc"].rel_err(fold, base) < 5e-4
     assert not torch.equal(fold, base)                    # two different chains really ran
+
+
+# ------------------------------------------------------------------------------------------------ serving path
+def test_serve_predict_panorama(env, vit2, tmp_path):
+    """pigeon_amd.serve.predict_panorama (the handler behind POST /api/v1/predict): four PIL views -> GPU preprocessing ->
+    SuperGuessr(serving=True) tuple -> ProtoRefiner; equals the explicit chain and, up to the refinement, the oracle head."""
+    from PIL import Image
+    from pigeon_amd import serve
+    from pigeon_amd.clip_embedder import gpu_preprocess
+    from pigeon_amd.proto_refiner import ProtoRefiner
+    from pigeon_amd.super_guessr import SuperGuessr
+    sd, vit = vit2
+    C = 200
+    model = SuperGuessr(vit, panorama=True, serving=True, freeze_base=True, num_candidates=5, geocell_path=_geocells_csv(tmp_path, C))
+    W, b = env["syn"].make_head_weights(C, seed=3)
+    with torch.no_grad():
+        model.cell_layer.weight.copy_(W); model.cell_layer.bias.copy_(b)
+    model.to(DEV).eval()
+    rng = np.random.default_rng(5)
+    views = [Image.fromarray(rng.integers(0, 255, (400 + 16 * i, 640, 3), dtype=np.uint8)) for i in range(4)]
+    got = serve.predict_panorama(views, model)
+    px = gpu_preprocess(views).reshape(1, 12, 336, 336)
+    llh, topk, emb = model(pixel_values=px)
+    assert got == {"lat": float(llh[0, 1]), "lng": float(llh[0, 0])}
+    ref = env["orc"].super_guessr_forward(W, b, model.lla_geocells.data.cpu(), 5, embedding=emb.cpu())
+    assert torch.equal(topk.indices.cpu(), ref["topk"].indices)
+    refiner = ProtoRefiner(topk=5, bank=env["syn"].make_bank(C, 20, seed=4, empty_frac=0.05)).eval()
+    got_r = serve.predict_panorama(views, model, refiner)
+    _, want, _ = refiner(embedding=emb, initial_preds=llh, candidate_cells=topk.indices, candidate_probs=topk.values)
+    assert got_r == {"lat": float(want[0, 1]), "lng": float(want[0, 0])}
