@@ -471,6 +471,10 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
     if (epi == EPI_PATCH && !aux) { pg_set_error("gemm: patch epilogue needs aux"); return PG_EINVAL; }
     if ((lda % 8) || (ldc % 8) || (qcols % 8) || (g.ldw % 8) || g.ldw < K) { pg_set_error("gemm: lda/ldw/ldc/qcols must be multiples of 8, ldw >= K"); return PG_EINVAL; }
     if (variant == 0) variant = pg_default_gemm_variant();
+    if (variant == 56) {                                     // 384 x 256 tiles where they exist, the product kernel elsewhere
+        if (pg_gemm_pp6_supported(epi, N, K)) return pg_gemm_pp6_launch(dtype, g, epi, s);
+        variant = 36;
+    }
     if (variant >= 30 && variant < 50) {
         // the persistent kernel needs N % 256 == 0 and an even number of K tiles; everything the model launches qualifies
         if (N % 256 == 0 && K % 128 == 0) return pg_gemm_pp_launch(dtype, g, epi, variant, s);

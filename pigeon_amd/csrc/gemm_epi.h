@@ -23,6 +23,9 @@ struct GemmArgs {
 
 // gemm_pp.hip: persistent ping-pong kernel (variants 30..39); tilesM/tilesN/ntiles are filled in by the callee
 int pg_gemm_pp_launch(int dtype, GemmArgs g, int epi, int variant, hipStream_t s);
+// gemm_pp6.hip: the same kernel with a 384 x 256 block tile, 16-bit-output epilogues only (variant 56, experimental)
+bool pg_gemm_pp6_supported(int epi, int N, int K);
+int pg_gemm_pp6_launch(int dtype, GemmArgs g, int epi, hipStream_t s);
 
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_base_uniform) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,

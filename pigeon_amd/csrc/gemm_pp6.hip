@@ -1,0 +1,392 @@
+// gemm_pp6.hip -- the persistent ping-pong GEMM of gemm_pp.hip with a 384 x 256 block tile (EXPERIMENTAL, variant 56).
+//
+// Why: every kernel of the path runs at the 1400 W package power cap and the operand DMA (global -> LDS) is the largest
+// energy item of the GEMMs (no DMA -> 1.45x; 7 of 8 DMAs -> -3...-9 % time).  The bytes DMA'd per
+// output are (BM + BN) / (BM * BN): 1/128 for 256 x 256, 1/153.6 for 384 x 256 -- the weight panel is fetched once per 384
+// instead of once per 256 rows (-33 % weight bytes, activation bytes unchanged).  The register file bounds the tile: 8 waves
+// x 64 lanes x 192 accumulator registers = 98 304 outputs is all that fits next to the fragments.
+//
+// Same structure as gemm_pp.hip (read its header first): one 512-thread block per CU walking tiles L0, L0+G, ...; waves
+// 2 (M) x 4 (N), wave tile 192 x 64 = 6 x 2 MFMA blocks of 32 x 32; two wave groups one barrier apart, a k-step is
+// {LOAD: 8 ds_read_b128 + share of the next K tile's DMA; barrier; MFMA: 12 MFMAs; barrier}; K tile 64, two 80 KB stages
+// = the whole 160 KB of LDS (A rows [0,384) then W rows [384,640), 128-byte rows, chunk c of row r at c ^ ((r>>1)&7));
+// the epilogue's per-wave transpose slabs (8 x 8.5 KB) overlay stage 1, which is free once every wave has left the
+// mainloop (K/64 even).  A wave issues 6 + 4 DMAs per K tile; the lane's offset inside a 64-row DMA group does not depend
+// on the group (the swizzle term only sees (row>>1)&7), so ONE VGPR offset per operand is kept and the group / K advance
+// is added per DMA -- there are no registers to spare: 192 accumulators + 32 fragment registers + bias.
+// Only the 16-bit-output epilogues (EPI_QKV, EPI_GELU and their LayerNorm-fold forms) exist here: QKV and fc1 are where the weight bytes are (N = 3072 /
+// 4096, K = 1024).  Same MFMA order over K as every other GEMM kernel of the library: results are bit-identical.
+#include "gemm_epi.h"
+
+namespace {
+
+constexpr int P6_TM = 6;                                   // 32-row MFMA blocks per wave along M
+constexpr int P6_BM = 2 * P6_TM * 32, P6_BN = 256;         // 384 x 256
+constexpr int P6_STAGE = (P6_BM + P6_BN) * ROWB;           // 80 KB
+constexpr int P6_W_OFF = P6_BM * ROWB;
+constexpr int P6_SLAB_OFF = P6_STAGE;                      // slabs overlay stage 1
+constexpr int P6_SLAB_ROWF = 64 + 4;
+constexpr int P6_SLAB_BYTES = 32 * P6_SLAB_ROWF * 4;       // 8704 B per wave, 8 waves = 68 KB <= 80 KB
+constexpr int P6_LDS = 2 * P6_STAGE;                       // 160 KB
+constexpr int P6_NDMA = P6_TM + 4;                         // DMAs per wave per K tile (6 A + 4 W)
+static_assert(8 * P6_SLAB_BYTES <= P6_STAGE, "slabs must fit into stage 1");
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_uniform, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_wave_uniform, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void wait_lgkm0() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void wait_vm0() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void raw_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void wave_lds_fence() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct Tile6 {
+    __amdgpu_buffer_rsrc_t ra, rw;
+    int m0, n0;
+    int sa, sw;                                              // bytes between two 64-row DMA groups of A / W
+};
+
+// same band / super-tile order as gemm_pp.hip make_tile (8 x 4 super-tiles per XCD round), in 384-row panels
+__device__ __forceinline__ Tile6 make_tile6(const GemmArgs& g, int L) {
+    Tile6 c;
+    const int gmax = g.gn >= 32 ? 1 : 32 / g.gn;
+    const int band_sz = gmax * g.tilesN;
+    const int band = L / band_sz, rem = L - band * band_sz;
+    const int gm = min(gmax, g.tilesM - band * gmax);
+    const int sup = rem / (gm * g.gn), rem2 = rem - sup * gm * g.gn;
+    const int im = rem2 / g.gn, in = rem2 - im * g.gn;
+    const int tm = band * gmax + im, tn = sup * g.gn + in;
+    c.m0 = tm * P6_BM; c.n0 = tn * P6_BN;
+    const int rows = min(P6_BM, g.M - c.m0);
+    c.ra = make_rsrc(g.A + (int64_t)c.m0 * g.lda, (uint32_t)rows * (uint32_t)g.lda * 2u);
+    c.rw = make_rsrc(g.W + (int64_t)c.n0 * g.ldw, (uint32_t)P6_BN * (uint32_t)g.ldw * 2u);
+    c.sa = 64 * (int)g.lda * 2; c.sw = 64 * (int)g.ldw * 2;
+    return c;
+}
+
+// DMA d of a K tile: d 0..5 = this wave's six 8-row groups of A (rows (wave + 8 d) * 8 ..), d 6..9 = its four of W
+template <int FROM, int CNT>
+__device__ __forceinline__ void issue_dma6(const Tile6& c, char* stage, int wave, int voffA, int voffW, int soff) {
+    // opaque: with a constant K offset (the peeled first K-tile pair, the next-tile prefetch) the ten per-lane offsets are
+    // invariant across the persistent tile loop and hipcc hoists -- and then spills -- thirty of them
+    asm volatile("" : "+s"(soff));
+#pragma unroll
+    for (int d = 0; d < P6_NDMA; ++d) {
+        if (d < FROM || d >= FROM + CNT) continue;
+        // group advance and K advance are added into the VGPR offset (one v_add with an SGPR operand per DMA): the SGPR
+        // soffset is NOT part of the descriptor's bounds check, and the M tail relies on that check (rows past M read 0)
+        if (d < P6_TM) dma16(c.ra, stage + (wave + 8 * d) * 8 * ROWB, voffA + (soff + d * c.sa), 0);
+        else dma16(c.rw, stage + P6_W_OFF + (wave + 8 * (d - P6_TM)) * 8 * ROWB, voffW + (soff + (d - P6_TM) * c.sw), 0);
+    }
+}
+
+template <typename T> struct Frag6 { typename T::v8 a[P6_TM], b[2]; };
+
+// Fragment reads as inline asm from ONE address register per operand: written as C++ loads, hipcc precomputes and keeps
+// live an address VGPR per (stage, k-step, operand) -- 16 registers this kernel does not have (it spilled 73).  The
+// k-step's chunk is an XOR on the address (disjoint bits, see ktile6), the 32-row blocks are immediates (<= 20 KB).
+template <int OFF, typename V>
+__device__ __forceinline__ void lds_read_b128(V& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <typename T>
+__device__ __forceinline__ void load_frag6(Frag6<T>& f, uint32_t aA, uint32_t aB) {
+    lds_read_b128<0 * 32 * ROWB>(f.a[0], aA); lds_read_b128<1 * 32 * ROWB>(f.a[1], aA); lds_read_b128<2 * 32 * ROWB>(f.a[2], aA);
+    lds_read_b128<3 * 32 * ROWB>(f.a[3], aA); lds_read_b128<4 * 32 * ROWB>(f.a[4], aA); lds_read_b128<5 * 32 * ROWB>(f.a[5], aA);
+    lds_read_b128<0>(f.b[0], aB); lds_read_b128<32 * ROWB>(f.b[1], aB);
+}
+
+template <typename T, bool ZERO>
+__device__ __forceinline__ void mma12(f32x16 (&acc)[P6_TM][2], const Frag6<T>& f) {
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < P6_TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma(f.b[j], f.a[i], ZERO ? zero16 : acc[i][j]);
+}
+
+// One K tile in ping-pong form; the wave's 10 DMAs of the next K tile go 5 / 5 in the first two LOAD phases.
+// baseA / baseB: LDS byte addresses of this lane's fragment row in STAGE 0 at k-step 0 (chunk (lhalf ^ sw) << 4); k-step kk
+// reads chunk (2 kk + lhalf) ^ sw = chunk0 ^ (kk << 1), i.e. address ^ (kk << 5) (disjoint bits).  The per-k-step
+// addresses are formed by asm (one v_add / v_xor each) so that they are NOT hoisted into 16 live registers.
+template <typename T, bool ZERO, int STAGE>
+__device__ __forceinline__ void ktile6(f32x16 (&acc)[P6_TM][2], char* smem, uint32_t baseA, uint32_t baseB, const Tile6& c,
+                                       int wave, int voffA, int voffW, int soff_next, bool has_next) {
+    char* nxt = smem + (STAGE ? 0 : P6_STAGE);
+    Frag6<T> f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        uint32_t aA, aB;
+        asm volatile("v_add_u32 %0, %2, %1\n\tv_xor_b32 %0, %3, %0" : "=&v"(aA) : "v"(baseA), "n"(STAGE * P6_STAGE), "n"(kk << 5));
+        asm volatile("v_add_u32 %0, %2, %1\n\tv_xor_b32 %0, %3, %0" : "=&v"(aB) : "v"(baseB), "n"(STAGE * P6_STAGE), "n"(kk << 5));
+        load_frag6<T>(f, aA, aB);
+        if (has_next) {
+            if (kk == 0) issue_dma6<0, 5>(c, nxt, wave, voffA, voffW, soff_next);
+            if (kk == 1) issue_dma6<5, 5>(c, nxt, wave, voffA, voffW, soff_next);
+            if (kk == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        wait_lgkm0();
+        raw_barrier();
+        __builtin_amdgcn_s_setprio(1);
+        if (ZERO && kk == 0) mma12<T, true>(acc, f);
+        else mma12<T, false>(acc, f);
+        __builtin_amdgcn_s_setprio(0);
+        raw_barrier();
+    }
+}
+
+struct Bias6 { f32x4 lo, hi; };
+
+__device__ __forceinline__ void load_bias6(Bias6& b, const GemmArgs& g, int col) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    b.lo = z; b.hi = z;
+    if (g.bias) {
+        b.lo = *(const f32x4*)(g.bias + col);
+        b.hi = *(const f32x4*)(g.bias + col + 4);
+    }
+}
+__device__ __forceinline__ void pin_bias6(Bias6& b) { asm volatile("" : "+v"(b.lo), "+v"(b.hi)); }
+
+template <int EPI> constexpr bool ln6() { return EPI == EPI_QKV_LN || EPI == EPI_GELU_LN; }
+template <int EPI> constexpr bool qkv6() { return EPI == EPI_QKV || EPI == EPI_QKV_LN; }
+
+// LayerNorm-fold epilogues: (rstd, mean*rstd) of the lane's rows of one 32-row slab (rows rr + 8 it), eight registers;
+// the slab's pair is fetched while the previous slab is processed (there is no room for a whole tile's worth: 48 registers)
+struct RowStat6 { u32x2 v[4]; };
+__device__ __forceinline__ void load_rowstat6(RowStat6& rs, __amdgpu_buffer_rsrc_t rrs, int rr, int slab) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) rs.v[it] = __builtin_amdgcn_raw_buffer_load_b64(rrs, (rr + slab * 32 + it * 8) * 8, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rowstat_rsrc6(const GemmArgs& g, int row0) {
+    int rvs = g.M - row0; rvs = rvs < 0 ? 0 : (rvs > P6_TM * 32 ? P6_TM * 32 : rvs);
+    return make_rsrc((const char*)g.ex.rowstat + (int64_t)row0 * 8, (uint32_t)rvs * 8u);
+}
+
+// Epilogue of the 16-bit outputs: per wave six 32-row x 64-column fp32 slabs transposed through LDS (gemm_pp.hip
+// pp_epilogue, WIDE geometry: 8 lanes per row, 8 rows per store instruction, 4 instructions per slab).
+// LN: colsum (cs) and the row statistics of slab 0 (rs0) were fetched right after the last MFMA phase.
+template <typename T, int EPI, typename PREFETCH_DMA, typename PREFETCH_BIAS>
+__device__ __forceinline__ void epilogue6(f32x16 (&acc)[P6_TM][2], const GemmArgs& g, char* smem, int wave, int lane, int row0,
+                                          int col0, const Bias6& bias, const Bias6& cs, const RowStat6& rs0,
+                                          __amdgpu_buffer_rsrc_t rrs, PREFETCH_DMA&& prefetch_dma, PREFETCH_BIAS&& prefetch_bias) {
+    constexpr int ROWPF = P6_SLAB_ROWF;
+    constexpr bool LN = ln6<EPI>();
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    float* slab = (float*)(smem + P6_SLAB_OFF + wave * P6_SLAB_BYTES);
+    const int rr = lane >> 3, cc = (lane & 7) * 8;
+    const int col = col0 + cc;
+    const float qsc = (qkv6<EPI>() && col < g.qcols) ? g.qscale : 1.f;
+    int rv = g.M - row0; rv = rv < 0 ? 0 : (rv > P6_TM * 32 ? P6_TM * 32 : rv);
+    const uint32_t nbytes = rv > 0 ? (uint32_t)(((int64_t)(rv - 1) * g.ldc + 64) * 2) : 0u;
+    __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)g.out + ((int64_t)row0 * g.ldc + col0) * 2, nbytes);
+    const int voff = (rr * (int)g.ldc + cc) * 2;
+    int rstep = 8 * (int)g.ldc * 2;                          // bytes between two store iterations
+    int sstep = 32 * (int)g.ldc * 2;                         // bytes between two slabs
+    asm volatile("" : "+s"(rstep), "+s"(sstep));             // not hoisted into 24 SGPRs across the K loop
+    prefetch_dma();
+    RowStat6 rs[2];
+    rs[0] = rs0;
+#pragma unroll
+    for (int i = 0; i < P6_TM; ++i) {
+        if constexpr (LN) { if (i + 1 < P6_TM) load_rowstat6(rs[(i + 1) & 1], rrs, rr, i + 1); }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                *(f32x4*)(slab + lrow * ROWPF + j * 32 + q * 8 + 4 * lhalf) = v;
+            }
+        wave_lds_fence();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = it * 8 + rr;
+            f32x4 lo = *(const f32x4*)(slab + r * ROWPF + cc);
+            f32x4 hi = *(const f32x4*)(slab + r * ROWPF + cc + 4);
+            // row offset in the VGPR offset, not the SGPR soffset (hipcc pads no wait states after a >64-bit buffer store
+            // with a register soffset: gemm_pp.hip)
+            const int ooff = voff + (i * sstep + it * rstep);
+            if constexpr (LN) {
+                // rstd * acc - (mean * rstd) * colsum + (beta.W^T + b); each scalar through an asm move of its own (hipcc
+                // SLP-packs the fmas into v_pk_fma_f32 and drops the op_sel of the high half of the loaded pair: gemm_pp.hip)
+                float rstd, mrs;
+                asm("v_mov_b32 %0, %1" : "=v"(rstd) : "v"(rs[i & 1].v[it][0]));
+                asm("v_mov_b32 %0, %1" : "=v"(mrs) : "v"(rs[i & 1].v[it][1]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] = fmaf(lo[e], rstd, fmaf(-mrs, cs.lo[e], bias.lo[e]));
+                    hi[e] = fmaf(hi[e], rstd, fmaf(-mrs, cs.hi[e], bias.hi[e]));
+                }
+            } else {
+                lo += bias.lo; hi += bias.hi;
+            }
+            if constexpr (qkv6<EPI>()) {
+                if (col0 < g.qcols) { lo *= qsc; hi *= qsc; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { lo[e] = quick_gelu(lo[e]); hi[e] = quick_gelu(hi[e]); }
+            }
+            u32x4 pk;
+            pk[0] = pack16x2<T>(lo[0], lo[1]); pk[1] = pack16x2<T>(lo[2], lo[3]);
+            pk[2] = pack16x2<T>(hi[0], hi[1]); pk[3] = pack16x2<T>(hi[2], hi[3]);
+            __builtin_amdgcn_raw_buffer_store_b128(pk, ro, ooff, 0, 0);
+        }
+        wave_lds_fence();                                    // slab reads retired before the next slab overwrites it
+        if (i == 0) prefetch_bias();                         // next tile's bias (/ nothing else): 32 registers are free now
+    }
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool follower = (wm == 1);
+
+    // per-lane DMA offset inside a 64-row group (bytes): row (wave * 8 + lane / 8) of the group, swizzled chunk
+    const int r0 = wave * 8 + (lane >> 3);
+    const int ch = (lane & 7) ^ ((r0 >> 1) & 7);
+    const int voffA = r0 * (int)g.lda * 2 + ch * 16;
+    const int voffW = r0 * (int)g.ldw * 2 + ch * 16;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int xo0 = (lhalf ^ ((lane >> 1) & 7)) << 4;
+    const uint32_t smem0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t baseA = smem0 + (wm * (P6_TM * 32) + lrow) * ROWB + xo0;
+    const uint32_t baseB = smem0 + P6_W_OFF + (wn * 64 + lrow) * ROWB + xo0;
+    const int ecc = (lane & 7) * 8;
+
+    const int nt = g.K / BK;                                 // even, >= 4 (checked on the host)
+    const int nblk = gridDim.x;
+    int L = xcd_remap(blockIdx.x, nblk);
+    if (L >= g.ntiles) return;
+    Tile6 c = make_tile6(g, L);
+    issue_dma6<0, P6_NDMA>(c, smem, wave, voffA, voffW, 0);  // K tile 0 of the first output tile -> stage 0
+    Bias6 bias;
+    load_bias6(bias, g, c.n0 + wn * 64 + ecc);
+    pin_bias6(bias);
+    // at the top of the next tile vmcnt(NST) must mean "the prefetched K tile 0 has landed": the DMAs are the oldest
+    // operations of an epilogue, at least 5 x 4 stores (+ the bias / row-statistics loads) are younger than all of them
+    constexpr int NST = (P6_TM - 1) * 4;
+    bool first = true;
+
+    while (true) {
+        f32x16 acc[P6_TM][2];                                // not cleared: the first k-step of the tile runs with C = 0
+        if (first) {
+            wait_vm0();
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wait_lgkm0();
+        raw_barrier();                                       // B_0: K tile 0 visible, previous epilogue's slabs released
+        if (follower) raw_barrier();
+        ktile6<T, true, 0>(acc, smem, baseA, baseB, c, wave, voffA, voffW, ROWB, true);
+        ktile6<T, false, 1>(acc, smem, baseA, baseB, c, wave, voffA, voffW, 2 * ROWB, true);
+        for (int t = 2; t < nt; t += 2) {
+            ktile6<T, false, 0>(acc, smem, baseA, baseB, c, wave, voffA, voffW, (t + 1) * ROWB, true);
+            ktile6<T, false, 1>(acc, smem, baseA, baseB, c, wave, voffA, voffW, (t + 2) * ROWB, t + 2 < nt);
+        }
+        // LN epilogues: colsum of the lane's 8 columns and the row statistics of slab 0, fetched as soon as the 32 fragment
+        // registers are dead (after the last MFMA phase); they land under the re-align barrier, the prefetch and slab 0's parking
+        const int row0 = c.m0 + wm * (P6_TM * 32), col0 = c.n0 + wn * 64;
+        Bias6 cs;
+        RowStat6 rs0;
+        __amdgpu_buffer_rsrc_t rrs = c.ra;                   // placeholder for the plain epilogues (never dereferenced)
+        if constexpr (ln6<EPI>()) {
+            cs.lo = *(const f32x4*)(g.ex.colsum + col0 + ecc);
+            cs.hi = *(const f32x4*)(g.ex.colsum + col0 + ecc + 4);
+            rrs = rowstat_rsrc6(g, row0);
+            load_rowstat6(rs0, rrs, lane >> 3, 0);
+        }
+        if (!follower) raw_barrier();                        // re-align: every wave has left the mainloop
+
+        L += nblk;
+        const bool more = L < g.ntiles;
+        Bias6 bias_next = bias;
+        // unconditional on purpose (see gemm_pp.hip: a VMEM block under `if (more)` breaks the compiler's in-order vmcnt count)
+        auto prefetch_dma = [&]() {
+            c = make_tile6(g, more ? L : L - nblk);
+            issue_dma6<0, P6_NDMA>(c, smem, wave, voffA, voffW, 0);
+        };
+        auto prefetch_bias = [&]() { load_bias6(bias_next, g, c.n0 + wn * 64 + ecc); };
+        epilogue6<T, EPI>(acc, g, smem, wave, lane, row0, col0, bias, cs, rs0, rrs, prefetch_dma, prefetch_bias);
+        if (!more) break;
+        pin_bias6(bias_next);
+        bias = bias_next;
+        first = false;
+    }
+}
+
+template <typename T, int EPI>
+int launch_pp6(const GemmArgs& g, int nblk, hipStream_t s) {
+    static bool attr_set = false;
+    auto kfn = gemm_pp6_kernel<T, EPI>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P6_LDS);
+        if (e != hipSuccess) { pg_set_error("gemm_pp6: set LDS attr: %s", hipGetErrorString(e)); return PG_EHIP; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(nblk), dim3(512), P6_LDS, s, g);
+    return pg_check_launch("gemm_pp6");
+}
+
+int cus6() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    }
+    return n > 0 ? n : 256;
+}
+
+}  // namespace
+
+// true if this (epilogue, shape) has a 384 x 256 kernel
+bool pg_gemm_pp6_supported(int epi, int N, int K) {
+    return (epi == EPI_QKV || epi == EPI_GELU || epi == EPI_QKV_LN || epi == EPI_GELU_LN) && N % P6_BN == 0 && K % (2 * BK) == 0 && K >= 4 * BK;
+}
+
+int pg_gemm_pp6_launch(int dtype, GemmArgs g, int epi, hipStream_t s) {
+    if (!pg_gemm_pp6_supported(epi, g.N, g.K)) { pg_set_error("gemm_pp6: unsupported epilogue / shape (epi=%d N=%d K=%d)", epi, g.N, g.K); return PG_EINVAL; }
+    if ((int64_t)g.lda * 2 * P6_BM >= (1ll << 31) || (int64_t)g.ldw * 2 * P6_BN >= (1ll << 31)) {
+        pg_set_error("gemm_pp6: operand panel exceeds the 2 GB buffer-descriptor range");
+        return PG_EINVAL;
+    }
+    g.tilesM = (g.M + P6_BM - 1) / P6_BM;
+    g.tilesN = g.N / P6_BN;
+    g.ntiles = g.tilesM * g.tilesN;
+    g.gn = (g.tilesN % 4 == 0) ? 4 : g.tilesN;               // 8 x 4 super-tiles per XCD round (gemm_pp.hip variant 36)
+    const int nblk = g.ntiles < cus6() ? g.ntiles : cus6();
+    if ((epi == EPI_QKV_LN || epi == EPI_GELU_LN) && (!g.ex.colsum || !g.ex.rowstat)) { pg_set_error("gemm_pp6: LN epilogue needs colsum / rowstat"); return PG_EINVAL; }
+#define P6_DISPATCH(TT)                                                          \
+    switch (epi) {                                                               \
+        case EPI_QKV: return launch_pp6<TT, EPI_QKV>(g, nblk, s);                \
+        case EPI_GELU: return launch_pp6<TT, EPI_GELU>(g, nblk, s);              \
+        case EPI_QKV_LN: return launch_pp6<TT, EPI_QKV_LN>(g, nblk, s);          \
+        default: return launch_pp6<TT, EPI_GELU_LN>(g, nblk, s);                 \
+    }
+    if (dtype == PG_DTYPE_F16) { P6_DISPATCH(T_F16) }
+    if (dtype == PG_DTYPE_BF16) { P6_DISPATCH(T_BF16) }
+#undef P6_DISPATCH
+    pg_set_error("gemm_pp6: operand dtype must be PG_DTYPE_F16 or PG_DTYPE_BF16 (got %d)", dtype);
+    return PG_EINVAL;
+}

@@ -40,8 +40,10 @@ int pg_default_gemm_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("PIGEON_GEMM_VARIANT");
-        v = e ? atoi(e) : 36;                                // persistent ping-pong kernel, 8x4 super-tile raster (gemm_pp.hip)
-        if (v <= 0) v = 36;
+        // 56: persistent ping-pong kernel with 384 x 256 tiles for the QKV / fc1 GEMMs (gemm_pp6.hip), 256 x 256 (variant 36:
+        // 8x4 super-tile raster, gemm_pp.hip) for everything else
+        v = e ? atoi(e) : 56;
+        if (v <= 0) v = 56;
     }
     return v;
 }

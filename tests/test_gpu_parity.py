@@ -53,7 +53,7 @@ def _geocells_csv(tmp_path, C, seed=0):
 
 # ------------------------------------------------------------------------------------------------ kernels
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("variant,K", [(0, 384), (1, 320), (5, 320), (8, 320), (33, 384), (36, 640), (30, 384)])
+@pytest.mark.parametrize("variant,K", [(0, 384), (1, 320), (5, 320), (8, 320), (33, 384), (36, 640), (30, 384), (56, 640)])
 def test_gemm_epilogues(env, dt, variant, K):
     ops, L = env["ops"], env["lib"]
     g = torch.Generator().manual_seed(3)
@@ -95,7 +95,7 @@ def test_gemm_persistent_many_tiles_bit_identical(env):
     X0 = torch.randn((M, N), generator=g).to(DEV)
     for epi in (L.EPI_QKV, L.EPI_GELU, L.EPI_RESID, L.EPI_F32):
         outs = []
-        for var in (8, 33, 36):
+        for var in (8, 33, 36, 56):                     # 56: 384 x 256 tiles for the 16-bit epilogues (47 row panels here)
             if epi in (L.EPI_QKV, L.EPI_GELU):
                 o = torch.full((M + 3, N), 7.0, dtype=torch.float16, device=DEV)
             elif epi == L.EPI_RESID:

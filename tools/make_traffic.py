@@ -19,8 +19,8 @@ def collect(sub, counter):
 
 fetch, write = collect("pmc_fetch", "FETCH_SIZE"), collect("pmc_write", "WRITE_SIZE")
 # kernel-name patterns per class: the LayerNorm-folded chain (default) uses epilogues 6 / 7 / 5, the separate-LayerNorm chain 0 / 1 / 2
-CLASSES = {"gemm_qkv": (("gemm_pp_kernel<T_F16, 6,", "gemm_pp_kernel<T_F16, 0,"), 2 * 1024 + 2 * 3072),
-           "gemm_fc1": (("gemm_pp_kernel<T_F16, 7,", "gemm_pp_kernel<T_F16, 1,"), 2 * 1024 + 2 * 4096),
+CLASSES = {"gemm_qkv": (("gemm_pp6_kernel<T_F16, 6>", "gemm_pp6_kernel<T_F16, 0>", "gemm_pp_kernel<T_F16, 6,", "gemm_pp_kernel<T_F16, 0,"), 2 * 1024 + 2 * 3072),
+           "gemm_fc1": (("gemm_pp6_kernel<T_F16, 7>", "gemm_pp6_kernel<T_F16, 1>", "gemm_pp_kernel<T_F16, 7,", "gemm_pp_kernel<T_F16, 1,"), 2 * 1024 + 2 * 4096),
            "gemm_out_fc2_mixed": (("gemm_pp_kernel<T_F16, 5,", "gemm_pp_kernel<T_F16, 2,"), None),
            "attention": (("attention",), 2 * 3072 + 2 * 1024),
            "layernorm": (("layernorm_kernel",), 4 * 1024 + 2 * 1024)}
