@@ -1,6 +1,6 @@
 """Bit-compare GEMM variants against variant 8 (the one-tile-per-block kernel) and time them on the model's shapes.
 
-   python tools/gemm_pp_check.py --variants 30,31,32 [--time] [--images 256]
+   python tools/gemm_pp_check.py --variants 56,36,30 [--time] [--images 512]
 
 Every variant runs in its own subprocess under a timeout (a wrong barrier count would hang the GPU), the parent only
 collects the printed lines.  The accumulation order of every output element is identical across variants (same MFMA
@@ -87,7 +87,7 @@ def child(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="31")
+    ap.add_argument("--variants", default="56,36")
     ap.add_argument("--child", type=int, default=-1)
     ap.add_argument("--time", action="store_true")
     ap.add_argument("--skip-check", action="store_true")
