@@ -91,3 +91,18 @@ def test_game_log(client):
     c, _, log = client
     r = c.post("/api/v1/game", json={"gameID": "abc", "roundID": 2, "game": {"score": 4999}})
     assert r.status_code == 200 and log == [{"gameID": "abc", "roundID": 2, "game": {"score": 4999}}]
+
+
+def test_decode_variants():
+    uri = _data_uri(11)
+    a = serve.decode_data_uri(uri)
+    b = serve.decode_data_uri(uri.split(",", 1)[1])               # bare base64 without the data: prefix
+    assert a.mode == "RGB" and a.size == (80, 60) and list(a.getdata()) == list(b.getdata())
+    rgba = Image.new("RGBA", (10, 8), (10, 20, 30, 128))
+    buf = io.BytesIO(); rgba.save(buf, format="PNG")
+    c = serve.decode_data_uri("data:image/png;base64," + base64.b64encode(buf.getvalue()).decode())
+    assert c.mode == "RGB" and c.getpixel((0, 0)) == (10, 20, 30)  # alpha dropped, as PIL's convert('RGB') does
+    with pytest.raises(serve.BadRequest):
+        serve.decode_data_uri("")
+    with pytest.raises(serve.BadRequest):
+        serve.decode_data_uri(None)
