@@ -101,6 +101,13 @@ int pg_vit_profile_enable(pg_vit* h, int on);
 int pg_vit_profile_read(pg_vit* h, int64_t* launches /*[PG_PROF_CLASSES]*/, double* ms /*[PG_PROF_CLASSES]*/);
 int pg_vit_profile_reset(pg_vit* h);
 
+/* fp16 saturation check (debug aid, off by default; costs one scan per 16-bit activation buffer per layer).  The
+ * encoder's fp32 -> fp16 conversions clamp at +-65504 instead of overflowing to inf; with the check enabled the forward
+ * pass counts, buffer by buffer, the 16-bit activations sitting exactly on that limit (bf16 operands: the +-inf).
+ * pg_vit_saturation_read returns the total since the last reset (synchronises the device); 0 = nothing was clamped. */
+int pg_vit_saturation_check(pg_vit* h, int on);
+int pg_vit_saturation_read(pg_vit* h, int64_t* count, int reset);
+
 /* ------------------------------------------------------------------------------------------------
  * SuperGuessr geocell head.
  * Replaces: models/super_guessr.py:437 (panel mean), :447 (cell_layer Linear), :448 (softmax), :454 (argmax),
@@ -122,7 +129,7 @@ int pg_head_forward(const float* emb, int B, int P, const float* W, const float*
  * ProtoRefiner prototype-distance refinement over a CSR prototype bank.
  * Replaces: models/proto_refiner.py:154-222 (the per-sample / per-candidate Python loop), :233-255
  * (within-cluster refinement: FARTHEST member), :332-344 (torch.cdist L2), :346-357 (temperature softmax
- * without max shift) and preprocessing/geo_utils.py:40-55 (haversine veto, float64).
+ * without max shift) and preprocessing/geo_utils.py:40-55 (haversine veto: float64, the refined fp32 point promoted after deg2rad / cos as torch does).
  * The bank arrays are BORROWED device pointers (caller keeps the tensors alive):
  *   proto_emb (P,1024) f32; cell_off (C+1) i64; proto_lnglat (P,2) f32; proto_count (P) i32;
  *   member_off (P+1) i64; member_idx (Nm) i64; train_emb (Ntr,1024) f32; train_lnglat (Ntr,2) f32.
@@ -174,6 +181,28 @@ int pg_prep_forward(pg_prep* h, const void* images_u8, int n_images, void* out, 
                     size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The one collective of the path: all-gather over RCCL (xGMI inside a node).
+ * Replaces: `accelerator.gather(index)` / `accelerator.gather(output)` at preprocessing/embed.py:36-37 (rank-major
+ * concatenation on every rank).  One process per GPU; rank 0 creates the PG_COMM_ID_BYTES-byte id and the host program
+ * ships it to the other ranks over its own bootstrap channel (a TCP store, MPI, a file ...); all ranks then call
+ * pg_comm_init_rank concurrently with the HIP device they own set current.  RCCL is bound at run time
+ * (dlopen "librccl.so.1"; env PIGEON_RCCL_LIB overrides), so a process that already carries an RCCL keeps a single copy.
+ *   send  DEVICE bytes_per_rank bytes; recv DEVICE nranks * bytes_per_rank bytes (rank r's block at r * bytes_per_rank);
+ *   asynchronous on `stream`, no host synchronisation. */
+#define PG_COMM_ID_BYTES 128
+int pg_comm_unique_id(void* id_out /*[PG_COMM_ID_BYTES]*/);
+int pg_comm_init_rank(void** comm, int nranks, const void* unique_id /*[PG_COMM_ID_BYTES]*/, int rank);
+int pg_comm_count(void* comm, int* nranks);          /* ranks as RCCL sees them */
+int pg_allgather(void* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+/* `count` buffers gathered in one RCCL group (one fused launch); buffer i: send[i] bytes_per_rank[i] bytes ->
+ * recv[i] nranks * bytes_per_rank[i] bytes, rank-major.  The data-parallel step gathers embeddings, candidate cells /
+ * probabilities, initial predictions and sample indices this way. */
+int pg_allgather_many(void* comm, int count, const void* const* send, void* const* recv, const size_t* bytes_per_rank,
+                      void* stream);
+int pg_comm_destroy(void* comm);
+int pg_comm_rccl_version(void);                       /* NCCL_VERSION_CODE of the bound library, < 0 on failure */
+
+/* ------------------------------------------------------------------------------------------------
  * Around the hot path.
  * ------------------------------------------------------------------------------------------------ */
 /* Prototype construction (reference models/proto_refiner.py:359-384): proto_emb[p] = fp32 mean, in member order, of
@@ -186,6 +215,10 @@ int pg_proto_build(const float* train_emb, int panels, int64_t num_train, const 
  * (PG_DTYPE_F32: deg2rad / cos(lat) in fp32 then promoted, torch's type promotion) or fp64; y DEVICE (M,2) fp64 (note:
  * row-major (M,2), i.e. lla_geocells itself, where the reference passes its transpose); out DEVICE (N,M) fp64 km. */
 int pg_haversine_matrix(const void* x, int x_dtype, const double* y, int N, int M, double* out, void* stream);
+/* Row-paired great-circle distance (reference preprocessing/geo_utils.py:40-55 `haversine(x, y)`): x DEVICE (N,2) fp64,
+ * y DEVICE (N,2) fp32 or fp64 (fp32: deg2rad / cos(lat) of y in fp32, then promoted -- the dtypes of the refiner's veto
+ * call, models/proto_refiner.py:198-202); out DEVICE (N,) fp64 km. */
+int pg_haversine_pairs(const double* x, const void* y, int y_dtype, int64_t N, double* out, void* stream);
 /* Label smoothing (reference preprocessing/utils.py:7-19): out = exp(-(d - rowmin(d)) / constant), NaN/inf -> 0.
  * distances, out: DEVICE (N,M) fp64 (may alias). */
 int pg_smooth_labels(const double* distances, int N, int M, double constant, double* out, void* stream);

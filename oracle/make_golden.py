@@ -1,7 +1,7 @@
 """Generate tests/golden/*.npz by running the REAL reference (from /root/reference) on seeded synthetic
 inputs.  Authoring-container only (the GPU box has no /root/reference); the outputs are committed.
 
-    python oracle/make_golden.py [--only vit2|vit24|head|pipeline|refine]
+    python oracle/make_golden.py [--only vit2|vit24|vit24_trained|head|pipeline|pipeline24|refine|geo]
 
 Every fixture stores only small tensors (inputs are regenerated from their seeds by
 ``pigeon_amd.synthetic`` on both sides).  What runs for each fixture:
@@ -227,7 +227,179 @@ def main():
             _, llh, cell = ref(emb3, initial_preds=init, candidate_cells=cands, candidate_probs=None)
         save["noprobs3d_LLH"] = llh.numpy()
         save["noprobs3d_cell"] = cell.numpy()
+        # veto edge: initial predictions placed max_refinement +- a few metres away from the point the refiner proposes, so
+        # that the `distance > max_refinement` test (proto_refiner.py:198-205) is decided by the last digits of the
+        # haversine -- which the reference evaluates with the refined point in float32 (deg2rad, cos) and the rest in float64
+        ref = ns.ProtoRefiner(topk=5, max_refinement=10 ** 9, temperature=1.6, proto_path=proto_csv,
+                              dataset_path=ds_dir, protos=base.protos)
+        ref.eval()
+        with torch.no_grad():
+            _, prop, _ = ref(emb, initial_preds=init, candidate_cells=cands, candidate_probs=probs)   # no veto: proposals
+        rng = np.random.default_rng(123)
+        Rkm = 6378.137
+        deltas = np.tile(np.array([-0.004, -0.002, -0.001, -0.0003, 0.0003, 0.001, 0.002, 0.004]), B // 8 + 1)[:B]
+        p = prop.numpy().astype(np.float64)
+        lam1, phi1 = np.radians(p[:, 0]), np.radians(p[:, 1])
+        brg = rng.uniform(0, 2 * np.pi, B)
+        ang = (1000.0 + deltas) / Rkm
+        phi2 = np.arcsin(np.sin(phi1) * np.cos(ang) + np.cos(phi1) * np.sin(ang) * np.cos(brg))
+        lam2 = lam1 + np.arctan2(np.sin(brg) * np.sin(ang) * np.cos(phi1), np.cos(ang) - np.sin(phi1) * np.sin(phi2))
+        init_edge = np.stack([(np.degrees(lam2) + 540) % 360 - 180, np.degrees(phi2)], axis=1)
+        ref.max_refinement = 1000
+        with torch.no_grad():
+            _, llh, cell = ref(emb, initial_preds=torch.from_numpy(init_edge), candidate_cells=cands, candidate_probs=probs)
+        d_ref = ns.haversine(torch.from_numpy(init_edge), prop).numpy()
+        save["vetoedge_init"], save["vetoedge_LLH"], save["vetoedge_cell"] = init_edge, llh.numpy(), cell.numpy()
+        save["vetoedge_dist"] = d_ref
+        d64 = ns.haversine(torch.from_numpy(init_edge), prop.double()).numpy()
+        print("refine vetoedge: vetoed", int((d_ref > 1000).sum()), "of", B, "; decisions an all-float64 haversine would flip:",
+              int(((d_ref > 1000) != (d64 > 1000)).sum()), "max |mixed - f64| km", float(np.abs(d_ref - d64).max()))
         np.savez(os.path.join(GOLD, "refine.npz"), **save)
+
+    if want("geo"):
+        # the reference's own great-circle / smoothing / metric helpers on seeded inputs (pins oracle/geo_oracle.py and, through
+        # it or directly, pg_haversine_matrix / pg_haversine_pairs / pg_smooth_labels and evaluate.compute_geoguessr_metrics)
+        ns = reference_loader.load(geo_small_csv, proto_csv, ds_dir)
+        mt = reference_loader.load_metrics()
+        rng = np.random.default_rng(17)
+        N, M = 24, 300
+        x64 = np.stack([rng.uniform(-180, 180, N), rng.uniform(-90, 90, N)], axis=1)
+        y64 = np.stack([rng.uniform(-180, 180, M), rng.uniform(-90, 90, M)], axis=1)
+        x64[0] = y64[0]                                   # zero distance
+        x64[1] = [(y64[1, 0] + 360) % 360 - 180, -y64[1, 1]]                      # antipode of y[1]
+        x32 = x64.astype(np.float32)
+        save = dict(x=x64, y=y64)
+        tx64, tx32, ty = torch.from_numpy(x64), torch.from_numpy(x32), torch.from_numpy(y64)
+        save["matrix_f64"] = ns.haversine_matrix(tx64, ty.t()).numpy()           # (N,M) f64
+        save["matrix_f32x"] = ns.haversine_matrix(tx32, ty.t()).numpy()          # fp32 labels, f64 geocells -> f64
+        d = torch.from_numpy(save["matrix_f64"]).clone()
+        d[2, 5] = float("nan"); d[3, :] = float("inf"); d[4, 7] = float("inf")
+        save["smooth_in"] = d.numpy()
+        save["smooth_out"] = ns.preprocessing.smooth_labels(d).numpy()           # LABEL_SMOOTHING_CONSTANT = 65
+        save["smooth_constant"] = np.array(float(ns.config.LABEL_SMOOTHING_CONSTANT))
+        # paired form with the refiner's dtypes: x float64, y float32 (and float64)
+        yp64 = y64[:N]
+        save["pairs_f32y"] = ns.haversine(tx64, torch.from_numpy(yp64.astype(np.float32))).numpy()
+        save["pairs_f64y"] = ns.haversine(tx64, torch.from_numpy(yp64)).numpy()
+        # metrics on 500 synthetic predictions
+        n = 500
+        labels = np.stack([rng.uniform(-180, 180, n), rng.uniform(-90, 90, n)], axis=1)
+        scale = np.exp(rng.uniform(np.log(1e-3), np.log(60), n))[:, None]
+        preds = labels + rng.normal(0, 1, (n, 2)) * scale
+        preds[:, 1] = np.clip(preds[:, 1], -90, 90)
+        preds = preds.astype(np.float32)                  # what evaluate_model collects (refiner output is fp32)
+        cell_labels = rng.integers(0, 50, n)
+        top5 = np.stack([rng.permutation(50)[:5] for _ in range(n)])
+        cell_preds = top5[:, 0]
+        dist = mt.haversine_np(preds, labels)
+        m = {"Mean_km_error": np.mean(dist), "Median_km_error": np.median(dist),
+             "Geoguessr_score": mt.geoguessr_score(dist),
+             "Geocell_top5_accuracy": mt.topk_geocell_accuracy(cell_labels, top5)}
+        for km in (1, 5, 10, 25, 50, 100, 200, 750, 1000, 2500):
+            m[f"Under_{km}_km"] = mt.percentage_within_radius(dist, km)
+        save.update(metric_preds=preds, metric_labels=labels, metric_cell_labels=cell_labels, metric_top5=top5,
+                    metric_cell_preds=cell_preds, metric_distances=dist,
+                    metric_names=np.array(sorted(m)), metric_values=np.array([float(m[k]) for k in sorted(m)]))
+        np.savez(os.path.join(GOLD, "geo.npz"), **save)
+        print("geo", save["matrix_f64"].shape, {k: round(float(v), 4) for k, v in m.items()})
+
+    if want("vit24_trained"):
+        # trained-regime stress: massive-activation channels + rows with |mean|/std >= 5 (synthetic.make_vit_weights_trained_like)
+        ns = reference_loader.load(geo_small_csv, proto_csv, ds_dir)
+        sd = synthetic.make_vit_weights_trained_like(seed=21, layers=24)
+        vit = hf_vit(sd, 24)
+        emb_ref = reference_loader.make_reference_embedder(ns, vit)
+        px = synthetic.make_pixels(2, seed=314)
+        with torch.no_grad():
+            e = emb_ref(px)
+            hs = vit(pixel_values=px, output_hidden_states=True).hidden_states
+        # regime statistics of the residual stream the fixture really produces (layer 12 input), recorded for the test
+        h = hs[12][0]
+        ratio = (h.mean(dim=1).abs() / h.std(dim=1)).numpy()
+        np.savez(os.path.join(GOLD, "vit24_trained.npz"), embedding=e.numpy(), meta=np.array([21, 24, 1, 2, 314]),
+                 absmax_layer12=float(h.abs().max()), mean_over_std_median=float(np.median(ratio)),
+                 mean_over_std_min=float(ratio.min()))
+        print("vit24_trained", e.shape, float(e.abs().mean()), "absmax", float(h.abs().max()), "|mean|/std median",
+              float(np.median(ratio)), "min", float(ratio.min()))
+
+    if want("pipeline24"):
+        # END TO END at full size: the real reference, 24 layers (the bench weights, seed 0), C = 10 000 geocells, 32 panoramas of
+        # the seed-1234 pixel stream, num_candidates = 50; refinement at the class defaults (top-5, T 1.6, 1000 km) AND at
+        # evaluate()'s settings (topk 40 of 50, T 0.6, 100000 km; evaluation/evaluate.py:44,79-80).
+        C, NP = 10000, 32
+        geo = synthetic.make_geocells(C, seed=0)
+        geo_csv = os.path.join(tmp, "geocells10k.csv")
+        synthetic.write_geocell_csv(geo_csv, geo)
+        ns = reference_loader.load(geo_csv, proto_csv, ds_dir)
+        sd = synthetic.make_vit_weights(seed=0, layers=24)
+        vit = hf_vit(sd, 24)
+        model = ns.SuperGuessr(vit, panorama=True, hierarchical=False, multi_task=False, heading=False,
+                               freeze_base=True, num_candidates=50)
+        model.eval()
+        px = synthetic.make_pixels(4 * NP, seed=1234, panorama=True)          # (32,12,336,336)
+        lab, labc = torch.zeros(NP, 2, dtype=torch.float64), torch.zeros(NP, dtype=torch.long)
+        import time
+        t0 = time.time()
+        with torch.no_grad():
+            outs = [model(pixel_values=px[i:i + 4], labels=lab[i:i + 4], labels_clf=labc[i:i + 4]) for i in range(0, NP, 4)]
+        emb = torch.cat([o.embedding for o in outs])                         # (32,4,1024) reference embeddings
+        print(f"pipeline24: reference ViT pass {time.time() - t0:.0f} s")
+        # Head with realistic margins: a random-init ViT maps every image to nearly the same embedding (|e_i - mean| ~ 0.1 |e|),
+        # so an untrained head would send all panoramas to one cell.  Centre the head on the mean embedding (bias = b0 - W.center)
+        # and scale it so the logits spread with sigma = 4: distinct argmax cells, top-1 probabilities 0.05 .. 0.9, honest near-ties.
+        pe = emb.mean(dim=1)
+        center = pe.mean(dim=0)
+        radius = float((pe - center).norm(dim=1).mean())
+        W0, b0 = synthetic.make_head_weights(C, seed=0)
+        sig = float(((pe - center) @ W0.t()).std())
+        scale = float(2.0 ** np.round(np.log2(4.0 / sig)))
+        W = W0 * scale
+        bias = b0 - W @ center
+        with torch.no_grad():
+            model.cell_layer.weight.copy_(W)
+            model.cell_layer.bias.copy_(bias)
+            base, model.base_model = model.base_model, None                  # head pass on the reference's own embeddings
+            out = model(embedding=emb, labels=lab, labels_clf=labc)
+            model.base_model = base
+            # one panorama again from pixels with the final head: same numbers through the one-call path
+            chk = model(pixel_values=px[:2], labels=lab[:2], labels_clf=labc[:2])
+        assert torch.equal(chk.preds_geocell, out.preds_geocell[:2]) and torch.equal(chk.embedding, emb[:2])
+        logits = model.cell_layer(pe)
+        top2 = torch.topk(logits, 2, dim=-1).values
+        margin = (top2[:, 0] - top2[:, 1]).detach()
+        print("pipeline24 cells", out.preds_geocell.tolist())
+        print("pipeline24 top-1 prob", [round(float(v), 3) for v in out.top5_geocells.values[:, 0]])
+        print("pipeline24 logit margins", [round(float(v), 3) for v in margin], "scale", scale, "radius", radius)
+        # prototype bank around the embedding cloud (synthetic.make_bank center/radius), 10 000 cells x 4 prototypes
+        bank24 = synthetic.make_bank(C, 4, seed=2, empty_frac=0.01, max_members=3, center=center.numpy(), radius=radius)
+        proto24 = os.path.join(tmp, "protos24.csv")
+        ds24 = os.path.join(tmp, "hf_train24")
+        synthetic.write_bank_reference_files(bank24, proto24, ds24)
+        ref = ns.ProtoRefiner(topk=5, max_refinement=1000, temperature=1.6, proto_path=proto24, dataset_path=ds24,
+                              protos=[None] * C)
+        # the reference builds prototypes per geocell (`_get_prototypes`, proto_refiner.py:288-313); only candidate cells are
+        # ever consulted (:167), so only those are built here (10 000 Arrow round trips otherwise)
+        import datasets as _ds
+        _ds.disable_progress_bar()
+        needed = sorted(set(out.top5_geocells.indices.flatten().tolist()))
+        for c in needed:
+            ref.protos[c] = ref._get_prototypes(c)
+        save = dict(embedding=emb.numpy(), head_bias=bias.numpy(), center=center.numpy(),
+                    meta=np.array([0, 24, NP, 1234, C, 4, 2, 3]), head_scale=np.array(scale), radius=np.array(radius),
+                    preds_LLH=out.preds_LLH.numpy(), preds_geocell=out.preds_geocell.numpy(),
+                    topk_values=out.top5_geocells.values.numpy(), topk_indices=out.top5_geocells.indices.numpy(),
+                    logit_margin=margin.numpy())
+        for tag, (topk, T, mr) in dict(default=(5, 1.6, 1000), evaluate=(40, 0.6, 100000)).items():
+            ref.topk, ref.max_refinement = topk, mr
+            ref.temperature.data = torch.tensor(T)
+            ref.eval()
+            with torch.no_grad():
+                _, llh, cell = ref(out.embedding, initial_preds=out.preds_LLH, candidate_cells=out.top5_geocells.indices,
+                                   candidate_probs=out.top5_geocells.values)
+            save[f"{tag}_LLH"], save[f"{tag}_cell"] = llh.numpy(), cell.numpy()
+            save[f"{tag}_params"] = np.array([topk, T, mr], dtype=np.float64)
+            print("pipeline24 refine", tag, "changed", int((cell != out.preds_geocell).sum()), "of", NP)
+        np.savez(os.path.join(GOLD, "pipeline24.npz"), **save)
 
     print("golden fixtures written to", GOLD)
 

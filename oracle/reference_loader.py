@@ -137,6 +137,32 @@ def load(geocell_path: str, proto_path: str, dataset_path: str, device: str = "c
     return ns
 
 
+def load_metrics():
+    """The reference's metric helpers (evaluation/metrics.py:89-136: percentage_within_radius, geoguessr_score,
+    topk_geocell_accuracy) plus haversine_np, WITHOUT importing the module: its top level pulls in geopandas / sklearn /
+    config.TRAIN_ARGS.  The three functions are cut out of the source by name (ast) and exec'd next to numpy and
+    DECAY_CONSTANT (config.py:52) -- their bodies run unmodified."""
+    import ast
+    import numpy as np
+    if not available():
+        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
+    path = os.path.join(REFERENCE_ROOT, "evaluation", "metrics.py")
+    src = open(path).read()
+    tree = ast.parse(src)
+    want = ("percentage_within_radius", "geoguessr_score", "topk_geocell_accuracy")
+    with open(os.path.join(REFERENCE_ROOT, "config.py")) as f:
+        cfg = {}
+        exec(compile(f.read().split("# Training arguments")[0].replace("from transformers import TrainingArguments", ""),
+                     "config.py", "exec"), cfg)
+    env = {"np": np, "DECAY_CONSTANT": cfg["DECAY_CONSTANT"], "Dict": dict}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in want:
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), env)
+    geo = _load_file_as("_ref_geo_utils_tmp", os.path.join(REFERENCE_ROOT, "preprocessing", "geo_utils.py"))
+    sys.modules.pop("_ref_geo_utils_tmp", None)
+    return types.SimpleNamespace(haversine_np=geo.haversine_np, **{k: env[k] for k in want})
+
+
 def make_reference_embedder(ns, vit, device="cpu", panorama=False):
     """Instantiate the reference CLIPEmbedding around an existing HF CLIPVisionModel.
 

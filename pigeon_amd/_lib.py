@@ -49,6 +49,15 @@ SIGNATURES = {
     "pg_vit_profile_enable": (_I, [_P, _I]),
     "pg_vit_profile_read": (_I, [_P, C.POINTER(_I64), C.POINTER(_D)]),
     "pg_vit_profile_reset": (_I, [_P]),
+    "pg_vit_saturation_check": (_I, [_P, _I]),
+    "pg_vit_saturation_read": (_I, [_P, C.POINTER(_I64), _I]),
+    "pg_comm_unique_id": (_I, [_P]),
+    "pg_comm_init_rank": (_I, [C.POINTER(_P), _I, _P, _I]),
+    "pg_comm_count": (_I, [_P, C.POINTER(_I)]),
+    "pg_allgather": (_I, [_P, _P, _P, _SZ, _P]),
+    "pg_allgather_many": (_I, [_P, _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_SZ), _P]),
+    "pg_comm_destroy": (_I, [_P]),
+    "pg_comm_rccl_version": (_I, []),
     "pg_prep_create": (_I, [C.POINTER(_P), _I, _I, _I]),
     "pg_prep_destroy": (_I, [_P]),
     "pg_prep_geometry": (_I, [_P, C.POINTER(C.c_int32)]),
@@ -56,6 +65,7 @@ SIGNATURES = {
     "pg_prep_forward": (_I, [_P, _P, _I, _P, _I, _P, _SZ, _P]),
     "pg_proto_build": (_I, [_P, _I, _I64, _P, _P, _I64, _P, _P]),
     "pg_haversine_matrix": (_I, [_P, _I, _P, _I, _I, _P, _P]),
+    "pg_haversine_pairs": (_I, [_P, _P, _I, _I64, _P, _P]),
     "pg_smooth_labels": (_I, [_P, _I, _I, _D, _P, _P]),
     "pg_head_forward": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "pg_refine_forward": (_I, [C.POINTER(Bank), _P, _I, _I, _P, _P, _P, _I, _I, _F, _D, _P, _P, _P, _P, _P]),

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libpigeon_hip.so")
-SOURCES = ["vit.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_pp6.hip", "attention.hip", "rowops.hip", "preprocess.hip", "geo_proto.hip", "head.hip", "refine.hip"]
+SOURCES = ["vit.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_pp6.hip", "attention.hip", "rowops.hip", "preprocess.hip", "geo_proto.hip", "head.hip", "refine.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "pigeon_internal.h"), os.path.join(CSRC, "gemm_epi.h"),
            os.path.join(os.path.dirname(HERE), "include", "pigeon_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -34,7 +34,19 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
+    """dev=False: the product library libpigeon_hip.so -- production kernels only.
+    dev=True:  libpigeon_hip_dev.so, compiled with -DPIGEON_ABLATIONS: additionally the superseded kernel generations, A/B arms
+               and the timing-only ablation kernels (which compute WRONG results by construction) that tools/ selects through
+               PIGEON_GEMM_VARIANT / PIGEON_ATTN_VARIANT; load it with PIGEON_HIP_LIB=pigeon_amd/libpigeon_hip_dev.so."""
+    global OBJ, LIB
+    obj_dir = os.path.join(CSRC, "build_dev" if dev else "build")
+    lib = os.path.join(HERE, "libpigeon_hip_dev.so" if dev else "libpigeon_hip.so")
+    flags = FLAGS + (["-DPIGEON_ABLATIONS"] if dev else [])
+    return _build(obj_dir, lib, flags, force, verbose)
+
+
+def _build(OBJ: str, LIB: str, FLAGS, force: bool, verbose: bool) -> str:
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
     jobs = []
@@ -60,7 +72,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             list(ex.map(compile_one, jobs))
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print("[pigeon_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -70,4 +82,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, dev="--dev" in sys.argv))

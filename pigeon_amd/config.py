@@ -39,5 +39,6 @@ PROTO_MODEL_LANDMARKS_PATH = 'saved_models/refiner/proto_landmarks.refiner'
 OPENAI_CLIP_MEAN = [0.48145466, 0.4578275, 0.40821073]
 OPENAI_CLIP_STD = [0.26862954, 0.26130258, 0.27577711]
 
-# reference config.py:55
+# Geoguessr score decay (reference config.py:52) and haversine label smoothing (config.py:55)
+DECAY_CONSTANT = 1492.7
 LABEL_SMOOTHING_CONSTANT = 65  # (PIGEOTTO), 75 (PIGEON)

@@ -776,7 +776,9 @@ int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hip
     if (dtype != PG_DTYPE_F16 && dtype != PG_DTYPE_BF16) { pg_set_error("attention: dtype must be PG_DTYPE_F16 or PG_DTYPE_BF16"); return PG_EINVAL; }
     const int pairs = n_images * VIT_HEADS;                  // always a multiple of 8
     const dim3 grid(pairs * ATT_NQB);
-    switch (attention_variant()) {
+    const int variant = attention_variant();
+#ifdef PIGEON_ABLATIONS                                   // tools build only: older generations, A/B arms, timing-only ablations (6..9, 14, 15: WRONG RESULTS)
+    switch (variant) {
         case 1: return att_launch2(dtype, attention_kernel<T_F16>, attention_kernel<T_BF16>, grid, qkv, out, s);
         case 4: return att_launch2(dtype, attention4_kernel<T_F16, 3>, attention4_kernel<T_BF16, 3>, grid, qkv, out, s);
         case 5: return att_launch2(dtype, attention4_kernel<T_F16, 4>, attention4_kernel<T_BF16, 4>, grid, qkv, out, s);
@@ -789,6 +791,12 @@ int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hip
         case 14: return att_launch2(dtype, attention5_kernel<T_F16, 3, true, true, 1>, attention5_kernel<T_BF16, 3, true, true, 1>, grid, qkv, out, s);
         case 15: return att_launch2(dtype, attention5_kernel<T_F16, 3, true, true, 2>, attention5_kernel<T_BF16, 3, true, true, 2>, grid, qkv, out, s);
         case 13: return att_launch2(dtype, attention5_kernel<T_F16, 3, true, false>, attention5_kernel<T_BF16, 3, true, false>, grid, qkv, out, s);
-        default: return att_launch2(dtype, attention5_kernel<T_F16, 3>, attention5_kernel<T_BF16, 3>, grid, qkv, out, s);
+        default: break;
     }
+#endif
+    if (variant != 11) {
+        pg_set_error("attention: PIGEON_ATTN_VARIANT=%d is not part of this build (product: 11; others need -DPIGEON_ABLATIONS)", variant);
+        return PG_EINVAL;
+    }
+    return att_launch2(dtype, attention5_kernel<T_F16, 3>, attention5_kernel<T_BF16, 3>, grid, qkv, out, s);
 }

@@ -439,6 +439,11 @@ static int launch_a3w2(const GemmArgs& g0, int epi, hipStream_t s) {
 template <typename T>
 static int gemm_dispatch(GemmArgs& g, int epi, int variant, hipStream_t s) {
     switch (variant) {
+        // the product library carries ONE one-tile-per-block kernel (variant 8: the fallback for shapes the persistent kernel
+        // does not take, and the bit-exact reference the persistent kernels are tested against); the older tilings and the
+        // timing-only ablations (21..23: wrong results by construction) exist only in the -DPIGEON_ABLATIONS tools build
+        case 8: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true, 4>(g, epi, s);   // 256x256, N-fastest raster, interleaved DMA
+#ifdef PIGEON_ABLATIONS
         case 1: return launch_cfg<T, 256, 256, 2, 4, false, false>(g, epi, s);
         case 2: return launch_cfg<T, 128, 128, 2, 2, false, true>(g, epi, s);
         case 3: return launch_cfg<T, 256, 128, 4, 2, false, true>(g, epi, s);
@@ -447,12 +452,12 @@ static int gemm_dispatch(GemmArgs& g, int epi, int variant, hipStream_t s) {
         case 6: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true>(g, epi, s);   // variant 4, N-fastest raster
         case 7: g.gn = 1 << 20; return launch_a3w2<T>(g, epi, s);                                  // variant 5, N-fastest raster
         case 11: return launch_cfg<T, 256, 256, 2, 4, true, false>(g, epi, s);
-        // ablations of variant 6 (timing only, wrong results): 21 no in-loop DMA, 22 no ds_reads, 23 neither
-        case 8: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true, 4>(g, epi, s);   // variant 6 + interleaved DMA
-        case 21: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true, 1>(g, epi, s);
-        case 22: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true, 2>(g, epi, s);
-        case 23: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true, 3>(g, epi, s);
-        default: pg_set_error("gemm: unknown variant %d", variant); return PG_EINVAL;
+        case 21: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true, 1>(g, epi, s);   // no in-loop DMA
+        case 22: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true, 2>(g, epi, s);   // no ds_reads
+        case 23: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true, 3>(g, epi, s);   // neither
+#endif
+        default: pg_set_error("gemm: variant %d is not part of this build (product variants: 8, 33, 36, 56; the rest needs the "
+                              "-DPIGEON_ABLATIONS tools build, python -m pigeon_amd.build --dev)", variant); return PG_EINVAL;
     }
 }
 

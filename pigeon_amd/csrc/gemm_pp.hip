@@ -668,23 +668,25 @@ template <typename T>
 int dispatch_pp(GemmArgs& g, int epi, int variant, int nblk, hipStream_t s) {
     g.gn = g.tilesN;                                         // N-fastest raster unless the variant says otherwise
     switch (variant) {
+        case 33: return launch_pp_epi<T, 1, 4, 4, 0>(g, epi, nblk, s);    // ping-pong, DMA 4/4/0/0, N-fastest raster
+        case 36: if (g.tilesN % 4 == 0) g.gn = 4; return launch_pp_epi<T, 1, 4, 4, 0>(g, epi, nblk, s);   // 33 + 8x4 super-tile raster (product)
+#ifdef PIGEON_ABLATIONS                                                     // tools build only (python -m pigeon_amd.build --dev)
         case 30: return launch_pp_epi<T, 0, 2, 2, 2>(g, epi, nblk, s);    // persistent, free-running
         case 31: return launch_pp_epi<T, 1, 3, 3, 2>(g, epi, nblk, s);    // ping-pong, DMA 3/3/2/0
-        case 33: return launch_pp_epi<T, 1, 4, 4, 0>(g, epi, nblk, s);    // ping-pong, DMA 4/4/0/0
         case 34: return launch_pp_epi<T, 2, 4, 4, 0>(g, epi, nblk, s);    // phases without stagger
-        case 36: if (g.tilesN % 4 == 0) g.gn = 4; return launch_pp_epi<T, 1, 4, 4, 0>(g, epi, nblk, s);   // 33 + 8x4 super-tile raster
         case 37: if (g.tilesN % 4 == 0) g.gn = 4; return launch_pp_epi<T, 1, 3, 3, 2>(g, epi, nblk, s);   // 31 + 8x4 super-tile raster
         case 38: g.stagger = (g.K / BK) * 2600 + 6000; return launch_pp_epi<T, 1, 4, 4, 0>(g, epi, nblk, s);   // 33 + staggered start
         case 39: g.stagger = (g.K / BK) * 1300 + 3000; return launch_pp_epi<T, 1, 4, 4, 0>(g, epi, nblk, s);   // 33 + half-period stagger
         // (DMA schedules 8/0/0/0, 6/2/0/0, 5/3/0/0, 4/2/2/0 measured within +-3 % of 4/4/0/0 -- box-to-box noise -- and removed)
-        // ablations of 33 (timing only, wrong results)
+        // ablations of 33 (timing only, WRONG RESULTS by construction)
         case 40: return launch_pp_epi<T, 1, 4, 4, 0, 1>(g, epi, nblk, s);          // no DMA in the K loop
         case 41: return launch_pp_epi<T, 1, 4, 4, 0, 2>(g, epi, nblk, s);          // every DMA hits panel 0 (L2 resident)
         case 42: return launch_pp_epi<T, 1, 4, 4, 0, 4>(g, epi, nblk, s);          // no fragment ds_reads
         case 43: return launch_pp_epi<T, 1, 4, 4, 0, 5>(g, epi, nblk, s);          // MFMA + barriers only
         case 44: return launch_pp_epi<T, 1, 4, 4, 0, 8>(g, epi, nblk, s);          // 7 of 8 operand DMAs (-12.5 % bytes)
         case 45: return launch_pp_epi<T, 1, 4, 4, 0, 16>(g, epi, nblk, s);         // 6 of 8 operand DMAs (-25 % bytes)
-        default: pg_set_error("gemm_pp: unknown variant %d", variant); return PG_EINVAL;
+#endif
+        default: pg_set_error("gemm_pp: variant %d is not part of this build (product: 33, 36; others need -DPIGEON_ABLATIONS)", variant); return PG_EINVAL;
     }
 }
 

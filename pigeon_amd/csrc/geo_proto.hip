@@ -96,7 +96,7 @@ template <> struct Deg<double> {
 };
 template <> struct Deg<float> {
     static __device__ __forceinline__ float rad(float v) { return v * (float)DEG2RAD_D; }
-    static __device__ __forceinline__ float cosv(float r) { return cosf(r); }
+    static __device__ __forceinline__ float cosv(float r) { return (float)cos((double)r); }   // correctly rounded fp32 cos
 };
 
 template <typename X>
@@ -125,6 +125,33 @@ extern "C" int pg_haversine_matrix(const void* x, int x_dtype, const double* y, 
     else if (x_dtype == PG_DTYPE_F32) hipLaunchKernelGGL(haversine_matrix_kernel<float>, grid, dim3(256), 0, s, (const float*)x, y, out, N, M);
     else { pg_set_error("haversine_matrix: x dtype must be PG_DTYPE_F32 or PG_DTYPE_F64"); return PG_EINVAL; }
     return pg_check_launch("haversine_matrix");
+}
+
+// pairwise form, reference preprocessing/geo_utils.py:40-55 (`haversine(x, y)`, rows paired): x is float64 (initial
+// predictions / labels), y float32 or float64 -- the dtype rules of the refiner's veto call (models/proto_refiner.py:198-202).
+template <typename Y>
+__global__ __launch_bounds__(256) void haversine_pairs_kernel(const double* __restrict__ x, const Y* __restrict__ y,
+                                                              double* __restrict__ out, int64_t N) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const double xlng = x[2 * i] * DEG2RAD_D, xlat = x[2 * i + 1] * DEG2RAD_D;
+    const Y ylng = Deg<Y>::rad(y[2 * i]), ylat = Deg<Y>::rad(y[2 * i + 1]);
+    const double dlng = (double)ylng - xlng, dlat = (double)ylat - xlat;
+    const double s1 = sin(dlat / 2), s0 = sin(dlng / 2);
+    const double a = s1 * s1 + cos(xlat) * (double)Deg<Y>::cosv(ylat) * (s0 * s0);
+    const double c = 2 * asin(sqrt(a));
+    out[i] = (6378137.0 * c) / 1000;
+}
+
+extern "C" int pg_haversine_pairs(const double* x, const void* y, int y_dtype, int64_t N, double* out, void* stream) {
+    if (!x || !y || !out) { pg_set_error("haversine_pairs: null argument"); return PG_EINVAL; }
+    if (N <= 0) return PG_OK;
+    dim3 grid((unsigned)((N + 255) / 256));
+    hipStream_t s = (hipStream_t)stream;
+    if (y_dtype == PG_DTYPE_F64) hipLaunchKernelGGL(haversine_pairs_kernel<double>, grid, dim3(256), 0, s, x, (const double*)y, out, N);
+    else if (y_dtype == PG_DTYPE_F32) hipLaunchKernelGGL(haversine_pairs_kernel<float>, grid, dim3(256), 0, s, x, (const float*)y, out, N);
+    else { pg_set_error("haversine_pairs: y dtype must be PG_DTYPE_F32 or PG_DTYPE_F64"); return PG_EINVAL; }
+    return pg_check_launch("haversine_pairs");
 }
 
 // --------------------------------------------------------------------------------------------- label smoothing

@@ -72,7 +72,10 @@ __global__ __launch_bounds__(256) void head_logits_kernel(const float* __restric
 }
 
 struct ValIdx { float v; int i; };
-__device__ __forceinline__ bool better(float v, int i, float bv, int bi) {   // (value desc, index asc)
+// (value desc, index asc); a NaN ranks above every number (torch.argmax / torch.topk semantics), lowest index first
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) {
+    const bool vn = v != v, bn = bv != bv;
+    if (vn || bn) return vn && (!bn || i < bi);
     return (v > bv) || (v == bv && i < bi);
 }
 __device__ __forceinline__ ValIdx block_argbest(ValIdx x, ValIdx* red /*[4]*/) {
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(256) void head_row_kernel(const float* __restrict__
         }
         best = block_argbest(best, red);
         if (tid == 0) {
+            if (best.i < 0 || best.i >= C) best.i = r < C ? r : C - 1;   // unreachable (k <= C, NaN ranks first); never index out of range
             topk_val[(int64_t)b * k + r] = best.v;
             topk_idx[(int64_t)b * k + r] = best.i;
             if (r == 0) {

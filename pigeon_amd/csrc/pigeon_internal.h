@@ -46,5 +46,6 @@ int pg_token_mean_launch(const float* x, float* out, int n_images, hipStream_t s
 int pg_cast_f32_launch(const float* x, void* y, int out_dtype, int64_t n, hipStream_t s);
 int pg_rowstat_cast_launch(const float* x, void* x16, int out_dtype, float* rowstat, int64_t rows, float eps, hipStream_t s);
 int pg_rowstat_finalize_launch(const float* statpart, int slots, float* rowstat, int64_t rows, float eps, hipStream_t s);
+int pg_count_sat16_launch(const void* buf, int64_t rows, int cols, int64_t ld, int dtype, unsigned long long* counter, hipStream_t s);
 // attention.hip
 int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hipStream_t s);

@@ -1,5 +1,5 @@
 // refine.hip -- ProtoRefiner: brute-force L2 nearest-prototype search over a CSR prototype bank, the
-// within-cluster (FARTHEST member) step, the un-shifted temperature softmax and the float64 haversine veto.
+// within-cluster (FARTHEST member) step, the un-shifted temperature softmax and the haversine veto (float64 with the reference's fp32 promotion of the refined point).
 //
 // Replaces the reference's Python double loop models/proto_refiner.py:154-222 (one H2D copy + >=3 .item()
 // syncs per (sample, candidate)) with two launches and no host round trips:
@@ -13,8 +13,9 @@
 //       takes argmax of the POSITIVE distances: the farthest member).  Empty cell -> score
 //       -100000, prediction (0,0) -- :168-174.  This kernel is pure HBM streaming: 4096 B per row touched.
 //   refine_select_kernel  one lane per query: probs = exp(score/T)/sum (no max shift, :355-357), final =
-//       c_probs*probs (:192), argmax with torch semantics (first max, NaN counts as max), haversine veto in
-//       float64 (:198-205, geo_utils.py:40-55), final argmax (:219), outputs (:221-222).
+//       c_probs*probs (:192), argmax with torch semantics (first max, NaN counts as max), haversine veto with
+//       the reference's dtypes (:198-205, geo_utils.py:40-55: initial point float64, refined point float32 through
+//       deg2rad and cos, float64 after), final argmax (:219), outputs (:221-222).
 #include "common.h"
 #include "pigeon_internal.h"
 #include <cmath>
@@ -35,6 +36,14 @@ __device__ __forceinline__ float row_sqdist(const float* __restrict__ row, int l
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const float d = v[i][e] - q[i][e]; s = fmaf(d, d, s); }
     return wave_sum(s);
+}
+
+// "a beats b" for a (min value, lowest index) search in which NaN beats every number and the FIRST NaN wins: what
+// torch.max / torch.argmax over `-distance` do on the reference side (proto_refiner.py:180-181, :254).
+__device__ __forceinline__ bool nan_aware_less(float v, long long i, float bv, long long bi) {
+    const bool vn = v != v, bn = bv != bv;
+    if (vn || bn) return vn && (!bn || i < bi);
+    return v < bv || (v == bv && i < bi);
 }
 
 // scratch layout per (b, j): [score, lng, lat, unused]
@@ -75,10 +84,12 @@ __global__ __launch_bounds__(256) void refine_candidates_kernel(pg_bank bank, co
     }
 
     // ---- phase 1: nearest prototype of the cell (min distance, lowest index on ties) ----
+    // torch.max / torch.argmax treat NaN as the maximum (first NaN wins): a NaN distance "wins" here too, so a NaN query
+    // propagates NaN scores exactly like the reference instead of leaving the sentinel index behind
     float best = INFINITY; long long bi = 0x7fffffffffffffffLL;
     for (int64_t r = s + wave; r < e; r += 4) {
         const float d = sqrtf(row_sqdist(bank.proto_emb + r * RF_DIM, lane, qv));
-        if (d < best || (d == best && r < bi)) { best = d; bi = r; }
+        if (nan_aware_less(d, r, best, bi)) { best = d; bi = r; }
     }
     if (lane == 0) { red_d[wave] = best; red_i[wave] = bi; }
     __syncthreads();
@@ -87,13 +98,17 @@ __global__ __launch_bounds__(256) void refine_candidates_kernel(pg_bank bank, co
         for (int w = 1; w < 4; ++w) {
             const float d = red_d[w]; const long long x = red_i[w];
             if (x == 0x7fffffffffffffffLL) continue;
-            if (bx == 0x7fffffffffffffffLL || d < bd || (d == bd && x < bx)) { bd = d; bx = x; }
+            if (bx == 0x7fffffffffffffffLL || nan_aware_less(d, x, bd, bx)) { bd = d; bx = x; }
         }
         chosen = bx;
         outp[0] = -bd;                                      // score = max(-distance)
     }
     __syncthreads();
     const int64_t pid = chosen;
+    if (pid < s || pid >= e) {                              // cannot happen (e > s); guard the gathers below anyway
+        if (tid == 0) { outp[1] = 0.f; outp[2] = 0.f; outp[3] = 0.f; }
+        return;
+    }
     const int cnt = bank.proto_count[pid];
     if (cnt == 1) {                                         // proto_refiner.py:245-246
         if (tid == 0) { outp[1] = bank.proto_lnglat[2 * pid]; outp[2] = bank.proto_lnglat[2 * pid + 1]; outp[3] = 0.f; }
@@ -104,9 +119,10 @@ __global__ __launch_bounds__(256) void refine_candidates_kernel(pg_bank bank, co
     const int64_t ms = bank.member_off[pid], me = bank.member_off[pid + 1];
     float far = -INFINITY; long long fi = 0x7fffffffffffffffLL;
     for (int64_t r = ms + wave; r < me; r += 4) {
-        const int64_t tr = bank.member_idx[r];
+        int64_t tr = bank.member_idx[r];
+        tr = tr < 0 ? 0 : (tr >= bank.num_train ? bank.num_train - 1 : tr);      // never fault on a corrupt member list
         const float d = sqrtf(row_sqdist(bank.train_emb + tr * RF_DIM, lane, qv));
-        if (d > far || (d == far && r < fi)) { far = d; fi = r; }
+        if (nan_aware_less(-d, r, -far, fi)) { far = d; fi = r; }
     }
     __syncthreads();
     if (lane == 0) { red_d[wave] = far; red_i[wave] = fi; }
@@ -116,11 +132,12 @@ __global__ __launch_bounds__(256) void refine_candidates_kernel(pg_bank bank, co
         for (int w = 1; w < 4; ++w) {
             const float d = red_d[w]; const long long x = red_i[w];
             if (x == 0x7fffffffffffffffLL) continue;
-            if (bx == 0x7fffffffffffffffLL || d > bd || (d == bd && x < bx)) { bd = d; bx = x; }
+            if (bx == 0x7fffffffffffffffLL || nan_aware_less(-d, x, -bd, bx)) { bd = d; bx = x; }
         }
         float lng = 0.f, lat = 0.f;
         if (bx != 0x7fffffffffffffffLL) {
-            const int64_t tr = bank.member_idx[bx];
+            int64_t tr = bank.member_idx[bx];
+            tr = tr < 0 ? 0 : (tr >= bank.num_train ? bank.num_train - 1 : tr);
             lng = bank.train_lnglat[2 * tr]; lat = bank.train_lnglat[2 * tr + 1];
         }
         outp[1] = lng; outp[2] = lat; outp[3] = 0.f;
@@ -138,13 +155,20 @@ __device__ __forceinline__ int argmax_torch(const float* v, int n) {
     return bi;
 }
 
-__device__ __forceinline__ double haversine_km(double lng1, double lat1, double lng2, double lat2) {
-    // preprocessing/geo_utils.py:40-55; x = point 1, y = point 2
-    const double d2r = 3.14159265358979323846 / 180.0;     // torch.deg2rad multiplies by pi/180
-    const double x0 = lng1 * d2r, x1 = lat1 * d2r, y0 = lng2 * d2r, y1 = lat2 * d2r;
-    const double dl = y0 - x0, dp = y1 - x1;
+// The veto distance with the reference's dtype promotion.  models/proto_refiner.py:198-202 calls
+// haversine(initial_LLH, refined_LLH) (preprocessing/geo_utils.py:40-55) with x = the float64 initial prediction and
+// y = torch.tensor(top_preds[...]) = a FLOAT32 tensor: torch.deg2rad(y) and torch.cos(y_rad[:,1]) are evaluated in fp32
+// (deg2rad multiplies by pi/180 rounded to the tensor dtype), `y_rad - x_rad` and everything after promote to float64.
+// cos of the fp32 latitude is taken as the correctly rounded fp32 value (double cos, rounded once): torch's CPU kernel
+// (Sleef, <= 1 ulp) agrees with it except for rare last-bit cases, which no device libm could reproduce anyway.
+__device__ __forceinline__ double haversine_km(double lng1, double lat1, float lng2, float lat2) {
+    const double d2r = 0.017453292519943295769236907684886127134428718885417;   // M_PI / 180
+    const double x0 = lng1 * d2r, x1 = lat1 * d2r;
+    const float y0 = lng2 * (float)d2r, y1 = lat2 * (float)d2r;                  // fp32 deg2rad
+    const double dl = (double)y0 - x0, dp = (double)y1 - x1;
     const double sp = sin(dp / 2), sl = sin(dl / 2);
-    const double a = sp * sp + cos(x1) * cos(y1) * sl * sl;
+    const float cy = (float)cos((double)y1);                                      // fp32 cos(lat of the refined point)
+    const double a = sp * sp + cos(x1) * (double)cy * (sl * sl);
     const double c = 2 * asin(sqrt(a));
     return (6378137.0 * c) / 1000;
 }
@@ -171,7 +195,7 @@ __global__ __launch_bounds__(64) void refine_select_kernel(const float* __restri
     }
     const int refined = argmax_torch(fin, topk);
     const float rlng = sc[4 * refined + 1], rlat = sc[4 * refined + 2];
-    const double dist = haversine_km(init_llh[2 * b], init_llh[2 * b + 1], (double)rlng, (double)rlat);
+    const double dist = haversine_km(init_llh[2 * b], init_llh[2 * b + 1], rlng, rlat);
     int choice = refined;
     if (dist > max_km) choice = argmax_torch(cp, topk);    // veto: fall back to the geocell probabilities
     out_llh[2 * b] = sc[4 * choice + 1];

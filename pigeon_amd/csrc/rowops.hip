@@ -271,3 +271,37 @@ int pg_cast_f32_launch(const float* x, void* y, int out_dtype, int64_t n, hipStr
     else { pg_set_error("cast: bad output dtype %d", out_dtype); return PG_EINVAL; }
     return pg_check_launch("cast_f32");
 }
+
+// ---- fp16 saturation scan (debug) ----------------------------------------------------------------------
+// Every fp32 -> fp16 conversion of the encoder saturates at +-65504 (common.h) instead of producing inf.  A clamped
+// conversion leaves exactly +-65504 (0x7bff / 0xfbff) behind; an un-clamped value rounds there only from the 16-wide
+// interval [65488, 65520).  With pg_vit_saturation_check(h, 1) the forward pass scans every 16-bit activation buffer right
+// after the kernel that wrote it and adds the number of such elements to a counter (pg_vit_saturation_read): 0 means no
+// activation ever touched the fp16 range limit.  bf16 has the fp32 exponent range: the scan then counts +-inf.
+__global__ __launch_bounds__(256) void count_sat16_kernel(const uint16_t* __restrict__ buf, int64_t rows, int cols, int64_t ld,
+                                                          int is_f16, unsigned long long* __restrict__ counter) {
+    const int64_t vec_per_row = cols / 8;
+    const int64_t total = rows * vec_per_row;
+    unsigned long long n = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / vec_per_row, c = (i - r * vec_per_row) * 8;
+        const u32x4 v = *(const u32x4*)(buf + r * ld + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t lo = v[e] & 0x7fffu, hi = (v[e] >> 16) & 0x7fffu;
+            if (is_f16) { n += (lo == 0x7bffu) + (hi == 0x7bffu); }
+            else { n += (lo == 0x7f80u) + (hi == 0x7f80u); }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o, 64);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(counter, n);
+}
+
+int pg_count_sat16_launch(const void* buf, int64_t rows, int cols, int64_t ld, int dtype, unsigned long long* counter, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return PG_OK;
+    if (cols % 8 || ld % 8) { pg_set_error("count_sat16: cols / ld must be multiples of 8"); return PG_EINVAL; }
+    hipLaunchKernelGGL(count_sat16_kernel, dim3(2048), dim3(256), 0, s, (const uint16_t*)buf, rows, cols, ld,
+                       dtype == PG_DTYPE_F16 ? 1 : 0, counter);
+    return pg_check_launch("count_sat16");
+}

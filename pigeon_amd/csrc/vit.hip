@@ -77,6 +77,9 @@ struct pg_vit {
     uint16_t* wpatch = nullptr;                           // [1024][640] bf16 (K zero padded)
     float *cls = nullptr, *pos = nullptr, *preg = nullptr, *preb = nullptr;
     std::vector<LayerW> layers;
+    // fp16 saturation scan (debug): device counter of 16-bit activations sitting on +-65504
+    bool sat_check = false;
+    unsigned long long* sat_counter = nullptr;
     // profiling
     bool prof = false;
     struct Ev { hipEvent_t a, b; int cls; };
@@ -312,6 +315,8 @@ struct ProfScope {
     }
 };
 
+#define SAT(buf, rows, cols, ld) do { if (h->sat_check) RC(pg_count_sat16_launch((buf), (rows), (cols), (ld), dt, h->sat_counter, s)); } while (0)
+
 static int vit_forward_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n, float* emb_out, float* hidden_out,
                              char* ws, hipStream_t s) {
     const int64_t M = (int64_t)n * VIT_TOKENS;
@@ -321,6 +326,7 @@ static int vit_forward_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n
     const float eps = h->cfg.ln_eps;
     const int dt = h->cfg.mma_dtype;
     { ProfScope p(h, s, 7); RC(pg_im2col_launch(pixels, pix_dtype, big, dt, n, s)); }
+    SAT(big, (int64_t)n * VIT_PATCHES, VIT_PATCH_KPAD, VIT_PATCH_KPAD);
     { ProfScope p(h, s, 4);
       RC(pg_gemm_launch(dt, big, VIT_PATCH_KPAD, h->wpatch, VIT_PATCH_KPAD, nullptr, X, VIT_HIDDEN, n * VIT_PATCHES, VIT_HIDDEN, VIT_PATCH_KPAD,
                         EPI_PATCH, 1.f, 0, h->pos, 0, s)); }
@@ -338,6 +344,7 @@ static int vit_forward_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n
         float* rsB = (float*)((char*)rsA + align_up((size_t)M * 8, 256));
         const int slots = VIT_HIDDEN / 64;
         { ProfScope p(h, s, 6); RC(pg_rowstat_cast_launch(X, Xn, dt, rsA, M, eps, s)); }
+        SAT(Xn, M, VIT_HIDDEN, VIT_HIDDEN);
         for (int l = 0; l < h->cfg.layers; ++l) {
             const LayerW& L = h->layers[l];
             const bool last = l + 1 == h->cfg.layers;
@@ -346,16 +353,20 @@ static int vit_forward_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n
               ex = PgGemmExtra(); ex.colsum = L.sqkv; ex.rowstat = rsA;
               RC(pg_gemm_launch(dt, Xn, VIT_HIDDEN, L.wqkv, VIT_HIDDEN, L.bqkv, big, 3 * VIT_HIDDEN, (int)M, 3 * VIT_HIDDEN, VIT_HIDDEN,
                                 EPI_QKV_LN, kQScale, VIT_HIDDEN, nullptr, 0, s, &ex)); }
+            SAT(big, M, 3 * VIT_HIDDEN, 3 * VIT_HIDDEN);
             { ProfScope p(h, s, 5); RC(pg_attention_launch(dt, big, Xn, n, s)); }
+            SAT(Xn, M, VIT_HIDDEN, VIT_HIDDEN);
             { ProfScope p(h, s, 1);
               ex = PgGemmExtra(); ex.x16 = Xn2; ex.ldx = VIT_HIDDEN; ex.statpart = statpart;
               RC(pg_gemm_launch(dt, Xn, VIT_HIDDEN, L.wo, VIT_HIDDEN, L.bo, X, VIT_HIDDEN, (int)M, VIT_HIDDEN, VIT_HIDDEN, EPI_RESID_STAT,
                                 1.f, 0, nullptr, 0, s, &ex)); }
+            SAT(Xn2, M, VIT_HIDDEN, VIT_HIDDEN);
             { ProfScope p(h, s, 6); RC(pg_rowstat_finalize_launch(statpart, slots, rsB, M, eps, s)); }
             { ProfScope p(h, s, 2);
               ex = PgGemmExtra(); ex.colsum = L.s1; ex.rowstat = rsB;
               RC(pg_gemm_launch(dt, Xn2, VIT_HIDDEN, L.w1, VIT_HIDDEN, L.b1, big, VIT_MLP, (int)M, VIT_MLP, VIT_HIDDEN, EPI_GELU_LN, 1.f, 0,
                                 nullptr, 0, s, &ex)); }
+            SAT(big, M, VIT_MLP, VIT_MLP);
             { ProfScope p(h, s, 3);
               if (last) {
                   RC(pg_gemm_launch(dt, big, VIT_MLP, L.w2, VIT_MLP, L.b2, X, VIT_HIDDEN, (int)M, VIT_HIDDEN, VIT_MLP, EPI_RESID, 1.f, 0, nullptr, 0, s));
@@ -364,21 +375,27 @@ static int vit_forward_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n
                   RC(pg_gemm_launch(dt, big, VIT_MLP, L.w2, VIT_MLP, L.b2, X, VIT_HIDDEN, (int)M, VIT_HIDDEN, VIT_MLP, EPI_RESID_STAT, 1.f, 0,
                                     nullptr, 0, s, &ex));
               } }
+            if (!last) SAT(Xn, M, VIT_HIDDEN, VIT_HIDDEN);
             if (!last) { ProfScope p(h, s, 6); RC(pg_rowstat_finalize_launch(statpart, slots, rsA, M, eps, s)); }
         }
     } else
     for (int l = 0; l < h->cfg.layers; ++l) {
         const LayerW& L = h->layers[l];
         { ProfScope p(h, s, 6); RC(pg_layernorm_launch(X, L.ln1g, L.ln1b, Xn, dt, M, eps, s)); }
+        SAT(Xn, M, VIT_HIDDEN, VIT_HIDDEN);
         { ProfScope p(h, s, 0);
           RC(pg_gemm_launch(dt, Xn, VIT_HIDDEN, L.wqkv, VIT_HIDDEN, L.bqkv, big, 3 * VIT_HIDDEN, (int)M, 3 * VIT_HIDDEN, VIT_HIDDEN, EPI_QKV,
                             kQScale, VIT_HIDDEN, nullptr, 0, s)); }
+        SAT(big, M, 3 * VIT_HIDDEN, 3 * VIT_HIDDEN);
         { ProfScope p(h, s, 5); RC(pg_attention_launch(dt, big, Xn, n, s)); }
+        SAT(Xn, M, VIT_HIDDEN, VIT_HIDDEN);
         { ProfScope p(h, s, 1);
           RC(pg_gemm_launch(dt, Xn, VIT_HIDDEN, L.wo, VIT_HIDDEN, L.bo, X, VIT_HIDDEN, (int)M, VIT_HIDDEN, VIT_HIDDEN, EPI_RESID, 1.f, 0, nullptr, 0, s)); }
         { ProfScope p(h, s, 6); RC(pg_layernorm_launch(X, L.ln2g, L.ln2b, Xn, dt, M, eps, s)); }
+        SAT(Xn, M, VIT_HIDDEN, VIT_HIDDEN);
         { ProfScope p(h, s, 2);
           RC(pg_gemm_launch(dt, Xn, VIT_HIDDEN, L.w1, VIT_HIDDEN, L.b1, big, VIT_MLP, (int)M, VIT_MLP, VIT_HIDDEN, EPI_GELU, 1.f, 0, nullptr, 0, s)); }
+        SAT(big, M, VIT_MLP, VIT_MLP);
         { ProfScope p(h, s, 3);
           RC(pg_gemm_launch(dt, big, VIT_MLP, L.w2, VIT_MLP, L.b2, X, VIT_HIDDEN, (int)M, VIT_HIDDEN, VIT_MLP, EPI_RESID, 1.f, 0, nullptr, 0, s)); }
     }
@@ -419,6 +436,29 @@ extern "C" int pg_vit_destroy(pg_vit* h) {
     for (void* p : h->allocs) (void)hipFree(p);
     for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     delete h;
+    return PG_OK;
+}
+
+extern "C" int pg_vit_saturation_check(pg_vit* h, int on) {
+    if (!h) { pg_set_error("saturation_check: null handle"); return PG_EINVAL; }
+    if (on && !h->sat_counter) {
+        PG_HIP(hipSetDevice(h->device));
+        PG_HIP(hipMalloc((void**)&h->sat_counter, sizeof(unsigned long long)));
+        h->allocs.push_back(h->sat_counter);
+        PG_HIP(hipMemset(h->sat_counter, 0, sizeof(unsigned long long)));
+    }
+    h->sat_check = on != 0;
+    return PG_OK;
+}
+extern "C" int pg_vit_saturation_read(pg_vit* h, int64_t* count, int reset) {
+    if (!h || !count) { pg_set_error("saturation_read: null argument"); return PG_EINVAL; }
+    *count = 0;
+    if (!h->sat_counter) return PG_OK;
+    PG_HIP(hipDeviceSynchronize());
+    unsigned long long v = 0;
+    PG_HIP(hipMemcpy(&v, h->sat_counter, sizeof(v), hipMemcpyDeviceToHost));
+    *count = (int64_t)v;
+    if (reset) PG_HIP(hipMemset(h->sat_counter, 0, sizeof(v)));
     return PG_OK;
 }
 

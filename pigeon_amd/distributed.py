@@ -1,10 +1,10 @@
 """One-process-per-GPU data parallelism for the inference path.
 
 The reference's only inference-time collective is `accelerator.gather` (preprocessing/embed.py:36-37): an
-all-gather, concatenating every rank's tensor along dim 0 in rank order.  Here that is
-`torch.distributed.all_gather_into_tensor` on the process group -- backend "nccl" is RCCL over xGMI on ROCm,
-"gloo" on CPU for tests -- wrapped in a tiny Communicator with accelerate's semantics, plus the batch sharding
-`accelerator.prepare(DataLoader)` performs (whole batches dealt round-robin to ranks, embed.py:68).
+all-gather, concatenating every rank's tensor along dim 0 in rank order.  Here that is `pg_allgather(_many)` of the C
+ABI -- RCCL over xGMI, csrc/comm.hip -- wrapped in a tiny Communicator with accelerate's semantics (torch.distributed
+is the control plane only: bootstrap of the RCCL id, barriers, and the gloo data path of the CPU tests), plus the batch
+sharding `accelerator.prepare(DataLoader)` performs (whole batches dealt round-robin to ranks, embed.py:68).
 """
 from __future__ import annotations
 
@@ -16,7 +16,12 @@ import torch.distributed as dist
 
 
 class Communicator:
-    """rank / world_size + rank-major all-gather.  world_size == 1 needs no process group."""
+    """rank / world_size + rank-major all-gather with accelerate's semantics.  world_size == 1 needs no process group.
+
+    Data path: device tensors go through the C ABI (`pg_allgather` / `pg_allgather_many` in libpigeon_hip.so = RCCL over
+    xGMI, csrc/comm.hip); the RCCL communicator is created lazily on first use, its unique id travelling from rank 0 over
+    the torch.distributed process group, which is only the CONTROL plane here (bootstrap, barrier; "gloo" by default).
+    Host tensors (the CPU tests) use that process group directly."""
 
     def __init__(self, group: Optional[dist.ProcessGroup] = None):
         self.group = group
@@ -25,6 +30,8 @@ class Communicator:
             self.world_size = dist.get_world_size(group)
         else:
             self.rank, self.world_size = 0, 1
+        self._rccl = None          # pg_comm handle (ctypes void*)
+        self._rccl_device = None
 
     @property
     def is_main_process(self) -> bool:
@@ -32,36 +39,78 @@ class Communicator:
 
     is_local_main_process = is_main_process
 
+    # ---- RCCL communicator behind the C ABI ----
+    def _comm(self, device: torch.device):
+        import ctypes as C
+        from . import _lib
+        if self._rccl is not None:
+            if self._rccl_device != device.index:
+                raise _lib.PigeonHipError(f"communicator was created on cuda:{self._rccl_device}, tensor is on {device}")
+            return self._rccl
+        lib = _lib.load()
+        ident = [None]
+        if self.rank == 0:
+            buf = C.create_string_buffer(128)
+            _lib.check(lib.pg_comm_unique_id(buf), "pg_comm_unique_id")
+            ident = [buf.raw]
+        dist.broadcast_object_list(ident, src=0, group=self.group)         # control plane: 128 bytes
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.pg_comm_init_rank(C.byref(h), self.world_size, ident[0], self.rank), "pg_comm_init_rank")
+        self._rccl, self._rccl_device = h, device.index
+        return h
+
+    def rccl_ranks(self) -> int:
+        """Number of ranks as RCCL sees them (0 before the communicator exists)."""
+        import ctypes as C
+        from . import _lib
+        if self._rccl is None:
+            return 0
+        n = C.c_int()
+        _lib.check(_lib.load().pg_comm_count(self._rccl, C.byref(n)), "pg_comm_count")
+        return int(n.value)
+
+    def close(self):
+        if self._rccl is not None:
+            from . import _lib
+            _lib.load().pg_comm_destroy(self._rccl)
+            self._rccl = None
+
     def gather(self, t: torch.Tensor) -> torch.Tensor:
         """accelerate.Accelerator.gather: (n, ...) on every rank -> (world*n, ...) rank-major, on every rank."""
-        if self.world_size == 1:
-            return t
-        t = t.contiguous()
-        out = torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        if t.is_cuda:
-            dist.all_gather_into_tensor(out, t, group=self.group)       # one RCCL all-gather over xGMI
-        else:
-            parts = list(out.chunk(self.world_size, dim=0))             # gloo: list form
-            dist.all_gather(parts, t, group=self.group)
-        return out
+        return self.gather_many([t])[0]
 
     def gather_many(self, tensors: List[torch.Tensor]) -> List[torch.Tensor]:
-        """Gather several tensors with the same leading dimension in ONE collective: they are packed as raw bytes
-        into a single (n, bytes_per_row) buffer, gathered once, and unpacked.  (Per step the payload is tiny --
-        2 MiB of embeddings + a few KiB of indices -- so one launch beats four.)"""
+        """Gather several tensors (same leading dimension on every rank) in ONE grouped collective; every result is
+        rank-major and contiguous -- no packing, no unpacking copies."""
         if self.world_size == 1:
             return list(tensors)
-        n = tensors[0].shape[0]
-        flat = [t.contiguous().view(n, -1).view(torch.uint8) for t in tensors]
-        widths = [f.shape[1] for f in flat]
-        packed = torch.cat(flat, dim=1)
-        g = self.gather(packed)
-        outs, off = [], 0
-        for t, w in zip(tensors, widths):
-            piece = g[:, off:off + w].contiguous().view(t.dtype).view((self.world_size * n,) + tuple(t.shape[1:]))
-            outs.append(piece)
-            off += w
+        srcs = [t.contiguous() for t in tensors]
+        outs = [torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in srcs]
+        if srcs[0].is_cuda:
+            import ctypes as C
+            from . import _lib
+            comm = self._comm(srcs[0].device)
+            n = len(srcs)
+            send = (C.c_void_p * n)(*[t.data_ptr() for t in srcs])
+            recv = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+            nbytes = (C.c_size_t * n)(*[t.numel() * t.element_size() for t in srcs])
+            stream = C.c_void_p(torch.cuda.current_stream(srcs[0].device).cuda_stream)
+            _lib.check(_lib.load().pg_allgather_many(comm, n, send, recv, nbytes, stream), "pg_allgather_many")
+        else:
+            for t, o in zip(srcs, outs):                                      # gloo (CPU tests): list form
+                dist.all_gather(list(o.chunk(self.world_size, dim=0)), t, group=self.group)
         return outs
+
+    def max_over_ranks(self, value: float) -> float:
+        """Control-plane MAX reduction of a host scalar (bench timing)."""
+        if self.world_size == 1:
+            return value
+        t = torch.tensor([value], dtype=torch.float64)
+        if dist.get_backend(self.group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
 
     def barrier(self):
         if self.world_size > 1:
@@ -71,48 +120,96 @@ class Communicator:
 
 
 def init_from_env(backend: Optional[str] = None) -> Communicator:
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun's env).
-    No-op for a single process."""
+    """Initialise the control-plane process group from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun's env);
+    no-op for a single process.  Default backend "gloo": the data path does not use it (see Communicator)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend == "nccl":
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group(backend=backend)
+        dist.init_process_group(backend=backend or "gloo")
     return Communicator()
+
+
+def _tree_map(fn, *bs):
+    b = bs[0]
+    if torch.is_tensor(b):
+        return fn(*bs)
+    if isinstance(b, dict):
+        return {k: _tree_map(fn, *[x[k] for x in bs]) for k in b}
+    if isinstance(b, (list, tuple)):
+        return type(b)(_tree_map(fn, *[x[i] for x in bs]) for i in range(len(b)))
+    return fn(*[torch.as_tensor(x) for x in bs])
+
+
+def _batch_len(b) -> int:
+    if torch.is_tensor(b):
+        return int(b.shape[0])
+    if isinstance(b, dict):
+        return _batch_len(next(iter(b.values())))
+    if isinstance(b, (list, tuple)):
+        return _batch_len(b[0])
+    return 1                                                         # opaque batch object: dealt whole
 
 
 def shard_batches(batches: Iterable, rank: int, world_size: int, even: bool = True) -> Iterator:
     """Deal whole batches round-robin to ranks, as accelerate's BatchSamplerShard does for
-    `accelerator.prepare(DataLoader)` with split_batches=False (batch i -> rank i % world_size).
-    even=True (accelerate's even_batches default) wraps around to the first batches so that every rank runs
-    the same number of steps -- required for the collective; the duplicates are removed downstream by the
-    gathered sample indices (reference preprocessing/dataset_preprocessing.py:299-300 argsorts by index)."""
+    `accelerator.prepare(DataLoader)` with split_batches=False (batch i -> rank i % world_size; reference
+    preprocessing/embed.py:68).
+
+    even=True (accelerate's even_batches default): every rank runs the same number of steps AND every batch it
+    yields has the full batch size -- the all-gather needs equal per-rank row counts.  A short final batch
+    (DataLoader drop_last=False) is completed at SAMPLE level with samples taken from the start of the data, and
+    the ranks left without a batch in the last round get filler batches cut from the same wrap-around stream,
+    exactly as BatchSamplerShard does; the duplicates are removed downstream by the gathered sample indices
+    (reference preprocessing/dataset_preprocessing.py:299-300 sorts by index and keeps the first num_samples)."""
     if world_size == 1:
         yield from batches
         return
-    head: List = []
+    head: List = []            # the first `world_size` batches = the wrap-around sample stream (accelerate: initial_data)
     group: List = []
+    bs = None
     for b in batches:
+        if bs is None:
+            bs = _batch_len(b)
         if len(head) < world_size:
             head.append(b)
         group.append(b)
-        if len(group) == world_size:
+        if len(group) == world_size and _batch_len(b) == bs:
             yield group[rank]
             group = []
-    if group:
-        if not even:
-            if rank < len(group):
-                yield group[rank]
-            return
-        i = 0
+    if not group:
+        return
+    if not even:
+        if rank < len(group):
+            yield group[rank]
+        return
+    if not (torch.is_tensor(head[0]) or isinstance(head[0], (dict, list, tuple))):
+        i = 0                                                            # opaque batches: whole-batch wrap-around
         while len(group) < world_size:
             group.append(head[i % len(head)])
             i += 1
         yield group[rank]
+        return
+    pool = _tree_map(lambda *ts: torch.cat(ts, dim=0), *head)
+    while _batch_len(pool) < bs * (world_size + 1):                 # enough samples for one padded + W-1 filler batches
+        pool = _tree_map(lambda a, b_: torch.cat([a, b_], dim=0), pool, pool)
+    cursor = 0
+
+    def take(n):
+        nonlocal cursor
+        piece = _tree_map(lambda t: t[cursor:cursor + n], pool)
+        cursor += n
+        return piece
+
+    last = group[-1]
+    short = bs - _batch_len(last)
+    if short > 0:
+        group[-1] = _tree_map(lambda a, b_: torch.cat([a, b_.to(a.dtype)], dim=0), last, take(short))
+    while len(group) < world_size:
+        group.append(take(bs))
+    yield group[rank]
 
 
 def restore_order(gathered_indices: torch.Tensor, *tensors: torch.Tensor):

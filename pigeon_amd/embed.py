@@ -1,8 +1,8 @@
 """Multi-GPU batch embedding, behind the reference's call surface (preprocessing/embed.py).
 
 `compute_embeddings(name, model, data, accelerator)` and `embed_images(loaded_model, dataset)` keep the
-reference's names, arguments and on-disk outputs (`data/landmark_embeddings/{name}.npy` = list of gathered
-batches, `{name}_indices.npy`; embed.py:41-43).  `accelerate.Accelerator` is replaced by
+reference's names, arguments and on-disk outputs (`data/landmark_embeddings/{name}.npy` = (steps, world*batch, 1024)
+float32 array of the gathered batches, `{name}_indices.npy` = (steps, world*batch) int64; embed.py:41-43).  `accelerate.Accelerator` is replaced by
 `pigeon_amd.distributed.Communicator` (same `.gather`, `.is_local_main_process`, `.wait_for_everyone`), one
 process per GPU, RCCL all-gather over xGMI.
 """
@@ -42,6 +42,22 @@ class EmbedDataset:
         return len(self.dataset)
 
 
+def _stack_padded(batches, fill):
+    """np.stack of per-step arrays; a shorter last step is padded to the common length (fill None: indices -> int max so
+    they sort last)."""
+    if not batches:
+        return np.zeros((0,))
+    n = max(b.shape[0] for b in batches)
+    out = []
+    for b in batches:
+        if b.shape[0] < n:
+            pad_shape = (n - b.shape[0],) + b.shape[1:]
+            v = np.iinfo(b.dtype).max if fill is None else fill
+            b = np.concatenate([b, np.full(pad_shape, v, dtype=b.dtype)], axis=0)
+        out.append(b)
+    return np.stack(out)
+
+
 def compute_embeddings(name: str, model: Any, data: Iterable, accelerator: Communicator,
                        out_dir: str = 'data/landmark_embeddings', save: bool = True):
     """reference preprocessing/embed.py:16-43.  `data` yields (pixels, index) batches ALREADY sharded for this
@@ -57,8 +73,13 @@ def compute_embeddings(name: str, model: Any, data: Iterable, accelerator: Commu
         all_indices.append(all_indic.cpu().detach().numpy())
     if accelerator.is_local_main_process and save:
         os.makedirs(out_dir, exist_ok=True)
-        np.save(f'{out_dir}/{name}.npy', np.array(all_outputs, dtype=object), allow_pickle=True)
-        np.save(f'{out_dir}/{name}_indices.npy', np.array(all_indices, dtype=object), allow_pickle=True)
+        # plain numeric arrays (steps, world*batch, 1024) / (steps, world*batch): what the reference's np.save of a list of
+        # equal-shape batches produces (:41-43) and what its reader np.load's WITHOUT allow_pickle
+        # (preprocessing/dataset_preprocessing.py:294-300).  A ragged last batch (single process, drop_last=False) is
+        # padded with zero rows whose index is INT64_MAX, which sort behind every real sample in that reader's argsort
+        # -- the reference itself cannot save that case with numpy >= 1.24.
+        np.save(f'{out_dir}/{name}.npy', _stack_padded(all_outputs, 0.0))
+        np.save(f'{out_dir}/{name}_indices.npy', _stack_padded(all_indices, None))
     return all_outputs, all_indices
 
 

@@ -3,8 +3,8 @@ SuperGuessr + ProtoRefiner, `evaluate_model()` (training/train_eval_loop.py:35-1
 `model(**data)` -> `refiner(...)` -> collect.  Plus `PanoramaPipeline`, the data-parallel step the benchmark
 times: ViT + head on the local shard, ONE all-gather of embeddings / candidates, refinement.
 
-Out of scope here (SURVEY.md section 2 rows 14,17): TensorBoard writers, the geopandas country metrics; the
-haversine-based distance metrics (evaluation/metrics.py:90-137 via haversine_np) are provided.
+Out of scope here (SURVEY.md section 2 rows 14,17): TensorBoard writers, the geopandas country metric; the
+distance / geocell metrics of evaluation/metrics.py:89-181 are provided under the reference's keys.
 """
 from __future__ import annotations
 
@@ -14,7 +14,7 @@ from typing import Callable, Dict, Optional
 import numpy as np
 import torch
 
-from .config import EVAL_BATCH_SIZE_PER_GPU
+from .config import DECAY_CONSTANT, EVAL_BATCH_SIZE_PER_GPU
 from .distributed import Communicator
 from .geo_utils import haversine_np
 from .proto_refiner import ProtoRefiner
@@ -23,16 +23,42 @@ from .super_guessr import SuperGuessr
 logger = logging.getLogger('train')
 
 
-def distance_metrics(preds: np.ndarray, labels: np.ndarray) -> Dict[str, float]:
-    """km-error statistics + %-within-radius + GeoGuessr score (reference evaluation/metrics.py:90-137,162-181;
-    DECAY_CONSTANT 1492.7, config.py:50)."""
-    km = haversine_np(np.asarray(labels, dtype=np.float64), np.asarray(preds, dtype=np.float64))
-    out = {'Mean_km_error': float(km.mean()), 'Median_km_error': float(np.median(km)),
-           'Mean_geoguessr_score': float((5000 * np.exp(-km / 1492.7)).mean())}
-    for name, r in (('Street_1km', 1), ('City_25km', 25), ('Region_200km', 200), ('Country_750km', 750),
-                    ('Continent_2500km', 2500)):
-        out[f'Percentage_{name}'] = float((km <= r).mean() * 100)
-    return out
+def percentage_within_radius(distances: np.ndarray, km: float) -> float:
+    """reference evaluation/metrics.py:89-100 (a FRACTION, strict `<`, despite the name)"""
+    return (distances < km).sum() / len(distances)
+
+
+def geoguessr_score(distances: np.ndarray) -> float:
+    """reference evaluation/metrics.py:102-114; DECAY_CONSTANT = 1492.7 (config.py:52)"""
+    return np.mean(np.round(5000 * np.exp(-distances / DECAY_CONSTANT)))
+
+
+def topk_geocell_accuracy(cell_labels: np.ndarray, topk_preds: np.ndarray) -> float:
+    """reference evaluation/metrics.py:116-136"""
+    num_correct = 0
+    for label, top5 in zip(cell_labels, topk_preds):
+        if label in top5:
+            num_correct += 1
+    return num_correct / len(cell_labels)
+
+
+def compute_geoguessr_metrics(results) -> Dict[str, float]:
+    """reference evaluation/metrics.py:138-181 on the 11-tuple evaluate_model builds (train_eval_loop.py:138-140):
+    the km-error statistics, the Under_*_km fractions, the GeoGuessr score and the geocell (top-k) accuracies, under the
+    reference's keys.  Left out: `Country_accuracy` (geopandas country polygons, absent here)
+    and the multi-task regressions (training-only heads).  Host numpy on the collected predictions, as in the reference."""
+    predictions, cell_preds, _, _, _, top5_geocells, labels, cell_labels, _, _, _ = results
+    cell_labels = np.asarray(cell_labels)
+    if cell_labels.ndim > 1:
+        cell_labels = np.argmax(cell_labels, axis=-1)
+    distances = haversine_np(np.asarray(predictions), np.asarray(labels))      # dtypes as collected (fp32 preds: np.radians in fp32)
+    eval_dict = {'Mean_km_error': np.mean(distances), 'Median_km_error': np.median(distances)}
+    for km in (1, 5, 10, 25, 50, 100, 200, 750, 1000, 2500):
+        eval_dict[f'Under_{km}_km'] = percentage_within_radius(distances, km)
+    eval_dict['Geoguessr_score'] = geoguessr_score(distances)
+    eval_dict['Geocell_accuracy'] = float(np.mean(cell_labels == np.asarray(cell_preds)))      # sklearn accuracy_score
+    eval_dict['Geocell_top5_accuracy'] = topk_geocell_accuracy(cell_labels, top5_geocells)
+    return eval_dict
 
 
 def evaluate_model(model: SuperGuessr, dataset, metrics: Optional[Callable] = None, train_args=None,
@@ -77,16 +103,12 @@ def evaluate_model(model: SuperGuessr, dataset, metrics: Optional[Callable] = No
     top5_geocells = np.concatenate(combined_top5_cells, axis=0)
     results = dict(preds=preds, preds_geocells=preds_geocells, top5_geocells=top5_geocells,
                    top5_probs=np.concatenate(combined_top5_probs, axis=0), loss_clf=combined_loss / max(n_seen, 1))
-    try:
-        labels_lla = np.asarray(dataset['labels'])
-        labels_cell = np.asarray(dataset['labels_clf'])
-        results.update(distance_metrics(preds, labels_lla))
-        results['Geocell_accuracy'] = float((preds_geocells == labels_cell).mean())
-        if metrics is not None:
-            results.update(metrics((preds, preds_geocells, None, None, None, top5_geocells,
-                                    labels_lla, labels_cell, None, None, None)))
-    except (KeyError, TypeError, IndexError):
-        pass                                                                      # dataset without label columns
+    if metrics is not None:                                                       # :122-140
+        labels_lla, labels_cell = dataset['labels'], dataset['labels_clf']
+        if isinstance(labels_lla, np.ndarray) == False:
+            labels_lla, labels_cell = np.asarray(labels_lla), np.asarray(labels_cell)
+        results.update(metrics((preds, preds_geocells, None, None, None, top5_geocells,
+                                labels_lla, labels_cell, None, None, None)))
     model.train()
     logger.warning('Back to training ...')
     return results
@@ -106,10 +128,14 @@ def evaluate(model: str, dataset, yfcc: bool, landmarks: bool, base_model=None, 
     from . import config as cfg
     full_model = SuperGuessr(base_model, panorama=True, hierarchical=False, multi_task=False, heading=heading,
                              freeze_base=True, yfcc=yfcc, num_candidates=50, geocell_path=geocell_path)
-    if head_state and os.path.exists(head_state):
-        full_model.load_state(head_state)
-    if model and os.path.exists(model):
-        full_model.load_state(model)
+    # the reference's torch.load raises on a missing checkpoint (:46); only the explicit random-init names skip loading
+    for ckpt in (head_state, model):
+        if ckpt in (None, '', 'none', 'random'):
+            continue
+        if not os.path.exists(ckpt):
+            raise FileNotFoundError(f'evaluate: checkpoint {ckpt!r} does not exist (pass "none" / "random" to evaluate '
+                                    f'a randomly initialised head on purpose)')
+        full_model.load_state(ckpt)
     full_model.to('cuda')
     print(full_model)
     refiner = None
@@ -130,7 +156,7 @@ def evaluate(model: str, dataset, yfcc: bool, landmarks: bool, base_model=None, 
             os.makedirs(os.path.dirname(packed) or '.', exist_ok=True)
             refiner.host_bank.save(packed)
         print(refiner)
-    return evaluate_model(full_model, dataset, None, None, refiner)
+    return evaluate_model(full_model, dataset, compute_geoguessr_metrics, None, refiner)
 
 
 class PanoramaPipeline:

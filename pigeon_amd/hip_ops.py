@@ -167,6 +167,17 @@ def haversine_matrix(x: torch.Tensor, y_rows: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def haversine_pairs(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """x (N,2) fp64, y (N,2) fp32/fp64 [lng,lat] degrees -> (N,) fp64 km (row-paired)."""
+    _dev(x, torch.float64); _dev(y)
+    if y.dtype not in (torch.float32, torch.float64) or x.shape != y.shape or x.dim() != 2 or x.shape[1] != 2:
+        raise _lib.PigeonHipError("haversine_pairs: x (N,2) fp64 and y (N,2) fp32/fp64 expected")
+    out = torch.empty((x.shape[0],), dtype=torch.float64, device=x.device)
+    check(load().pg_haversine_pairs(_p(x), _p(y), _lib.PG_DTYPE_F64 if y.dtype == torch.float64 else _lib.PG_DTYPE_F32,
+                                    x.shape[0], _p(out), _stream()), "pg_haversine_pairs")
+    return out
+
+
 def smooth_labels(distances: torch.Tensor, constant: float) -> torch.Tensor:
     _dev(distances, torch.float64)
     N, M = distances.shape
@@ -301,6 +312,16 @@ class VitEncoder:
         ms = (C.c_double * n)()
         check(load().pg_vit_profile_read(self._h, launches, ms), "pg_vit_profile_read")
         return {name: (int(launches[i]), float(ms[i])) for i, name in enumerate(_lib.PROF_CLASSES)}
+
+    # ---- fp16 saturation counter (debug) ----
+    def saturation_check(self, on: bool = True):
+        check(load().pg_vit_saturation_check(self._h, 1 if on else 0), "pg_vit_saturation_check")
+
+    def saturation_read(self, reset: bool = True) -> int:
+        """16-bit activations found sitting exactly on the fp16 limit +-65504 (= clamped conversions) since the last reset."""
+        n = C.c_int64()
+        check(load().pg_vit_saturation_read(self._h, C.byref(n), 1 if reset else 0), "pg_vit_saturation_read")
+        return int(n.value)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

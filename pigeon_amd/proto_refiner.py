@@ -67,30 +67,23 @@ def _training_arrays(dataset_path):
     else:
         train = datasets.DatasetDict.load_from_disk(dataset_path)['train']
     train = train.with_format('numpy')
-    emb = np.asarray(train['embedding'][:], dtype=np.float32)
+    emb = np.ascontiguousarray(np.asarray(train['embedding'][:], dtype=np.float32))
     if emb.ndim == 3:                                             # (N,4,1024): mean over panels (:252-253,:374-375)
-        emb = torch.from_numpy(emb).mean(dim=1).numpy()
+        emb = _panel_mean_gpu(emb)
     lab = np.asarray(train['labels'][:], dtype=np.float32)
     return np.ascontiguousarray(emb), np.ascontiguousarray(lab[:, :2])
 
 
-def _segmented_mean_host(train_emb, member_off, member_idx, lens):
-    """Host version (used when no GPU is visible) of the prototype mean, bit-identical to torch's
-    `embeddings.mean(dim=0)`: below 16 members torch's CPU reduction is a plain member-order sum (swept here across all
-    prototypes at once; np.add.reduceat sums pairwise and differs in the last ulp), from 16 members on it is a cascade
-    of 16-row chunks -- those prototypes simply go through torch itself."""
-    P = lens.shape[0]
-    proto_emb = np.zeros((P, train_emb.shape[1]), dtype=np.float32)
-    small = lens < 16
-    for j in range(int(lens[small].max()) if small.any() else 0):
-        sel = np.nonzero(small & (lens > j))[0]
-        proto_emb[sel] += train_emb[member_idx[member_off[sel] + j]]
-    nz = small & (lens > 0)
-    proto_emb[nz] /= lens[nz].astype(np.float32)[:, None]
-    for p in np.nonzero(~small)[0]:
-        rows = train_emb[member_idx[member_off[p]:member_off[p + 1]]]
-        proto_emb[p] = torch.from_numpy(np.ascontiguousarray(rows)).mean(dim=0).numpy()
-    return proto_emb
+def _panel_mean_gpu(emb4: np.ndarray, device="cuda", rows_per_call: int = 1 << 20) -> np.ndarray:
+    """`embeddings.mean(dim=1)` of a (N,4,1024) training bank on the GPU: pg_proto_build in its 4-panel mode with one
+    single-member "prototype" per row (sum of the 4 panels in order, x 0.25 -- bit-identical to torch's CPU mean)."""
+    n = emb4.shape[0]
+    out = np.empty((n, emb4.shape[2]), dtype=np.float32)
+    for s in range(0, n, rows_per_call):
+        e = min(n, s + rows_per_call)
+        ar = torch.arange(e - s + 1, device=device, dtype=torch.int64)
+        out[s:e] = hip_ops.proto_build(torch.from_numpy(emb4[s:e]).to(device), ar, ar[:-1].contiguous()).cpu().numpy()
+    return out
 
 
 def _segmented_mean_gpu(train_emb, member_off, member_idx, device="cuda"):
@@ -102,7 +95,7 @@ def _segmented_mean_gpu(train_emb, member_off, member_idx, device="cuda"):
     return out.cpu().numpy()
 
 
-def build_bank(proto_path: str, dataset_path, verbose: bool = False, use_gpu: Optional[bool] = None) -> HostBank:
+def build_bank(proto_path: str, dataset_path, verbose: bool = False) -> HostBank:
     """CSV + training embeddings -> CSR bank, reproducing the reference's prototype construction:
     rows of one geocell in CSV order (`proto_df.loc[cell]`, :299), a cell whose FIRST row has no indices is
     empty (:307-308), prototype embedding = fp32 mean of the member embeddings (:359-378), lng/lat/count
@@ -138,13 +131,8 @@ def build_bank(proto_path: str, dataset_path, verbose: bool = False, use_gpu: Op
     member_off = np.zeros(P + 1, dtype=np.int64)
     np.cumsum(lens, out=member_off[1:])
     member_idx = np.fromiter((i for l in idx_lists for i in l), dtype=np.int64, count=int(member_off[-1]))
-    # prototype embedding = mean of the member embeddings (:359-378): on the GPU when one is visible
-    if use_gpu is None:
-        use_gpu = torch.cuda.is_available()
-    if use_gpu and P:
-        proto_emb = _segmented_mean_gpu(train_emb, member_off, member_idx)
-    else:
-        proto_emb = _segmented_mean_host(train_emb, member_off, member_idx, lens)
+    # prototype embedding = mean of the member embeddings (:359-378): pg_proto_build, torch's summation order (no host path)
+    proto_emb = _segmented_mean_gpu(train_emb, member_off, member_idx) if P else np.zeros((0, train_emb.shape[1]), np.float32)
     return HostBank(proto_emb=proto_emb, cell_off=cell_off, proto_lnglat=np.stack([lng, lat], axis=1),
                     proto_count=cnt, member_off=member_off, member_idx=member_idx,
                     train_emb=train_emb, train_lnglat=train_lnglat)

@@ -18,7 +18,7 @@ from . import hip_ops
 from .geo_utils import haversine_matrix, smooth_labels
 from .clip_embedder import HipCLIPVisionModel
 from .config import CLIP_EMBED_DIM, GEOCELL_PATH, GEOCELL_PATH_YFCC
-from .utils import ModelOutput, TopK
+from .utils import ModelOutput, TopK, resolve_name
 
 
 class SuperGuessr(nn.Module):
@@ -88,13 +88,18 @@ class SuperGuessr(nn.Module):
         """reference models/super_guessr.py:222-238: name-wise copy of a saved state dict"""
         own_state = self.state_dict()
         state_dict = torch.load(path, map_location=torch.device('cuda') if torch.cuda.is_available() else 'cpu')
+        matched = 0
         for name, param in state_dict.items():
+            name = resolve_name(name, own_state)         # transformers 4.23.1 `base_model.vision_model.*` -> `base_model.*`
             if name not in own_state:
                 print(f'Parameter {name} not in model\'s state.')
                 continue
             if isinstance(param, Parameter):
                 param = param.data
             own_state[name].copy_(param)
+            matched += 1
+        if len(state_dict) > 0 and matched == 0:
+            raise KeyError(f'load_state: none of the {len(state_dict)} parameters in {path} matched the model')
         self._hip_base = None
         if isinstance(self.base_model, HipCLIPVisionModel):
             self.base_model._weights_changed()

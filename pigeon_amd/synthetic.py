@@ -90,6 +90,36 @@ def make_vit_weights(seed: int = 0, layers: int = LAYERS, affine_jitter: bool = 
     return sd
 
 
+def make_vit_weights_trained_like(seed: int = 21, layers: int = LAYERS) -> Dict[str, torch.Tensor]:
+    """Random weights pushed into the numeric regime of a TRAINED CLIP tower (stress fixture for the 16-bit operand
+    chain; there are no public PIGEON weights, reference README.md:11):
+
+      * massive activations -- a few (token, channel) entries of the residual stream two orders of magnitude above the
+        rest, the well-known outlier features of trained ViTs: three tokens (CLS, 97, 333) get a 150x position-embedding
+        spike on channels 7 and 519, which pre_layrnorm (gamma 10 on those channels) turns into |x| ~ 200;
+      * rows whose mean dwarfs their spread -- pre_layrnorm.bias = 6 on every channel, so every residual row has
+        |mean| / std >= 5 for the whole depth of the network (the regime in which rounding the UN-normalised row to
+        16 bits costs digits that LayerNorm-then-round keeps);
+      * LayerNorm gammas spanning 0.05 .. 1.6 (outlier channels damped, as trained models do) and non-zero betas/biases.
+    """
+    sd = make_vit_weights(seed=seed, layers=layers, affine_jitter=True)
+    g = torch.Generator().manual_seed(seed + 1000)
+    spikes_tok, spikes_ch = [0, 97, 333], [7, 519]
+    pos = sd["embeddings.position_embedding.weight"]
+    for t in spikes_tok:
+        for c in spikes_ch:
+            pos[t, c] += 3.0
+    sd["pre_layrnorm.weight"][spikes_ch] = 10.0
+    sd["pre_layrnorm.bias"] += 6.0
+    for i in range(layers):
+        for ln in ("layer_norm1", "layer_norm2"):
+            w = sd[f"encoder.layers.{i}.{ln}.weight"]
+            w.mul_(torch.empty(HIDDEN).uniform_(0.6, 1.5, generator=g))
+            w[spikes_ch] = 0.05
+            sd[f"encoder.layers.{i}.{ln}.bias"].add_(torch.empty(HIDDEN).normal_(0, 0.2, generator=g))
+    return sd
+
+
 def make_pixels(n_images: int, seed: int = 1234, panorama: bool = False) -> torch.Tensor:
     """Seeded N(0,1) pixels, the statistics of CLIP-normalised images.
 
@@ -150,7 +180,7 @@ class SyntheticBank:
 
 def make_bank(num_cells: int, protos_per_cell: int, seed: int = 2, dim: int = HIDDEN,
               empty_frac: float = 0.01, max_members: int = 8, exact_means: bool = True,
-              jitter_protos: bool = True) -> SyntheticBank:
+              jitter_protos: bool = True, center: Optional[np.ndarray] = None, radius: float = 1.0) -> SyntheticBank:
     """Synthetic prototype bank per SURVEY 8d: ~1% empty cells; 50% singleton clusters, 50% with 2..8
     members.  Training rows are laid out cluster by cluster so member lists are contiguous ranges (the
     kernels do not rely on that; member_idx is still an explicit index list).
@@ -158,6 +188,11 @@ def make_bank(num_cells: int, protos_per_cell: int, seed: int = 2, dim: int = HI
     exact_means=True computes each prototype as the fp32 mean of its members exactly as the reference
     does (needed for parity against the reference's own prototype builder).  For the 1M-row perf bank
     exact_means=False draws prototypes directly (mean-of-members is irrelevant to kernel speed).
+
+    center / radius (end-to-end fixtures): the training embeddings are placed around `center` (the mean query
+    embedding, (dim,) f32) instead of the origin, every geocell at its own distance a_c in [0.3, 3] x radius
+    (log-uniform) from it -- `radius` being the typical |query - center| -- so that the nearest-prototype distances
+    of the candidate cells of one query differ by O(radius) and the refinement genuinely re-ranks candidates.
     """
     rng = np.random.default_rng(seed)
     empty = rng.random(num_cells) < empty_frac
@@ -175,7 +210,14 @@ def make_bank(num_cells: int, protos_per_cell: int, seed: int = 2, dim: int = HI
     train_lnglat = np.stack([rng.uniform(-180, 180, Ntr), rng.uniform(-90, 90, Ntr)], axis=1).astype(np.float32)
     if exact_means:
         train_emb = rng.standard_normal((Ntr, dim), dtype=np.float32)
-        if jitter_protos:
+        if center is not None:
+            a_cell = radius * np.exp(rng.uniform(np.log(0.3), np.log(3.0), size=num_cells))
+            a = np.repeat(a_cell, n_per_cell).astype(np.float32)                   # (P,)
+            centres = rng.standard_normal((P, dim), dtype=np.float32) * (a / np.sqrt(dim))[:, None]
+            centres += np.asarray(center, dtype=np.float32)[None, :]
+            rows = np.repeat(np.arange(P), count)
+            train_emb[member_idx] = centres[rows] + np.float32(0.2 * radius / np.sqrt(dim)) * train_emb[member_idx]
+        elif jitter_protos:
             # members of one cluster share a centre so that "nearest prototype" is meaningful
             centres = rng.standard_normal((P, dim), dtype=np.float32)
             rows = np.repeat(np.arange(P), count)

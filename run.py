@@ -56,6 +56,9 @@ class _SyntheticImages(torch.utils.data.Dataset):
         return self.n
 
     def __getitem__(self, i):
+        if isinstance(i, str):                       # column access, as evaluate_model reads dataset['labels'] (train_eval_loop.py:123-124)
+            import numpy as np
+            return {'labels': np.zeros((self.n, 2)), 'labels_clf': np.zeros(self.n, dtype=np.int64)}[i]
         g = torch.Generator().manual_seed(1234 + i)
         if self.panorama:
             return {'pixel_values': torch.randn((12, 336, 336), generator=g), 'labels': torch.zeros(2, dtype=torch.float64),
@@ -102,6 +105,7 @@ def main():
         embed_images(embedder, dataset, comm, out_dir=args.out_dir, num_workers=0 if args.synthetic else 8)
         if comm.is_main_process:
             print(f'Embeddings written to {args.out_dir}/')
+        return args.out_dir
 
     elif args.function == 'evaluate':
         from pigeon_amd.evaluate import evaluate
@@ -122,7 +126,8 @@ def main():
         results = evaluate(args.name, dataset, yfcc=args.yfcc, base_model=_vision_model(args), refine=True,
                            landmarks=args.landmarks, geocell_path=geocell_path, bank=bank)
         if comm.is_main_process:
-            print({k: (v if not hasattr(v, 'shape') else tuple(v.shape)) for k, v in results.items()})
+            print({k: (v if not hasattr(v, 'shape') or v.shape == () else tuple(v.shape)) for k, v in results.items()})
+        return results
 
 
 if __name__ == '__main__':

@@ -53,11 +53,72 @@ def _worker(rank, world, port, outdir):
     outs, idxs = compute_embeddings("train", lambda px: px * 2.0, shard, comm, out_dir=outdir)
     comm.barrier()
     if rank == 0:
-        emb = np.concatenate(list(np.load(os.path.join(outdir, "train.npy"), allow_pickle=True)), axis=0)
-        idx = np.concatenate(list(np.load(os.path.join(outdir, "train_indices.npy"), allow_pickle=True)), axis=0)
+        emb = np.concatenate(list(np.load(os.path.join(outdir, "train.npy"))), axis=0)
+        idx = np.concatenate(list(np.load(os.path.join(outdir, "train_indices.npy"))), axis=0)
         e, = distributed.restore_order(torch.from_numpy(idx.astype(np.int64)), torch.from_numpy(emb.astype(np.float32)))
         assert e.shape == (20, 5)
         assert torch.equal(e[:, 0], torch.arange(20, dtype=torch.float32) * 2.0)
+    # --- embed_images end to end with a GENUINELY ragged final batch (23 samples, batch 4, DataLoader drop_last=False):
+    #     every rank must see full batches (sample-level wrap-around padding, accelerate's even_batches) or the collective
+    #     would run with unequal counts
+    from pigeon_amd.embed import embed_images
+
+    class Stub(torch.nn.Module):
+        def forward(self, px):
+            assert px.shape[0] == 4, px.shape                           # never a short batch under world_size > 1
+            return px.flatten(1)[:, :6] * 2.0
+
+    items = [{"image": torch.full((3, 2, 2), float(i)), "index": i} for i in range(23)]
+    out2 = os.path.join(outdir, "ragged")
+    embed_images(Stub(), {"train": items}, comm, batch_size=4, num_workers=0, out_dir=out2)
+    if rank == 0:
+        emb = np.load(os.path.join(out2, "train.npy"))                     # plain numeric arrays, no pickle
+        idx = np.load(os.path.join(out2, "train_indices.npy"))
+        assert emb.shape == (3, 8, 6) and idx.shape == (3, 8)
+        e, = distributed.restore_order(torch.from_numpy(idx.reshape(-1)), torch.from_numpy(emb.reshape(-1, 6)))
+        assert e.shape == (23, 6) and torch.equal(e[:, 0], torch.arange(23, dtype=torch.float32) * 2.0)
+        # the reference reader's reorder (dataset_preprocessing.py:296-300) gives the same rows
+        arg = np.argsort(idx.flatten()[:])                                 # duplicates sort next to their originals
+        assert np.array_equal(np.unique(idx.flatten()), np.arange(23))
+    # --- the data-parallel step: ViT+head on the shard -> ONE gather -> refine own slice -> restore order
+    from pigeon_amd.evaluate import PanoramaPipeline
+    from pigeon_amd.utils import ModelOutput, TopK
+    B, k = 3, 5
+
+    class Model:
+        def __call__(self, pixel_values=None, labels_clf=None):
+            v = pixel_values[:, 0, 0, 0]                                    # one scalar per panorama
+            emb = v[:, None, None].repeat(1, 4, 8)
+            cells = (v.long()[:, None] * 10 + torch.arange(k)[None]).contiguous()
+            probs = torch.linspace(0.5, 0.1, k)[None].repeat(B, 1)
+            llh = torch.stack([v.double(), -v.double()], dim=1)
+            return ModelOutput(None, None, 0, 0, 0, llh, cells[:, 0].contiguous(), None, None, None, TopK(probs, cells), emb)
+
+    class Refiner:
+        calls = []
+
+        def __call__(self, emb, initial_preds=None, candidate_cells=None, candidate_probs=None, quiet=False):
+            Refiner.calls.append(emb[:, 0, 0].clone())
+            return None, (initial_preds + 0.25).float(), candidate_cells[:, 1].contiguous()
+
+    pipe = PanoramaPipeline(Model(), Refiner(), comm)
+    px = (torch.arange(B, dtype=torch.float32) + 100 * rank)[:, None, None, None].repeat(1, 12, 2, 2)
+    index = torch.arange(B) * world + rank                                   # interleaved sample ids, as a sharded loader gives
+    res = pipe.step(px, index)
+    assert res["embedding"].shape == (B * world, 4, 8)
+    want_v = torch.cat([torch.arange(B, dtype=torch.float32) + 100 * r for r in range(world)])
+    assert torch.equal(res["embedding"][:, 0, 0], want_v)                    # rank-major
+    assert torch.equal(res["index"], torch.cat([torch.arange(B) * world + r for r in range(world)]))
+    assert torch.equal(res["preds_geocell"], (want_v.long() * 10))
+    assert torch.equal(Refiner.calls[-1], torch.arange(B, dtype=torch.float32) + 100 * rank)   # refined ITS slice only
+    assert torch.equal(res["refined_LLH"][:, 0], (torch.arange(B) + 100 * rank + 0.25).float())
+    assert torch.equal(res["refined_geocell"], (torch.arange(B) + 100 * rank) * 10 + 1)
+    ordered_emb, ordered_llh = distributed.restore_order(res["index"], res["embedding"], res["preds_LLH"])
+    assert torch.equal(ordered_emb[:, 0, 0], torch.tensor([0., 100., 1., 101., 2., 102.]))
+    # refined results of all ranks, gathered and re-ordered the same way
+    all_cells, = comm.gather_many([res["refined_geocell"]])
+    oc, = distributed.restore_order(res["index"], all_cells)
+    assert oc.tolist() == [1, 1001, 11, 1011, 21, 1021]
     torch.distributed.destroy_process_group()
 
 

@@ -1,0 +1,470 @@
+"""GPU tests (run with -m gpu on an MI355X) of the kept ENTRY POINTS and of the full-size end-to-end fixture:
+
+  pipeline24          pixels -> ViT-L/14-336 (24 layers) -> SuperGuessr head (C = 10 000) -> ProtoRefiner at the class
+                      defaults AND at evaluate()'s settings, against the REAL reference's outputs on 32 panoramas
+                      (tests/golden/pipeline24.npz, oracle/make_golden.py --only pipeline24); prints the flip counts.
+  run.py embed|evaluate, embed_images, evaluate(), evaluate_model()   (reference run.py:124-182,
+                      preprocessing/embed.py:45-83, evaluation/evaluate.py:10-85, training/train_eval_loop.py:35-161)
+  CLIPEmbedding(load_checkpoint=True)   reference models/clip_embedder.py:28-33
+  trained-regime ViT fixture (both LayerNorm chains) + the fp16 saturation counter
+  refiner veto edge (mixed fp32/fp64 haversine, proto_refiner.py:198-202), NaN inputs
+  f4 kernels against outputs of the reference's own functions (tests/golden/geo.npz)
+  the RCCL all-gather of the C ABI with a 1-rank communicator
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+EMB_TOL = 1e-3
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def env():
+    from pigeon_amd import _lib, hip_ops, synthetic
+    from oracle import pigeon_oracle as orc
+    _lib.require_gpu()
+    return dict(lib=_lib, ops=hip_ops, syn=synthetic, orc=orc)
+
+
+def _gold(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _geocells_csv(tmp_path, C, seed=0):
+    from pigeon_amd import synthetic
+    p = os.path.join(str(tmp_path), f"geocells_{C}.csv")
+    synthetic.write_geocell_csv(p, synthetic.make_geocells(C, seed=seed))
+    return p
+
+
+# ------------------------------------------------------------------------------------------------ full-size end to end
+def test_pipeline24_matches_reference_end_to_end(env, golden_dir, tmp_path, capsys):
+    """24 layers, C = 10 000, 32 panoramas (128 images) of the seed-1234 pixel stream, num_candidates = 50.
+    Asserted: embeddings < 1e-3; geocell argmax, centroid, the top-5 candidates the default refiner consumes, and the
+    refined cell / (lng,lat) at BOTH refiner settings identical to the reference's.  Reported: flip counts and how many
+    of evaluate()'s top-40 candidate lists differ in order anywhere (tail candidates with p ~ 1e-4 may swap)."""
+    from pigeon_amd.clip_embedder import HipCLIPVisionModel
+    from pigeon_amd.proto_refiner import ProtoRefiner
+    from pigeon_amd.super_guessr import SuperGuessr
+    syn, orc = env["syn"], env["orc"]
+    g = _gold(golden_dir, "pipeline24.npz")
+    wseed, layers, NP, pseed, C, ppc, bseed, maxm = [int(x) for x in g["meta"]]
+    vit = HipCLIPVisionModel(syn.make_vit_weights(seed=wseed, layers=layers), layers=layers).to(DEV)
+    model = SuperGuessr(vit, panorama=True, hierarchical=False, multi_task=False, heading=False, freeze_base=True,
+                        num_candidates=50, geocell_path=_geocells_csv(tmp_path, C))
+    W0, _ = syn.make_head_weights(C, seed=0)
+    with torch.no_grad():
+        model.cell_layer.weight.copy_(W0 * float(g["head_scale"]))
+        model.cell_layer.bias.copy_(torch.from_numpy(g["head_bias"]))
+    model.to(DEV).eval()
+    px = syn.make_pixels(4 * NP, seed=pseed, panorama=True)
+    out = model(pixel_values=px.to(DEV), labels=torch.zeros(NP, 2, dtype=torch.float64), labels_clf=torch.zeros(NP, dtype=torch.long))
+    ref_emb = torch.from_numpy(g["embedding"])
+    e_all = orc.rel_err(out.embedding.cpu(), ref_emb)
+    e_row = orc.max_rel_err_rows(out.embedding.cpu().reshape(-1, 1024), ref_emb.reshape(-1, 1024))
+    cells = out.preds_geocell.cpu().numpy()
+    flips = int((cells != g["preds_geocell"]).sum())
+    top = out.top5_geocells.indices.cpu().numpy()
+    top5_diff = int((top[:, :5] != g["topk_indices"][:, :5]).any(axis=1).sum())
+    top40_diff = int((top[:, :40] != g["topk_indices"][:, :40]).any(axis=1).sum())
+    top40_set_diff = int(sum(set(a[:40]) != set(b[:40]) for a, b in zip(top, g["topk_indices"])))
+    report = [f"pipeline24: embedding rel err {e_all:.2e} (worst image {e_row:.2e}); geocell argmax flips {flips}/{NP}; "
+              f"top-5 lists differing {top5_diff}/{NP}; top-40 lists differing in order {top40_diff}/{NP} (as sets {top40_set_diff}/{NP}); "
+              f"smallest reference logit margin {float(g['logit_margin'].min()):.3f}"]
+    bank = syn.make_bank(C, ppc, seed=bseed, empty_frac=0.01, max_members=maxm, center=g["center"], radius=float(g["radius"]))
+    results = {}
+    for tag in ("default", "evaluate"):
+        topk, T, mr = g[f"{tag}_params"]
+        refiner = ProtoRefiner(topk=int(topk), max_refinement=float(mr), temperature=float(T), bank=bank).eval()
+        _, llh, cell = refiner(out.embedding, initial_preds=out.preds_LLH, candidate_cells=out.top5_geocells.indices,
+                               candidate_probs=out.top5_geocells.values, quiet=True)
+        rc = int((cell.cpu().numpy() != g[f"{tag}_cell"]).sum())
+        rl = int((llh.cpu().numpy() != g[f"{tag}_LLH"]).any(axis=1).sum())
+        changed = int((g[f"{tag}_cell"] != g["preds_geocell"]).sum())
+        report.append(f"pipeline24 refine[{tag}: topk {int(topk)}, T {T}, {mr:g} km]: refined-cell flips {rc}/{NP}, (lng,lat) flips {rl}/{NP} "
+                      f"(the reference's refinement changes the cell of {changed}/{NP} panoramas)")
+        results[tag] = (rc, rl)
+    with capsys.disabled():
+        print("\n" + "\n".join(report))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "pipeline24_report.txt"), "w") as f:
+        f.write("\n".join(report) + "\n")
+    assert e_all < EMB_TOL and e_row < EMB_TOL
+    assert flips == 0, "geocell argmax differs from the reference"
+    assert np.array_equal(out.preds_LLH.cpu().numpy(), g["preds_LLH"])
+    assert top5_diff == 0
+    assert top40_set_diff <= 1, "evaluate()'s top-40 candidate SETS differ (boundary swap tolerated on at most one panorama)"
+    np.testing.assert_allclose(out.top5_geocells.values.cpu().numpy()[:, :5], g["topk_values"][:, :5], rtol=5e-2)
+    assert results["default"] == (0, 0), "refined cell / coordinates differ from the reference at the class defaults"
+    assert results["evaluate"] == (0, 0), "refined cell / coordinates differ from the reference at evaluate()'s settings"
+
+
+# ------------------------------------------------------------------------------------------------ trained-regime stress
+def test_vit24_trained_regime_both_ln_chains(env, golden_dir, monkeypatch, capsys):
+    """Massive-activation channels (|x| ~ 200) and rows with |mean|/std ~ 5 for the whole depth
+    (synthetic.make_vit_weights_trained_like): the LayerNorm-folded chain (16-bit copy of the UN-normalised row is the
+    MFMA operand) and the separate-LayerNorm chain must both stay within 1e-3 of the reference; no fp16 saturation."""
+    syn, ops, orc = env["syn"], env["ops"], env["orc"]
+    g = _gold(golden_dir, "vit24_trained.npz")
+    wseed, layers, _, n, pseed = [int(x) for x in g["meta"]]
+    assert float(g["absmax_layer12"]) > 100 and float(g["mean_over_std_median"]) > 4     # the fixture IS in that regime
+    sd = syn.make_vit_weights_trained_like(seed=wseed, layers=layers)
+    px = syn.make_pixels(n, seed=pseed).to(DEV)
+    ref = torch.from_numpy(g["embedding"])
+    errs, sats = {}, {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("PIGEON_LN_FOLD", fold)
+        enc = ops.VitEncoder(sd, device=0)
+        enc.saturation_check(True)
+        emb = enc.forward(px)
+        sats[fold] = enc.saturation_read()
+        errs[fold] = orc.rel_err(emb.cpu(), ref)
+        enc.close()
+    with capsys.disabled():
+        print(f"\nvit24_trained: rel err LN-fold {errs['1']:.2e}, separate LayerNorm {errs['0']:.2e}; "
+              f"fp16 saturated activations {sats['1']} / {sats['0']}")
+    with open(os.path.join(ROOT, "gpurun_out", "vit24_trained_report.txt"), "w") as f:
+        f.write(f"ln_fold {errs['1']:.3e} separate {errs['0']:.3e} sat {sats['1']} {sats['0']}\n")
+    assert errs["1"] < EMB_TOL and errs["0"] < EMB_TOL
+    assert sats["1"] == 0 and sats["0"] == 0
+
+
+def test_saturation_counter_counts_clamped_conversions(env):
+    syn, ops = env["syn"], env["ops"]
+    enc = ops.VitEncoder(syn.make_vit_weights(seed=11, layers=1), device=0)
+    enc.saturation_check(True)
+    px = syn.make_pixels(1, seed=5).to(DEV)
+    enc.forward(px)
+    assert enc.saturation_read() == 0
+    big = px.clone()
+    big[0, 0, :14, :14] = 1e6                                  # one patch of one channel beyond the fp16 range: 196 pixels clamp
+    enc.forward(big)
+    n = enc.saturation_read()
+    assert n >= 196, n
+    enc.saturation_check(False)
+    enc.forward(big)
+    assert enc.saturation_read() == 0
+    enc.close()
+
+
+# ------------------------------------------------------------------------------------------------ refiner edge cases
+def _refine_bank(env, g):
+    C, ppc, bseed = [int(x) for x in g["meta"][:3]]
+    return env["syn"].make_bank(C, ppc, seed=bseed, empty_frac=0.05)
+
+
+def test_refiner_veto_edge_matches_reference(env, golden_dir):
+    """Initial predictions 1000 km +- 0.3 .. 4 m from the proposed point: the veto decision hangs on the reference's
+    mixed-precision haversine (refined point float32 through deg2rad / cos, the rest float64)."""
+    from pigeon_amd.proto_refiner import ProtoRefiner
+    g = _gold(golden_dir, "refine.npz")
+    ref = ProtoRefiner(topk=5, max_refinement=1000, temperature=1.6, bank=_refine_bank(env, g)).eval()
+    _, llh, cell = ref(torch.from_numpy(g["embedding"]).to(DEV), initial_preds=torch.from_numpy(g["vetoedge_init"]).to(DEV),
+                       candidate_cells=torch.from_numpy(g["candidate_cells"]).to(DEV),
+                       candidate_probs=torch.from_numpy(g["candidate_probs"]).to(DEV), quiet=True)
+    assert np.array_equal(cell.cpu().numpy(), g["vetoedge_cell"])
+    assert np.array_equal(llh.cpu().numpy(), g["vetoedge_LLH"])
+    d = g["vetoedge_dist"]
+    assert 0 < int((d > 1000).sum()) < len(d)                                  # the fixture straddles the threshold
+
+
+def test_refiner_and_head_survive_nan_inputs(env, golden_dir):
+    """A NaN embedding must propagate like torch (NaN ranks as the maximum, first index wins) -- not fault the GPU."""
+    from pigeon_amd.proto_refiner import ProtoRefiner
+    ops, orc = env["ops"], env["orc"]
+    g = _gold(golden_dir, "refine.npz")
+    bank = _refine_bank(env, g)
+    emb = torch.from_numpy(g["embedding"]).clone()
+    emb[3, 17] = float("nan")
+    emb[9, :] = float("nan")
+    emb[11, 5] = float("inf")
+    args = dict(initial_preds=torch.from_numpy(g["initial_preds"]), candidate_cells=torch.from_numpy(g["candidate_cells"]),
+                candidate_probs=torch.from_numpy(g["candidate_probs"]))
+    ref = ProtoRefiner(topk=5, max_refinement=1000, temperature=1.6, bank=bank).eval()
+    _, llh, cell = ref(emb.to(DEV), quiet=True, **{k: v.to(DEV) for k, v in args.items()})
+    torch.cuda.synchronize()
+    _, o_llh, o_cell = orc.proto_refiner_forward(bank, emb, args["initial_preds"], args["candidate_cells"], args["candidate_probs"],
+                                                 5, 1.6, 1000)
+    assert torch.equal(cell.cpu(), o_cell)
+    assert np.array_equal(llh.cpu().numpy(), o_llh.numpy())
+    # head: NaN logits -> all-NaN probabilities; torch.argmax gives index 0
+    C, k = 300, 7
+    W, b = env["syn"].make_head_weights(C, seed=1)
+    cen = torch.from_numpy(env["syn"].make_geocells(C, seed=0))
+    e = torch.randn(4, 4, 1024)
+    e[2, 1, 100] = float("nan")
+    o = ops.head_forward(e.to(DEV), W.to(DEV), b.to(DEV), cen.to(DEV), k)
+    torch.cuda.synchronize()
+    r = orc.super_guessr_forward(W, b, cen, k, embedding=e)
+    assert torch.equal(o["preds_geocell"].cpu(), r["preds_geocell"]) and int(o["preds_geocell"][2]) == 0
+    ok = [0, 1, 3]
+    assert torch.equal(o["topk_indices"].cpu()[ok], r["topk"].indices[ok])
+    assert bool(torch.isnan(o["topk_values"][2]).all())
+    assert bool(((o["topk_indices"][2] >= 0) & (o["topk_indices"][2] < C)).all())
+
+
+# ------------------------------------------------------------------------------------------------ f4 against the reference
+def test_geo_kernels_match_reference_outputs(env, golden_dir):
+    """pg_haversine_matrix / pg_haversine_pairs / pg_smooth_labels against outputs of the reference's OWN functions
+    (preprocessing/geo_utils.py:40-74, preprocessing/utils.py:7-19) stored in tests/golden/geo.npz, and against the host
+    restatement oracle/geo_oracle.py on fresh inputs.  fp64 in: 1e-12 relative.  fp32 points: deg2rad / cos(lat) run in
+    fp32 on both sides; the device uses the correctly rounded cos, torch's CPU kernel is <= 1 ulp -- one fp32 ulp of
+    cos(lat) moves near-antipodal distances by up to 0.2 km, hence 0.5 km / 3e-5 there (stated, not bit-exact by contract)."""
+    from oracle import geo_oracle
+    from pigeon_amd import geo_utils
+    g = _gold(golden_dir, "geo.npz")
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    got = geo_utils.haversine_matrix(x.to(DEV), y.to(DEV).t())
+    assert got.dtype == torch.float64
+    np.testing.assert_allclose(got.cpu().numpy(), g["matrix_f64"], rtol=1e-12, atol=1e-9)
+    got32 = geo_utils.haversine_matrix(x.float().to(DEV), y.to(DEV).t())
+    np.testing.assert_allclose(got32.cpu().numpy(), g["matrix_f32x"], rtol=3e-5, atol=0.5)
+    n = x.shape[0]
+    p64 = geo_utils.haversine(x.to(DEV), y[:n].to(DEV))
+    np.testing.assert_allclose(p64.cpu().numpy(), g["pairs_f64y"], rtol=1e-12, atol=1e-9)
+    p32 = geo_utils.haversine(x.to(DEV), y[:n].float().to(DEV))
+    np.testing.assert_allclose(p32.cpu().numpy(), g["pairs_f32y"], rtol=3e-5, atol=0.5)
+    sm = geo_utils.smooth_labels(torch.from_numpy(g["smooth_in"]).to(DEV), float(g["smooth_constant"]))
+    np.testing.assert_allclose(sm.cpu().numpy(), g["smooth_out"], rtol=1e-11, atol=1e-300)
+    assert bool((sm[3] == 0).all()) and bool((sm[2] == 0).all()) and float(sm[4, 7]) == 0
+    # fresh, larger inputs against the restatement
+    gen = torch.Generator().manual_seed(8)
+    N, M = 37, 10000
+    x = torch.stack([torch.rand(N, generator=gen, dtype=torch.float64) * 360 - 180, torch.rand(N, generator=gen, dtype=torch.float64) * 180 - 90], 1)
+    y = torch.stack([torch.rand(M, generator=gen, dtype=torch.float64) * 360 - 180, torch.rand(M, generator=gen, dtype=torch.float64) * 180 - 90], 1)
+    got = geo_utils.haversine_matrix(x.to(DEV), y.to(DEV).t())
+    assert torch.allclose(got.cpu(), geo_oracle.haversine_matrix(x, y.t()), rtol=1e-12, atol=1e-9)
+    s = geo_utils.smooth_labels(got, 65)
+    assert torch.allclose(s.cpu(), geo_oracle.smooth_labels(got.cpu(), 65), rtol=1e-11, atol=1e-300)
+    with pytest.raises(env["lib"].PigeonHipError):
+        geo_utils.haversine_matrix(x, y.t())                                   # host tensors: no CPU fallback
+
+
+# ------------------------------------------------------------------------------------------------ prototype means
+def test_bank_means_on_gpu_match_torch(env):
+    from pigeon_amd import proto_refiner as pr
+    rng = np.random.default_rng(3)
+    train = rng.standard_normal((300, 1024)).astype(np.float32)
+    lens = rng.integers(0, 9, 120)
+    lens[::17] = rng.integers(16, 70, lens[::17].shape[0])
+    off = np.zeros(121, dtype=np.int64); np.cumsum(lens, out=off[1:])
+    idx = rng.integers(0, 300, int(off[-1])).astype(np.int64)
+    gpu = pr._segmented_mean_gpu(train, off, idx)
+    t = torch.from_numpy(train)
+    for p in range(120):
+        ix = torch.from_numpy(idx[off[p]:off[p + 1]])
+        want = t[ix].mean(dim=0).numpy() if len(ix) else np.zeros(1024, np.float32)
+        assert np.array_equal(gpu[p], want), p
+    t4 = torch.from_numpy(rng.standard_normal((50, 4, 1024)).astype(np.float32))
+    assert np.array_equal(pr._panel_mean_gpu(t4.numpy()), t4.mean(dim=1).numpy())
+
+
+# ------------------------------------------------------------------------------------------------ RCCL behind the C ABI
+def test_rccl_allgather_one_rank(env):
+    """pg_comm_unique_id / pg_comm_init_rank / pg_allgather(_many) / pg_comm_count / pg_comm_destroy with nranks = 1 (the
+    only size a 1-GPU box offers): RCCL loads, the communicator initialises, the gather is the identity copy."""
+    import ctypes as C
+    lib = env["lib"].load()
+    assert lib.pg_comm_rccl_version() > 20000
+    ident = C.create_string_buffer(128)
+    env["lib"].check(lib.pg_comm_unique_id(ident), "pg_comm_unique_id")
+    h = C.c_void_p()
+    torch.cuda.set_device(0)
+    env["lib"].check(lib.pg_comm_init_rank(C.byref(h), 1, ident.raw, 0), "pg_comm_init_rank")
+    n = C.c_int()
+    env["lib"].check(lib.pg_comm_count(h, C.byref(n)), "pg_comm_count")
+    assert n.value == 1
+    a = torch.randn(128, 4, 1024, device=DEV)
+    b = torch.arange(128 * 5, device=DEV, dtype=torch.int64).view(128, 5)
+    ra, rb = torch.zeros_like(a), torch.zeros_like(b)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    env["lib"].check(lib.pg_allgather(h, C.c_void_p(a.data_ptr()), C.c_void_p(ra.data_ptr()), a.numel() * 4, st), "pg_allgather")
+    torch.cuda.synchronize()
+    assert torch.equal(a, ra)
+    ra.zero_()
+    send = (C.c_void_p * 2)(a.data_ptr(), b.data_ptr())
+    recv = (C.c_void_p * 2)(ra.data_ptr(), rb.data_ptr())
+    nb = (C.c_size_t * 2)(a.numel() * 4, b.numel() * 8)
+    env["lib"].check(lib.pg_allgather_many(h, 2, send, recv, nb, st), "pg_allgather_many")
+    torch.cuda.synchronize()
+    assert torch.equal(a, ra) and torch.equal(b, rb)
+    env["lib"].check(lib.pg_comm_destroy(h), "pg_comm_destroy")
+
+
+# ------------------------------------------------------------------------------------------------ CLIPEmbedding checkpoints
+def test_clip_embedding_load_checkpoint_branches(env, tmp_path):
+    """reference models/clip_embedder.py:28-33: `load_checkpoint=True` copies a SuperGuessr-style checkpoint
+    (`base_model.` prefix, transformers 4.23.1 `vision_model.` nesting) over the base weights."""
+    from pigeon_amd.clip_embedder import CLIPEmbedding
+    syn, orc = env["syn"], env["orc"]
+    base = syn.make_vit_weights(seed=1, layers=1)
+    tuned = syn.make_vit_weights(seed=2, layers=1, affine_jitter=True)
+    px = syn.make_pixels(2, seed=9)
+    want = orc.clip_embedding(tuned, px)
+    ckpt = {"base_model.vision_model." + k: v for k, v in tuned.items()}
+    ckpt["cell_layer.weight"] = torch.zeros(3, 1024)
+    path = os.path.join(str(tmp_path), "StreetviewCLIP.model")
+    torch.save(ckpt, path)
+    a = CLIPEmbedding(path, device=DEV, load_checkpoint=True, state_dict=base)          # base weights + checkpoint copy (:30-32)
+    b = CLIPEmbedding(path, device=DEV, load_checkpoint=True)                           # checkpoint only
+    ea, eb = a(px.to(DEV)), b(px.to(DEV))
+    assert torch.equal(ea, eb)
+    assert orc.rel_err(ea.cpu(), want) < EMB_TOL
+    with pytest.raises(RuntimeError):
+        CLIPEmbedding("missing.model", device=DEV)
+
+
+# ------------------------------------------------------------------------------------------------ run.py / evaluate / embed
+def _run_main(monkeypatch, argv):
+    sys.path.insert(0, ROOT)
+    import importlib
+    monkeypatch.setattr(sys, "argv", ["run.py"] + argv)
+    import run
+    importlib.reload(run)                                     # argparse is module level, as in the reference
+    return run.main()
+
+
+def test_run_py_embed_synthetic(env, monkeypatch, tmp_path):
+    """`run.py embed random --synthetic 64` (BASELINE configs[0] shape, reference run.py:124-141 ->
+    preprocessing/embed.py): the written .npy files, read back the way the reference does, equal the oracle's embeddings."""
+    syn, orc = env["syn"], env["orc"]
+    out_dir = os.path.join(str(tmp_path), "emb")
+    _run_main(monkeypatch, ["embed", "random", "--synthetic", "64", "--layers", "2", "--out-dir", out_dir, "--yfcc"])
+    embeds = np.load(os.path.join(out_dir, "train.npy"))
+    indices = np.load(os.path.join(out_dir, "train_indices.npy"))
+    assert embeds.dtype == np.float32 and embeds.ndim == 3 and embeds.shape[-1] == 1024
+    arg = np.argsort(indices.flatten()[:64])                                   # dataset_preprocessing.py:299-300
+    e = torch.from_numpy(embeds.reshape((-1, 1024))[arg])
+    px = torch.stack([torch.randn((3, 336, 336), generator=torch.Generator().manual_seed(1234 + i)) for i in range(64)])
+    want = orc.clip_embedding(syn.make_vit_weights(seed=0, layers=2), px)
+    assert orc.rel_err(e, want) < EMB_TOL and orc.max_rel_err_rows(e, want) < EMB_TOL
+
+
+def test_run_py_evaluate_synthetic(env, monkeypatch, capsys):
+    """`run.py evaluate none --synthetic 16` (reference run.py:171-182 -> evaluation/evaluate.py:10-85 ->
+    training/train_eval_loop.py:35-161): the result dict against the oracle fed with the very model / bank evaluate() built."""
+    import pigeon_amd.evaluate as ev
+    orc = env["orc"]
+    captured = {}
+    real = ev.evaluate_model
+
+    def spy(model, dataset, metrics, train_args, refiner, *a, **k):
+        captured.update(model=model, dataset=dataset, refiner=refiner)
+        return real(model, dataset, metrics, train_args, refiner, *a, **k)
+
+    monkeypatch.setattr(ev, "evaluate_model", spy)
+    torch.manual_seed(0)
+    results = _run_main(monkeypatch, ["evaluate", "none", "--synthetic", "16", "--layers", "2", "--geocells", "300"])
+    model, refiner, ds = captured["model"], captured["refiner"], captured["dataset"]
+    assert model.num_candidates == 50 and refiner.topk == 40 and abs(float(refiner.temperature) - 0.6) < 1e-6   # evaluate.py:44,79-80
+    px = torch.stack([ds[i]["pixel_values"] for i in range(16)])
+    o = orc.super_guessr_forward(model.cell_layer.weight.data.cpu(), model.cell_layer.bias.data.cpu(), model.lla_geocells.data.cpu(),
+                                 50, vit_sd=model.base_model.state_dict(), pixel_values=px)
+    _, r_llh, r_cell = orc.proto_refiner_forward(refiner.host_bank, o["embedding"], o["preds_LLH"], o["topk"].indices,
+                                                 o["topk"].values, 40, 0.6, 100000)
+    assert np.array_equal(results["preds_geocells"], o["preds_geocell"].numpy())
+    assert np.array_equal(results["top5_geocells"][:, :5], o["topk"].indices.numpy()[:, :5])
+    assert np.array_equal(results["preds"], r_llh.numpy())
+    for key in ("Mean_km_error", "Median_km_error", "Under_1_km", "Under_2500_km", "Geoguessr_score", "Geocell_accuracy",
+                "Geocell_top5_accuracy"):
+        assert key in results, key
+    assert "SuperGuessr(" in capsys.readouterr().out
+
+
+def test_evaluate_model_on_precomputed_embeddings(env, tmp_path):
+    """evaluate_model() (training/train_eval_loop.py:77-140) over a labelled dataset of precomputed (4,1024) embeddings,
+    with and without a refiner; metrics through compute_geoguessr_metrics under the reference's keys."""
+    from oracle import geo_oracle
+    from pigeon_amd.evaluate import compute_geoguessr_metrics, evaluate_model
+    from pigeon_amd.proto_refiner import ProtoRefiner
+    from pigeon_amd.super_guessr import SuperGuessr
+    syn, orc = env["syn"], env["orc"]
+    C, n = 200, 37
+    model = SuperGuessr(None, panorama=True, num_candidates=10, geocell_path=_geocells_csv(tmp_path, C))
+    W, b = syn.make_head_weights(C, seed=3)
+    with torch.no_grad():
+        model.cell_layer.weight.copy_(W * 8); model.cell_layer.bias.copy_(b)
+    model.to(DEV)
+    gen = torch.Generator().manual_seed(2)
+    emb = torch.randn((n, 4, 1024), generator=gen)
+    labels = torch.stack([torch.rand(n, generator=gen, dtype=torch.float64) * 360 - 180, torch.rand(n, generator=gen, dtype=torch.float64) * 180 - 90], 1)
+    labels_clf = torch.randint(0, C, (n,), generator=gen)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self): return n
+        def __getitem__(self, i):
+            if isinstance(i, str):
+                return {"labels": labels.numpy(), "labels_clf": labels_clf.numpy()}[i]
+            return {"embedding": emb[i], "labels": labels[i], "labels_clf": labels_clf[i]}
+
+    bank = syn.make_bank(C, 12, seed=2, empty_frac=0.05)
+    refiner = ProtoRefiner(topk=5, bank=bank)
+    for ref in (None, refiner):
+        res = evaluate_model(model, DS(), compute_geoguessr_metrics, None, ref, batch_size=16)
+        o = orc.super_guessr_forward(W * 8, b, model.lla_geocells.data.cpu(), 10, embedding=emb)
+        want = o["preds_LLH"].numpy()
+        if ref is not None:
+            want = orc.proto_refiner_forward(bank, emb, o["preds_LLH"], o["topk"].indices, o["topk"].values, 5, 1.6, 1000)[1].numpy()
+        assert np.array_equal(res["preds"], want)
+        assert np.array_equal(res["preds_geocells"], o["preds_geocell"].numpy())
+        assert np.array_equal(res["top5_geocells"], o["topk"].indices.numpy())
+        m = geo_oracle.geoguessr_metrics(want, labels.numpy(), o["preds_geocell"].numpy(), labels_clf.numpy(), o["topk"].indices.numpy())
+        for k, v in m.items():
+            assert res[k] == v, k
+        assert model.training                                                   # `model.train()` at the end, as the reference
+
+
+def test_evaluate_entry_point(env, tmp_path, capsys):
+    """evaluate() (evaluation/evaluate.py:10-85): head checkpoint loading, the cached-bank refiner settings (40 / 100000 km /
+    T 0.6) and the first-build settings (20 / 10000 km / T 1) with the packed bank written next to it."""
+    from pigeon_amd import config as cfg
+    from pigeon_amd.clip_embedder import HipCLIPVisionModel
+    from pigeon_amd.evaluate import evaluate
+    syn, orc = env["syn"], env["orc"]
+    C = 120
+    geo = _geocells_csv(tmp_path, C)
+    W, b = syn.make_head_weights(C, seed=5)
+    head = os.path.join(str(tmp_path), "head.model")
+    torch.save({"cell_layer.weight": W * 8, "cell_layer.bias": b}, head)
+    vit_sd = syn.make_vit_weights(seed=11, layers=1, affine_jitter=True)
+    base = HipCLIPVisionModel(vit_sd, layers=1)
+    bank = syn.make_bank(C, 8, seed=2, empty_frac=0.05)
+    px = syn.make_pixels(4 * 6, seed=21, panorama=True)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self): return 6
+        def __getitem__(self, i):
+            if isinstance(i, str):
+                return {"labels": np.zeros((6, 2)), "labels_clf": np.zeros(6, dtype=np.int64)}[i]
+            return {"pixel_values": px[i], "labels": torch.zeros(2, dtype=torch.float64), "labels_clf": torch.tensor(0)}
+
+    res = evaluate(head, DS(), yfcc=False, landmarks=False, base_model=base, refine=True, geocell_path=geo, bank=bank)
+    out = capsys.readouterr().out
+    assert "topk\t\t= 40" in out and "max_refinement\t= 100000" in out
+    o = orc.super_guessr_forward(W * 8, b, torch.from_numpy(syn.make_geocells(C, seed=0)), 50, vit_sd=vit_sd, pixel_values=px)
+    assert np.array_equal(res["preds_geocells"], o["preds_geocell"].numpy())
+    r = orc.proto_refiner_forward(bank, o["embedding"], o["preds_LLH"], o["topk"].indices, o["topk"].values, 40, 0.6, 100000)
+    assert np.array_equal(res["preds"], r[1].numpy())
+    # first-build branch: CSV + HF dataset -> ProtoRefiner(20, False, 10000, temperature=1), packed bank cached
+    csv, ds = os.path.join(str(tmp_path), "protos.csv"), os.path.join(str(tmp_path), "hf")
+    syn.write_bank_reference_files(bank, csv, ds)
+    old = cfg.PROTO_MODEL_PATH
+    cfg.PROTO_MODEL_PATH = os.path.join(str(tmp_path), "refiner", "proto.refiner")
+    try:
+        res2 = evaluate(head, DS(), yfcc=False, landmarks=False, base_model=base, refine=True, geocell_path=geo,
+                        proto_path=csv, dataset_path=ds)
+        out = capsys.readouterr().out
+        assert "topk\t\t= 20" in out and os.path.exists(cfg.PROTO_MODEL_PATH + ".npz")
+        r2 = orc.proto_refiner_forward(bank, o["embedding"], o["preds_LLH"], o["topk"].indices, o["topk"].values, 20, 1.0, 10000)
+        assert np.array_equal(res2["preds"], r2[1].numpy())
+        res3 = evaluate(head, DS(), yfcc=False, landmarks=False, base_model=base, refine=True, geocell_path=geo)   # cached bank
+        assert np.array_equal(res3["preds"], res["preds"])
+    finally:
+        cfg.PROTO_MODEL_PATH = old

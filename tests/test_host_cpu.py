@@ -1,0 +1,226 @@
+"""Host-side logic of the kept entry points, on CPU (no GPU, no compute calls into the library):
+
+  SuperGuessr.load_state / load_state_dict      reference models/super_guessr.py:222-238, models/utils.py:24-45
+  bank_from_protos / HostBank.save|load          reference evaluation/evaluate.py:66-75 (pickled `refiner.protos`)
+  compute_geoguessr_metrics                      reference evaluation/metrics.py:89-181
+  shard_batches / compute_embeddings on disk     reference preprocessing/embed.py:16-43,68, dataset_preprocessing.py:294-300
+  evaluate() argument handling                   reference evaluation/evaluate.py:42-47
+Where the reference tree is present (/root/reference, authoring container) the inputs come from the reference's own
+classes through oracle/reference_loader.py; the committed fixtures (tests/golden/geo.npz) cover the rest.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_loader
+from pigeon_amd import synthetic
+
+needs_reference = pytest.mark.skipif(not reference_loader.available(), reason="reference tree not present")
+
+
+def _geo_csv(tmp_path, C=37):
+    p = os.path.join(str(tmp_path), "geocells.csv")
+    synthetic.write_geocell_csv(p, synthetic.make_geocells(C, seed=0))
+    return p
+
+
+# ------------------------------------------------------------------------------------------------ checkpoints
+def _vit_sd(layers=1, seed=3):
+    return synthetic.make_vit_weights(seed=seed, layers=layers, affine_jitter=True)
+
+
+@pytest.mark.parametrize("layout", ["flat", "vision_model"])
+def test_super_guessr_load_state_copies_head_and_base(tmp_path, layout, capsys):
+    """A full SuperGuessr checkpoint, in the transformers >= 5 (flat) and the 4.23.1 (`base_model.vision_model.*`,
+    reference env.yml:60) key layouts, lands in cell_layer AND in the HIP encoder's weights."""
+    from pigeon_amd.clip_embedder import HipCLIPVisionModel
+    from pigeon_amd.super_guessr import SuperGuessr
+    geo = _geo_csv(tmp_path)
+    model = SuperGuessr(HipCLIPVisionModel(_vit_sd(seed=3), layers=1), panorama=True, freeze_base=True, geocell_path=geo)
+    src = _vit_sd(seed=4)
+    g = torch.Generator().manual_seed(0)
+    ckpt = {"cell_layer.weight": torch.randn((37, 1024), generator=g), "cell_layer.bias": torch.randn((37,), generator=g),
+            "lla_geocells": torch.zeros((37, 2), dtype=torch.float64)}
+    pre = "base_model." + ("vision_model." if layout == "vision_model" else "")
+    ckpt.update({pre + k: v for k, v in src.items()})
+    ckpt["hedge_layer.weight"] = torch.zeros(3)                       # unknown name: skipped with the reference's message
+    path = os.path.join(str(tmp_path), "full.model")
+    torch.save(ckpt, path)
+    model.load_state(path)
+    assert "Parameter hedge_layer.weight not in model's state." in capsys.readouterr().out
+    assert torch.equal(model.cell_layer.weight.data, ckpt["cell_layer.weight"])
+    assert torch.equal(model.cell_layer.bias.data, ckpt["cell_layer.bias"])
+    own = model.base_model.state_dict()
+    for k, v in src.items():
+        assert torch.equal(own[k], v), k
+    assert bool((model.lla_geocells.data == 0).all())
+
+
+def test_load_state_raises_when_nothing_matches(tmp_path):
+    from pigeon_amd.super_guessr import SuperGuessr
+    model = SuperGuessr(None, panorama=True, geocell_path=_geo_csv(tmp_path))
+    path = os.path.join(str(tmp_path), "bad.model")
+    torch.save({"totally.unrelated": torch.zeros(2)}, path)
+    with pytest.raises(KeyError, match="none of the 1 parameters"):
+        model.load_state(path)
+
+
+@pytest.mark.parametrize("prefix,embedder", [("", False), ("vision_model.", False), ("base_model.", True),
+                                             ("base_model.vision_model.", True)])
+def test_load_state_dict_layouts(prefix, embedder):
+    """models/utils.py:24-45 incl. the embedder=True strip (:34-35) used by CLIPEmbedding (clip_embedder.py:30-32)."""
+    from pigeon_amd.clip_embedder import HipCLIPVisionModel
+    from pigeon_amd.utils import load_state_dict
+    m = HipCLIPVisionModel(_vit_sd(seed=3), layers=1)
+    src = _vit_sd(seed=5)
+    n = load_state_dict(m, {prefix + k: v for k, v in src.items()}, embedder=embedder)
+    assert n == len(src)
+    for k, v in src.items():
+        assert torch.equal(m.state_dict()[k], v), k
+    with pytest.raises(KeyError):
+        load_state_dict(m, {"nope." + k: v for k, v in src.items()})
+    # HF-style entry point of the module itself
+    m2 = HipCLIPVisionModel(_vit_sd(seed=3), layers=1)
+    m2.load_state_dict({"vision_model." + k: v for k, v in src.items()})
+    assert torch.equal(m2.state_dict()["encoder.layers.0.mlp.fc1.weight"], src["encoder.layers.0.mlp.fc1.weight"])
+
+
+@needs_reference
+def test_load_state_reads_a_checkpoint_written_by_the_reference(tmp_path):
+    """torch.save(reference SuperGuessr(HF CLIPVisionModel).state_dict()) -> our load_state: every tensor arrives."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    from pigeon_amd.clip_embedder import HipCLIPVisionModel
+    from pigeon_amd.super_guessr import SuperGuessr
+    geo = _geo_csv(tmp_path)
+    ns = reference_loader.load(geo, "unused.csv", "unused_dir")
+    cfg = CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=1, num_attention_heads=16,
+                           image_size=336, patch_size=14, projection_dim=768)
+    torch.manual_seed(7)
+    ref_model = ns.SuperGuessr(CLIPVisionModel(cfg), panorama=True, freeze_base=True, num_candidates=5)
+    path = os.path.join(str(tmp_path), "ref.model")
+    torch.save(ref_model.state_dict(), path)
+    ours = SuperGuessr(HipCLIPVisionModel(_vit_sd(seed=3), layers=1), panorama=True, freeze_base=True, geocell_path=geo)
+    ours.load_state(path)
+    ref_sd = ref_model.state_dict()
+    mine = ours.state_dict()
+    n_base = 0
+    for k, v in ref_sd.items():
+        kk = k.replace("base_model.vision_model.", "base_model.")
+        if not v.is_floating_point():
+            continue
+        assert kk in mine, k
+        assert torch.equal(mine[kk].cpu(), v), k
+        n_base += kk.startswith("base_model.")
+    assert n_base >= 20
+
+
+# ------------------------------------------------------------------------------------------------ prototype bank formats
+def _arrays_equal(a, b):
+    from pigeon_amd.proto_refiner import HostBank
+    for f in HostBank.FIELDS:
+        x, y = np.asarray(getattr(a, f)), np.asarray(getattr(b, f))
+        assert x.shape == y.shape and np.array_equal(x, y), f
+
+
+def test_host_bank_save_load_roundtrip(tmp_path):
+    from pigeon_amd.proto_refiner import HostBank
+    bank = synthetic.make_bank(23, 5, seed=4, empty_frac=0.1)
+    hb = HostBank(**{f: getattr(bank, f) for f in HostBank.FIELDS})
+    p = os.path.join(str(tmp_path), "proto.refiner.npz")
+    hb.save(p)
+    back = HostBank.load(p)
+    _arrays_equal(hb, back)
+    assert back.num_cells == 23 and back.proto_emb.dtype == np.float32 and back.cell_off.dtype == np.int64
+
+
+@needs_reference
+def test_bank_from_protos_on_the_references_own_protos(tmp_path):
+    """`refiner.protos` as the REFERENCE builds it (list of per-cell HF Datasets / None, the object
+    evaluation/evaluate.py:66-75 pickles) -> bank_from_protos -> exactly the CSR bank the files were written from."""
+    from pigeon_amd.proto_refiner import bank_from_protos
+    C = 30
+    bank = synthetic.make_bank(C, 6, seed=2, empty_frac=0.1)
+    proto_csv = os.path.join(str(tmp_path), "protos.csv")
+    ds_dir = os.path.join(str(tmp_path), "hf_train")
+    synthetic.write_bank_reference_files(bank, proto_csv, ds_dir)
+    ns = reference_loader.load(_geo_csv(tmp_path, C), proto_csv, ds_dir)
+    ref = ns.ProtoRefiner(topk=5, proto_path=proto_csv, dataset_path=ds_dir)
+    assert sum(p is None for p in ref.protos) == int((np.diff(bank.cell_off) == 0).sum()) > 0
+    hb = bank_from_protos(ref.protos, ds_dir)
+    _arrays_equal(hb, bank)
+
+
+# ------------------------------------------------------------------------------------------------ metrics
+def test_compute_geoguessr_metrics_matches_reference_fixture(golden_dir):
+    """tests/golden/geo.npz holds the outputs of the reference's own percentage_within_radius / geoguessr_score /
+    topk_geocell_accuracy / haversine_np (evaluation/metrics.py, preprocessing/geo_utils.py) on 500 seeded predictions."""
+    from pigeon_amd.evaluate import compute_geoguessr_metrics
+    from pigeon_amd.geo_utils import haversine_np
+    g = np.load(os.path.join(golden_dir, "geo.npz"))
+    preds, labels = g["metric_preds"], g["metric_labels"]
+    assert np.array_equal(haversine_np(preds, labels), g["metric_distances"])
+    res = compute_geoguessr_metrics((preds, g["metric_cell_preds"], None, None, None, g["metric_top5"], labels,
+                                     g["metric_cell_labels"], None, None, None))
+    want = dict(zip([str(k) for k in g["metric_names"]], g["metric_values"]))
+    for k, v in want.items():
+        assert res[k] == v, (k, res[k], v)
+    assert res["Geocell_accuracy"] == float(np.mean(g["metric_cell_preds"] == g["metric_cell_labels"]))
+    # one-hot labels are accepted like the reference does (metrics.py:152-158)
+    oh = np.zeros((len(preds), 50)); oh[np.arange(len(preds)), g["metric_cell_labels"]] = 1
+    res2 = compute_geoguessr_metrics((preds, g["metric_cell_preds"], None, None, None, g["metric_top5"], labels, oh,
+                                      None, None, None))
+    assert res2["Geocell_top5_accuracy"] == res["Geocell_top5_accuracy"]
+
+
+@needs_reference
+def test_metrics_against_live_reference_functions():
+    from pigeon_amd import evaluate as ev
+    mt = reference_loader.load_metrics()
+    rng = np.random.default_rng(5)
+    d = np.exp(rng.uniform(-3, 9, 1000))
+    assert ev.geoguessr_score(d) == mt.geoguessr_score(d)
+    for km in (1, 25, 750):
+        assert ev.percentage_within_radius(d, km) == mt.percentage_within_radius(d, km)
+    lab, top = rng.integers(0, 9, 200), rng.integers(0, 9, (200, 5))
+    assert ev.topk_geocell_accuracy(lab, top) == mt.topk_geocell_accuracy(lab, top)
+
+
+# ------------------------------------------------------------------------------------------------ embedding files
+def test_shard_batches_pads_ragged_last_batch_like_accelerate():
+    """accelerate BatchSamplerShard(split_batches=False, even_batches=True): 10 samples, batch 3, 2 ranks."""
+    from pigeon_amd.distributed import shard_batches
+    bat = [(torch.arange(i, min(i + 3, 10)).float()[:, None], torch.arange(i, min(i + 3, 10))) for i in range(0, 10, 3)]
+    r0 = [b[1].tolist() for b in shard_batches(bat, 0, 2)]
+    r1 = [b[1].tolist() for b in shard_batches(bat, 1, 2)]
+    assert r0 == [[0, 1, 2], [6, 7, 8]] and r1 == [[3, 4, 5], [9, 0, 1]]
+    # 11 samples, 3 ranks: short batch completed, then two filler batches cut from the wrap-around stream
+    bat = [{"x": torch.arange(i, min(i + 3, 11)).float(), "index": torch.arange(i, min(i + 3, 11))} for i in range(0, 11, 3)]
+    got = [[b["index"].tolist() for b in shard_batches(bat, r, 3)] for r in range(3)]
+    assert got == [[[0, 1, 2], [9, 10, 0]], [[3, 4, 5], [1, 2, 3]], [[6, 7, 8], [4, 5, 6]]]
+    assert all(b["x"].shape[0] == 3 for r in range(3) for b in shard_batches(bat, r, 3))
+
+
+def test_compute_embeddings_writes_plain_numeric_arrays(tmp_path):
+    """np.load WITHOUT allow_pickle, as the reference's reader does (dataset_preprocessing.py:294-300), incl. a ragged
+    final batch in the single-process case."""
+    from pigeon_amd.distributed import Communicator
+    from pigeon_amd.embed import compute_embeddings
+    n, bs = 11, 4
+    data = [(torch.arange(i, min(i + bs, n), dtype=torch.float32)[:, None].repeat(1, 1024), torch.arange(i, min(i + bs, n)))
+            for i in range(0, n, bs)]
+    compute_embeddings("val", lambda px: px + 0.5, data, Communicator(), out_dir=str(tmp_path))
+    embeds = np.load(os.path.join(str(tmp_path), "val.npy"))                   # no allow_pickle
+    indices = np.load(os.path.join(str(tmp_path), "val_indices.npy"))
+    assert embeds.dtype == np.float32 and embeds.shape == (3, 4, 1024) and indices.dtype == np.int64
+    arg = np.argsort(indices.flatten())[:n]                                    # the reference reader's reorder
+    e = embeds.reshape((-1, 1024))[arg]
+    assert np.array_equal(e[:, 0], np.arange(n, dtype=np.float32) + 0.5)
+
+
+def test_evaluate_raises_on_missing_checkpoint(tmp_path):
+    from pigeon_amd.evaluate import evaluate
+    with pytest.raises(FileNotFoundError):
+        evaluate(os.path.join(str(tmp_path), "missing.model"), [], yfcc=False, landmarks=False, refine=False,
+                 geocell_path=_geo_csv(tmp_path))
