@@ -152,7 +152,7 @@ typedef struct pg_bank {
  *   init_llh   DEVICE (B,2) float64 initial [lng,lat] predictions
  *   cand       DEVICE (B,k) int64 candidate geocells;  cand_prob DEVICE (B,k) fp32 (NULL -> [1,0,0,...], :143-145)
  *   topk <= k, topk <= 64
- *   scratch    DEVICE >= B*topk*4 floats (score, lng, lat, pad per candidate)
+ *   scratch    DEVICE >= B*topk*4 floats; on return (score, lng, lat, bank rows streamed) per (query, candidate)
  *   out_llh    DEVICE (B,2) fp32; out_cell DEVICE (B) int64; out_choice DEVICE (B) int32 (index of the chosen
  *              candidate, the reference's guess_index, proto_refiner.py:220)                              */
 int pg_refine_forward(const pg_bank* bank, const float* q, int B, int P, const double* init_llh,

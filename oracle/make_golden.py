@@ -382,8 +382,15 @@ def main():
         import datasets as _ds
         _ds.disable_progress_bar()
         needed = sorted(set(out.top5_geocells.indices.flatten().tolist()))
-        for c in needed:
-            ref.protos[c] = ref._get_prototypes(c)
+        # (collected in a separate list and attached afterwards: `datasets` fingerprints the mapped method -- i.e. pickles the
+        # whole refiner including .protos -- on every call, which would make the loop quadratic)
+        built = [None] * C
+        t0 = time.time()
+        for n_done, c in enumerate(needed):
+            built[c] = ref._get_prototypes(c)
+            if n_done % 200 == 0:
+                print(f"pipeline24: prototypes of {n_done}/{len(needed)} candidate cells, {time.time() - t0:.0f} s", flush=True)
+        ref.protos = built
         save = dict(embedding=emb.numpy(), head_bias=bias.numpy(), center=center.numpy(),
                     meta=np.array([0, 24, NP, 1234, C, 4, 2, 3]), head_scale=np.array(scale), radius=np.array(radius),
                     preds_LLH=out.preds_LLH.numpy(), preds_geocell=out.preds_geocell.numpy(),

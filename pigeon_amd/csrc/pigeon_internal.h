@@ -40,7 +40,7 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
 int pg_layernorm_launch(const float* x, const float* gamma, const float* beta, void* y, int out_dtype,
                         int64_t rows, float eps, hipStream_t s);
 int pg_preln_launch(float* x, const float* cls, const float* pos0, const float* gamma, const float* beta,
-                    int64_t rows, float eps, hipStream_t s);
+                    int64_t rows, float eps, hipStream_t s, void* x16 = nullptr, int x16_dtype = 0, float* rowstat = nullptr);
 int pg_im2col_launch(const void* pixels, int pix_dtype, void* out, int out_dtype, int n_images, hipStream_t s);
 int pg_token_mean_launch(const float* x, float* out, int n_images, hipStream_t s);
 int pg_cast_f32_launch(const float* x, void* y, int out_dtype, int64_t n, hipStream_t s);

@@ -46,7 +46,8 @@ __device__ __forceinline__ bool nan_aware_less(float v, long long i, float bv, l
     return v < bv || (v == bv && i < bi);
 }
 
-// scratch layout per (b, j): [score, lng, lat, unused]
+// scratch layout per (b, j): [score, lng, lat, rows] -- rows = bank rows this (query, candidate) streamed (prototypes of the
+// cell + members of the chosen cluster when count > 1): the algorithmic-bytes bookkeeping of the benchmark (4096 B each)
 __global__ __launch_bounds__(256) void refine_candidates_kernel(pg_bank bank, const float* __restrict__ q, int P,
                                                                 const int64_t* __restrict__ cand, int k, int topk,
                                                                 float* __restrict__ scratch) {
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void refine_candidates_kernel(pg_bank bank, co
     }
     const int cnt = bank.proto_count[pid];
     if (cnt == 1) {                                         // proto_refiner.py:245-246
-        if (tid == 0) { outp[1] = bank.proto_lnglat[2 * pid]; outp[2] = bank.proto_lnglat[2 * pid + 1]; outp[3] = 0.f; }
+        if (tid == 0) { outp[1] = bank.proto_lnglat[2 * pid]; outp[2] = bank.proto_lnglat[2 * pid + 1]; outp[3] = (float)(e - s); }
         return;
     }
 
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void refine_candidates_kernel(pg_bank bank, co
             tr = tr < 0 ? 0 : (tr >= bank.num_train ? bank.num_train - 1 : tr);
             lng = bank.train_lnglat[2 * tr]; lat = bank.train_lnglat[2 * tr + 1];
         }
-        outp[1] = lng; outp[2] = lat; outp[3] = 0.f;
+        outp[1] = lng; outp[2] = lat; outp[3] = (float)((e - s) + (me - ms));
     }
 }
 

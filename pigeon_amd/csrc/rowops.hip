@@ -68,9 +68,14 @@ int pg_layernorm_launch(const float* x, const float* gamma, const float* beta, v
 // Row r of x is token t = r % 577 of image r / 577.  Patch rows already hold conv + position (written by the
 // patch GEMM epilogue); row t == 0 is synthesised here as class_embedding + position_embedding[0]
 // (modeling_clip.py:212-217), then every row gets pre_layrnorm.
+// STAT (LayerNorm-folded chain): the same pass also emits what layer 0's LN1 fold needs from the NEW row -- its 16-bit copy
+// (the QKV GEMM's A operand) and (rstd, mean*rstd), two-pass like rowstat_cast_kernel (bit-identical to running that kernel
+// afterwards, minus one 4 KB/row read of the residual stream).
+template <typename T, bool STAT>
 __global__ __launch_bounds__(256) void preln_kernel(float* __restrict__ x, const float* __restrict__ cls,
                                                     const float* __restrict__ pos0, const float* __restrict__ gamma,
-                                                    const float* __restrict__ beta, int64_t rows, float eps) {
+                                                    const float* __restrict__ beta, int64_t rows, float eps,
+                                                    uint16_t* __restrict__ x16, float* __restrict__ rowstat) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -102,14 +107,38 @@ __global__ __launch_bounds__(256) void preln_kernel(float* __restrict__ x, const
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
         *(f32x4*)(xr + c) = o;
+        v[i] = o;
+    }
+    if (STAT) {
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s2 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        const float mean2 = wave_sum(s2) * (1.0f / VIT_HIDDEN);
+        float q2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean2; q2 += d * d; }
+        const float rstd2 = 1.0f / sqrtf(wave_sum(q2) * (1.0f / VIT_HIDDEN) + eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x2 pk;
+            pk[0] = pack16x2<T>(v[i][0], v[i][1]); pk[1] = pack16x2<T>(v[i][2], v[i][3]);
+            *(u32x2*)(x16 + row * VIT_HIDDEN + i * 256 + lane * 4) = pk;
+        }
+        if (lane == 0) { rowstat[2 * row] = rstd2; rowstat[2 * row + 1] = mean2 * rstd2; }
     }
 }
 
 int pg_preln_launch(float* x, const float* cls, const float* pos0, const float* gamma, const float* beta,
-                    int64_t rows, float eps, hipStream_t s) {
+                    int64_t rows, float eps, hipStream_t s, void* x16, int x16_dtype, float* rowstat) {
     if (rows <= 0) return PG_OK;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-    hipLaunchKernelGGL(preln_kernel, grid, block, 0, s, x, cls, pos0, gamma, beta, rows, eps);
+    if (!x16) hipLaunchKernelGGL((preln_kernel<T_F16, false>), grid, block, 0, s, x, cls, pos0, gamma, beta, rows, eps, nullptr, nullptr);
+    else if (!rowstat) { pg_set_error("pre_layernorm: x16 without rowstat"); return PG_EINVAL; }
+    else if (x16_dtype == PG_DTYPE_F16) hipLaunchKernelGGL((preln_kernel<T_F16, true>), grid, block, 0, s, x, cls, pos0, gamma, beta, rows, eps, (uint16_t*)x16, rowstat);
+    else if (x16_dtype == PG_DTYPE_BF16) hipLaunchKernelGGL((preln_kernel<T_BF16, true>), grid, block, 0, s, x, cls, pos0, gamma, beta, rows, eps, (uint16_t*)x16, rowstat);
+    else { pg_set_error("pre_layernorm: bad 16-bit dtype %d", x16_dtype); return PG_EINVAL; }
     return pg_check_launch("pre_layernorm");
 }
 

@@ -330,7 +330,7 @@ static int vit_forward_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n
     { ProfScope p(h, s, 4);
       RC(pg_gemm_launch(dt, big, VIT_PATCH_KPAD, h->wpatch, VIT_PATCH_KPAD, nullptr, X, VIT_HIDDEN, n * VIT_PATCHES, VIT_HIDDEN, VIT_PATCH_KPAD,
                         EPI_PATCH, 1.f, 0, h->pos, 0, s)); }
-    { ProfScope p(h, s, 6); RC(pg_preln_launch(X, h->cls, h->pos, h->preg, h->preb, M, eps, s)); }
+    if (!h->ln_fold) { ProfScope p(h, s, 6); RC(pg_preln_launch(X, h->cls, h->pos, h->preg, h->preb, M, eps, s)); }
     if (h->ln_fold) {
         // LayerNorm folded into the GEMM that consumes it: the residual GEMMs (out_proj, fc2) emit, next to the fp32
         // residual row, its 16-bit copy and per-slice partial (sum, sum of squares); a per-row finalize turns those into
@@ -343,7 +343,8 @@ static int vit_forward_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n
         float* rsA = (float*)((char*)statpart + align_up((size_t)M * (VIT_HIDDEN / 64) * 8, 256));
         float* rsB = (float*)((char*)rsA + align_up((size_t)M * 8, 256));
         const int slots = VIT_HIDDEN / 64;
-        { ProfScope p(h, s, 6); RC(pg_rowstat_cast_launch(X, Xn, dt, rsA, M, eps, s)); }
+        // class token + position + pre_layrnorm, and in the same pass the 16-bit copy + row statistics layer 0's folded LN1 needs
+        { ProfScope p(h, s, 6); RC(pg_preln_launch(X, h->cls, h->pos, h->preg, h->preb, M, eps, s, Xn, dt, rsA)); }
         SAT(Xn, M, VIT_HIDDEN, VIT_HIDDEN);
         for (int l = 0; l < h->cfg.layers; ++l) {
             const LayerW& L = h->layers[l];

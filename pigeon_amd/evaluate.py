@@ -168,6 +168,7 @@ class PanoramaPipeline:
     def __init__(self, model: SuperGuessr, refiner: Optional[ProtoRefiner], comm: Optional[Communicator] = None):
         self.model, self.refiner = model, refiner
         self.comm = comm or Communicator()
+        self.refine_events = None        # set to a list to collect (start, end) stream events around the refinement launches
 
     @torch.no_grad()
     def step(self, pixel_values: torch.Tensor, index: Optional[torch.Tensor] = None):
@@ -181,7 +182,13 @@ class PanoramaPipeline:
         if self.refiner is not None:
             r, W = self.comm.rank, self.comm.world_size
             sl = slice(r * B, (r + 1) * B)                                        # this rank's slice of the gathered batch
+            if self.refine_events is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             _, ref_llh, ref_cell = self.refiner(emb[sl], initial_preds=llh[sl], candidate_cells=topi[sl],
                                                 candidate_probs=topv[sl], quiet=True)
+            if self.refine_events is not None:
+                ev[1].record()
+                self.refine_events.append(ev)
             res['refined_LLH'], res['refined_geocell'] = ref_llh, ref_cell
         return res

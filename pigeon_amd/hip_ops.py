@@ -375,8 +375,10 @@ class DeviceBank:
 
 
 def refine_forward(bank: DeviceBank, q: torch.Tensor, init_llh: torch.Tensor, cand: torch.Tensor,
-                   cand_prob: Optional[torch.Tensor], topk: int, temperature: float, max_refine_km: float):
-    """Returns (preds_LLH (B,2) f32, preds_geocell (B,) i64, choice (B,) i32)."""
+                   cand_prob: Optional[torch.Tensor], topk: int, temperature: float, max_refine_km: float,
+                   return_scratch: bool = False):
+    """Returns (preds_LLH (B,2) f32, preds_geocell (B,) i64, choice (B,) i32) [, scratch (B,topk,4) f32 =
+    (score, lng, lat, bank rows streamed) per (query, candidate)]."""
     _dev(q, torch.float32); _dev(init_llh, torch.float64); _dev(cand, torch.int64)
     if cand_prob is not None:
         _dev(cand_prob, torch.float32)
@@ -391,4 +393,6 @@ def refine_forward(bank: DeviceBank, q: torch.Tensor, init_llh: torch.Tensor, ca
     check(load().pg_refine_forward(C.byref(bank.struct), _p(q), B, P, _p(init_llh), _p(cand), _p(cand_prob), k, topk,
                                    float(temperature), float(max_refine_km), _p(scratch), _p(out_llh), _p(out_cell),
                                    _p(out_choice), _stream()), "pg_refine_forward")
+    if return_scratch:
+        return out_llh, out_cell, out_choice, scratch
     return out_llh, out_cell, out_choice

@@ -194,6 +194,15 @@ class ProtoRefiner(nn.Module):
         self._dbank = None
         self._device = device
 
+    def _temperature_value(self) -> float:
+        """float(temperature) without a device sync per call: the Parameter is read back once and re-read only when its
+        storage was replaced or modified in place (version counter)."""
+        t = self.temperature
+        key = (t.data_ptr(), t._version)
+        if getattr(self, '_temp_key', None) != key:
+            self._temp_key, self._temp_val = key, float(t.data.item())
+        return self._temp_val
+
     def _device_bank(self, device) -> hip_ops.DeviceBank:
         if self._dbank is None:
             self._dbank = hip_ops.DeviceBank(self.host_bank, device=device)
@@ -224,9 +233,9 @@ class ProtoRefiner(nn.Module):
             init = initial_preds.to(dev, torch.float64).contiguous()
             cand = candidate_cells.to(dev, torch.int64).contiguous()
             probs = None if candidate_probs is None else candidate_probs.to(dev, torch.float32).contiguous()
-            preds_LLH, preds_geocell, guess_index = hip_ops.refine_forward(
+            preds_LLH, preds_geocell, guess_index, self.last_scratch = hip_ops.refine_forward(
                 self._device_bank(dev), q, init, cand, probs, self.topk,
-                float(self.temperature.data.item()), float(self.max_refinement))
+                self._temperature_value(), float(self.max_refinement), return_scratch=True)
             if not quiet:                                          # :224-227 (costs one D2H sync, like the reference)
                 perc_changed = (guess_index != 0).sum() / guess_index.size(0)
                 print(f'Changed geocell predictions of {perc_changed * 100:.1f} % of guesses.')

@@ -103,3 +103,66 @@ def test_haversine_known_values():
     y = torch.tensor([[90.0, 0.0], [180.0, 0.0]], dtype=torch.float64)
     km = orc.haversine(x, y)
     np.testing.assert_allclose(km.numpy(), [np.pi / 2 * 6378.137, np.pi * 6378.137], rtol=1e-12)
+
+
+def test_refiner_veto_edge_matches_reference(golden_dir):
+    """Initial predictions within a few metres of max_refinement from the proposed point: pins the oracle's veto to the
+    reference's mixed-precision haversine (refined point float32, proto_refiner.py:198-202)."""
+    g = _load(golden_dir, "refine.npz")
+    C, ppc, bseed = [int(x) for x in g["meta"]]
+    bank = synthetic.make_bank(C, ppc, seed=bseed, empty_frac=0.05)
+    _, llh, cell = orc.proto_refiner_forward(bank, torch.from_numpy(g["embedding"]), torch.from_numpy(g["vetoedge_init"]),
+                                             torch.from_numpy(g["candidate_cells"]), torch.from_numpy(g["candidate_probs"]), 5, 1.6, 1000)
+    assert np.array_equal(cell.numpy(), g["vetoedge_cell"]) and np.array_equal(llh.numpy(), g["vetoedge_LLH"])
+
+
+def test_geo_oracle_matches_reference_functions(golden_dir):
+    """oracle/geo_oracle.py against outputs of the reference's own haversine / haversine_matrix / smooth_labels."""
+    from oracle import geo_oracle
+    g = _load(golden_dir, "geo.npz")
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    assert np.array_equal(geo_oracle.haversine_matrix(x, y.t()).numpy(), g["matrix_f64"])
+    # fp32 points: torch's CPU cos is vectorised (Sleef) on full vectors and scalar on chunk tails, so the last ulp of
+    # cos(lat) depends on the thread partition; one fp32 ulp of cos(lat) moves near-antipodal distances by up to 0.2 km
+    np.testing.assert_allclose(geo_oracle.haversine_matrix(x.float(), y.t()).numpy(), g["matrix_f32x"], rtol=3e-5, atol=0.5)
+    n = x.shape[0]
+    np.testing.assert_allclose(geo_oracle.haversine(x, y[:n].float()).numpy(), g["pairs_f32y"], rtol=3e-5, atol=0.5)
+    assert np.array_equal(geo_oracle.haversine(x, y[:n]).numpy(), g["pairs_f64y"])
+    assert np.array_equal(geo_oracle.smooth_labels(torch.from_numpy(g["smooth_in"]), float(g["smooth_constant"])).numpy(), g["smooth_out"])
+    m = geo_oracle.geoguessr_metrics(g["metric_preds"], g["metric_labels"], g["metric_cell_preds"], g["metric_cell_labels"], g["metric_top5"])
+    for k, v in zip([str(s) for s in g["metric_names"]], g["metric_values"]):
+        assert float(m[k]) == float(v), k
+
+
+def test_vit24_trained_regime_matches_reference(golden_dir):
+    """The oracle ViT in the trained-like numeric regime (massive activations, |mean|/std ~ 5 rows), fp32 vs fp32."""
+    g = _load(golden_dir, "vit24_trained.npz")
+    seed, layers, _, n, pseed = [int(x) for x in g["meta"]]
+    sd = synthetic.make_vit_weights_trained_like(seed=seed, layers=layers)
+    emb = orc.clip_embedding(sd, synthetic.make_pixels(n, seed=pseed))
+    assert orc.rel_err(emb, torch.from_numpy(g["embedding"])) < 5e-6
+
+
+def test_pipeline24_head_and_refine_match_reference(golden_dir, tmp_path):
+    """Full-size end-to-end fixture (24 layers, C = 10 000, 32 panoramas): the oracle's head + refiner, fed with the
+    reference's embeddings, reproduce the reference's argmax / top-50 / refined outputs at both refiner settings.  (The
+    oracle ViT itself is pinned on 4 + 2 + 2 images by the vit24* fixtures; 128 images would take minutes on CPU.)"""
+    g = _load(golden_dir, "pipeline24.npz")
+    wseed, layers, NP, pseed, C, ppc, bseed, maxm = [int(x) for x in g["meta"]]
+    W0, _ = synthetic.make_head_weights(C, seed=0)
+    cen = _geocells_like_reference(C, 0, tmp_path)
+    emb = torch.from_numpy(g["embedding"])
+    o = orc.super_guessr_forward(W0 * float(g["head_scale"]), torch.from_numpy(g["head_bias"]), cen, 50, embedding=emb)
+    assert np.array_equal(o["preds_geocell"].numpy(), g["preds_geocell"])
+    assert np.array_equal(o["topk"].indices.numpy(), g["topk_indices"])
+    assert np.array_equal(o["preds_LLH"].numpy(), g["preds_LLH"])
+    assert len(set(g["preds_geocell"].tolist())) >= 24                      # the fixture spreads over many cells
+    bank = synthetic.make_bank(C, ppc, seed=bseed, empty_frac=0.01, max_members=maxm, center=g["center"], radius=float(g["radius"]))
+    changed = 0
+    for tag in ("default", "evaluate"):
+        topk, T, mr = g[f"{tag}_params"]
+        _, llh, cell = orc.proto_refiner_forward(bank, emb, torch.from_numpy(g["preds_LLH"]), torch.from_numpy(g["topk_indices"]),
+                                                 torch.from_numpy(g["topk_values"]), int(topk), float(T), float(mr))
+        assert np.array_equal(cell.numpy(), g[f"{tag}_cell"]) and np.array_equal(llh.numpy(), g[f"{tag}_LLH"])
+        changed += int((g[f"{tag}_cell"] != g["preds_geocell"]).sum())
+    assert changed > 0                                                      # refinement genuinely re-ranks in this fixture

@@ -23,7 +23,8 @@ CLASSES = {"gemm_qkv": (("gemm_pp6_kernel<T_F16, 6>", "gemm_pp6_kernel<T_F16, 0>
            "gemm_fc1": (("gemm_pp6_kernel<T_F16, 7>", "gemm_pp6_kernel<T_F16, 1>", "gemm_pp_kernel<T_F16, 7,", "gemm_pp_kernel<T_F16, 1,"), 2 * 1024 + 2 * 4096),
            "gemm_out_fc2_mixed": (("gemm_pp_kernel<T_F16, 5,", "gemm_pp_kernel<T_F16, 2,"), None),
            "attention": (("attention",), 2 * 3072 + 2 * 1024),
-           "layernorm": (("layernorm_kernel",), 4 * 1024 + 2 * 1024)}
+           "layernorm": (("layernorm_kernel",), 4 * 1024 + 2 * 1024),
+           "refine_candidates": (("refine_candidates_kernel",), None)}
 res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py, one launch = %d token rows; KiB as "
                "reported; hbm_bytes_per_launch_corrected = 2 x FETCH_SIZE (gfx950 under-report of wide coalesced reads, "
                "MI355X_MICROARCH.md) + WRITE_SIZE; algorithmic_bytes = activation rows in + out (+ weights once)" % rows}
