@@ -105,6 +105,10 @@ int pg_vit_profile_reset(pg_vit* h);
  * encoder's fp32 -> fp16 conversions clamp at +-65504 instead of overflowing to inf; with the check enabled the forward
  * pass counts, buffer by buffer, the 16-bit activations sitting exactly on that limit (bf16 operands: the +-inf).
  * pg_vit_saturation_read returns the total since the last reset (synchronises the device); 0 = nothing was clamped. */
+/* Tuning knob (process-wide, default from the build / env PIGEON_GEMM_STAGGER): the persistent GEMMs start XCD x of the 8
+ * XCDs x/8 * fraction of a tile period late, so that the epilogue (HBM) phase of one XCD overlaps the mainloop (MFMA)
+ * phases of the others; 0 = all blocks start together.  Changes timing only, never results. */
+int pg_tune_gemm_stagger(float fraction);
 int pg_vit_saturation_check(pg_vit* h, int on);
 int pg_vit_saturation_read(pg_vit* h, int64_t* count, int reset);
 

@@ -468,7 +468,7 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
     GemmArgs g;
     g.A = (const uint16_t*)A; g.lda = lda; g.W = (const uint16_t*)W; g.ldw = ldw > 0 ? ldw : K; g.bias = bias; g.out = out; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.qscale = qscale; g.qcols = qcols; g.aux = aux;
-    g.tilesM = 0; g.tilesN = 0; g.ntiles = 0; g.gn = 0; g.stagger = 0;
+    g.tilesM = 0; g.tilesN = 0; g.ntiles = 0; g.gn = 0; g.stagger = 0; g.xcd_stagger_ticks = 0;
     if (extra) g.ex = *extra;
     if ((epi == EPI_GELU || epi == EPI_RESID || epi >= EPI_RESID_STAT) && !bias) { pg_set_error("gemm: epilogue %d needs a bias", epi); return PG_EINVAL; }
     if (epi == EPI_RESID_STAT && (!g.ex.x16 || !g.ex.statpart || g.ex.ldx != ldc)) { pg_set_error("gemm: EPI_RESID_STAT needs x16 / statpart and ldx == ldc"); return PG_EINVAL; }
@@ -476,6 +476,18 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
     if (epi == EPI_PATCH && !aux) { pg_set_error("gemm: patch epilogue needs aux"); return PG_EINVAL; }
     if ((lda % 8) || (ldc % 8) || (qcols % 8) || (g.ldw % 8) || g.ldw < K) { pg_set_error("gemm: lda/ldw/ldc/qcols must be multiples of 8, ldw >= K"); return PG_EINVAL; }
     if (variant == 0) variant = pg_default_gemm_variant();
+    {
+        // XCD stagger (gemm_epi.h): total spread = fraction x estimated tile period.  Tile periods measured on MI355X
+        // (profiles/r02): 256x256 tiles 25 us + 1.63 us per 64-wide K tile (fp32 residual epilogues), 384x256 tiles
+        // 8 us (+4 us with the GELU) + 2.44 us per K tile.
+        const float f = pg_gemm_stagger_fraction();
+        if (f > 0.f && M >= 256 * 64) {
+            const bool six = variant == 56 && pg_gemm_pp6_supported(epi, N, K);
+            const float period_us = six ? ((epi == EPI_GELU || epi == EPI_GELU_LN ? 12.f : 8.f) + 2.44f * (K / 64))
+                                        : ((epi == EPI_RESID || epi == EPI_RESID_STAT ? 25.f : 10.f) + 1.63f * (K / 64));
+            g.xcd_stagger_ticks = (int)(f * period_us * 100.f);              // 100 ticks per us
+        }
+    }
     if (variant == 56) {                                     // 384 x 256 tiles where they exist, the product kernel elsewhere
         if (pg_gemm_pp6_supported(epi, N, K)) return pg_gemm_pp6_launch(dtype, g, epi, s);
         variant = 36;

@@ -17,7 +17,8 @@ struct GemmArgs {
     const float* aux;             // epi 3: position embedding [577][N]
     int tilesM, tilesN, ntiles;
     int gn;                       // N tiles per raster group (see tile_coords)
-    int stagger;                  // gemm_pp: shader cycles of one output tile (0 = blocks start together)
+    int stagger;                  // gemm_pp (tools build): shader cycles of one output tile, per-CU start stagger (0 = off)
+    int xcd_stagger_ticks;        // persistent kernels: XCD x starts x * ticks / 8 wall-clock ticks (100 MHz) late (0 = off)
     PgGemmExtra ex;               // LayerNorm-fold epilogues (EPI_RESID_STAT / EPI_QKV_LN / EPI_GELU_LN)
 };
 
@@ -26,6 +27,21 @@ int pg_gemm_pp_launch(int dtype, GemmArgs g, int epi, int variant, hipStream_t s
 // gemm_pp6.hip: the same kernel with a 384 x 256 block tile, 16-bit-output epilogues only (variant 56, experimental)
 bool pg_gemm_pp6_supported(int epi, int N, int K);
 int pg_gemm_pp6_launch(int dtype, GemmArgs g, int epi, hipStream_t s);
+
+// XCD-level start stagger of the persistent GEMMs.  Every tile of a launch takes the same time, so blocks that start
+// together reach their epilogues together: all 256 CUs then hit HBM at once (the fp32 residual read-modify-write of an
+// out-proj / fc2 tile is 640 KB per CU, 164 MB per round) while the matrix pipes idle, and during the mainloops HBM idles.
+// Delaying XCD x by x/8 of a tile period keeps the 32 CUs of an XCD in lock step -- they share operand panels through
+// their L2 at the same K position, which the per-CU stagger tried in round 1 destroyed -- but lets one XCD's epilogue run
+// under the other XCDs' mainloops.  The launch ends with the partial last round anyway (its few tiles go to XCD 0, which is
+// not delayed), so a spread below one tile period adds no tail.  Wall clock (100 MHz s_memrealtime), immune to DVFS.
+__device__ __forceinline__ void xcd_stagger_wait(int ticks) {
+    if (ticks <= 0) return;
+    const int xcd = blockIdx.x & 7;
+    if (xcd == 0) return;
+    const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)ticks * xcd / 8;
+    while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(16);
+}
 
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_base_uniform) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,

@@ -526,6 +526,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     const int nblk = gridDim.x;
     int L = xcd_remap(blockIdx.x, nblk);
     if (L >= g.ntiles) return;
+    xcd_stagger_wait(g.xcd_stagger_ticks);
     if (g.stagger > 0) {
         // De-synchronise the persistent blocks: every tile takes the same time, so blocks that start together also
         // reach their epilogues together and HBM sees bursts (all CUs storing / fetching residual rows) separated by

@@ -277,6 +277,7 @@ __global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
     const int nblk = gridDim.x;
     int L = xcd_remap(blockIdx.x, nblk);
     if (L >= g.ntiles) return;
+    xcd_stagger_wait(g.xcd_stagger_ticks);
     Tile6 c = make_tile6(g, L);
     issue_dma6<0, P6_NDMA>(c, smem, wave, voffA, voffW, 0);  // K tile 0 of the first output tile -> stage 0
     Bias6 bias;

@@ -88,9 +88,31 @@ __global__ __launch_bounds__(256) void refine_candidates_kernel(pg_bank bank, co
     // torch.max / torch.argmax treat NaN as the maximum (first NaN wins): a NaN distance "wins" here too, so a NaN query
     // propagates NaN scores exactly like the reference instead of leaving the sentinel index behind
     float best = INFINITY; long long bi = 0x7fffffffffffffffLL;
-    for (int64_t r = s + wave; r < e; r += 4) {
-        const float d = sqrtf(row_sqdist(bank.proto_emb + r * RF_DIM, lane, qv));
-        if (nan_aware_less(d, r, best, bi)) { best = d; bi = r; }
+    {
+        // two rows in flight per wave (8 KB): with one 4 KB row per wave the kernel is latency-bound (10 resident waves per CU
+        // keep ~40 KB in flight where HBM needs ~60 KB per CU to stay busy); rows of a wave are visited in ascending order, so
+        // the (min, first index) result is what the single-row loop gives
+        int64_t r = s + wave;
+        for (; r + 4 < e; r += 8) {
+            f32x4 v0[4], v1[4];
+            load_row16(bank.proto_emb + r * RF_DIM, lane, v0);
+            load_row16(bank.proto_emb + (r + 4) * RF_DIM, lane, v1);
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const float d0 = v0[i][e4] - qv[i][e4]; s0 = fmaf(d0, d0, s0);
+                    const float d1 = v1[i][e4] - qv[i][e4]; s1 = fmaf(d1, d1, s1);
+                }
+            const float dd0 = sqrtf(wave_sum(s0)), dd1 = sqrtf(wave_sum(s1));
+            if (nan_aware_less(dd0, r, best, bi)) { best = dd0; bi = r; }
+            if (nan_aware_less(dd1, r + 4, best, bi)) { best = dd1; bi = r + 4; }
+        }
+        for (; r < e; r += 4) {
+            const float d = sqrtf(row_sqdist(bank.proto_emb + r * RF_DIM, lane, qv));
+            if (nan_aware_less(d, r, best, bi)) { best = d; bi = r; }
+        }
     }
     if (lane == 0) { red_d[wave] = best; red_i[wave] = bi; }
     __syncthreads();

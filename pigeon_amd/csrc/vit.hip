@@ -48,6 +48,24 @@ int pg_default_gemm_variant() {
     return v;
 }
 
+#ifndef PG_DEFAULT_GEMM_STAGGER
+#define PG_DEFAULT_GEMM_STAGGER 0.0f
+#endif
+static float g_stagger = -1.f;
+float pg_gemm_stagger_fraction() {
+    if (g_stagger < 0.f) {
+        const char* e = getenv("PIGEON_GEMM_STAGGER");
+        g_stagger = e ? (float)atof(e) : PG_DEFAULT_GEMM_STAGGER;
+        if (!(g_stagger >= 0.f && g_stagger <= 4.f)) g_stagger = 0.f;
+    }
+    return g_stagger;
+}
+extern "C" int pg_tune_gemm_stagger(float fraction) {
+    if (!(fraction >= 0.f && fraction <= 4.f)) { pg_set_error("tune_gemm_stagger: fraction must be in [0, 4]"); return PG_EINVAL; }
+    g_stagger = fraction;
+    return PG_OK;
+}
+
 extern "C" const char* pg_last_error(void) { return g_err; }
 extern "C" int pg_abi_version(void) { return PG_ABI_VERSION; }
 extern "C" int pg_device_count(void) {
@@ -88,6 +106,9 @@ struct pg_vit {
     double prof_ms[PG_PROF_CLASSES] = {0};
 };
 
+#ifndef PG_DEFAULT_GEMM_STAGGER
+#define PG_DEFAULT_GEMM_STAGGER 0.0f
+#endif
 static const float kQScale = 0.125f * 1.4426950408889634f;    // head_dim^-0.5 * log2(e)
 
 static std::string canon(const char* name) {

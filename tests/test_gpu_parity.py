@@ -53,7 +53,7 @@ def _geocells_csv(tmp_path, C, seed=0):
 
 # ------------------------------------------------------------------------------------------------ kernels
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("variant,K", [(0, 384), (1, 320), (5, 320), (8, 320), (33, 384), (36, 640), (30, 384), (56, 640)])
+@pytest.mark.parametrize("variant,K", [(0, 384), (8, 320), (33, 384), (36, 640), (56, 640)])
 def test_gemm_epilogues(env, dt, variant, K):
     ops, L = env["ops"], env["lib"]
     g = torch.Generator().manual_seed(3)

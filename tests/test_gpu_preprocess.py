@@ -88,45 +88,3 @@ def test_proto_build_matches_torch_mean(env):
             if e.dim() == 3:
                 e = e.mean(dim=1)
             assert torch.equal(got[p], e.mean(dim=0)), (panels, p)
-
-
-def test_build_bank_gpu_equals_host(env, tmp_path):
-    from pigeon_amd import proto_refiner as pr
-    rng = np.random.default_rng(3)
-    train = rng.standard_normal((300, 1024)).astype(np.float32)
-    lens = rng.integers(0, 9, 120)
-    lens[::17] = rng.integers(16, 70, lens[::17].shape[0])       # some prototypes in torch's cascade regime
-    off = np.zeros(121, dtype=np.int64); np.cumsum(lens, out=off[1:])
-    idx = rng.integers(0, 300, int(off[-1])).astype(np.int64)
-    host = pr._segmented_mean_host(train, off, idx, lens.astype(np.int64))
-    gpu = pr._segmented_mean_gpu(train, off, idx)
-    assert np.array_equal(host, gpu)
-
-
-@pytest.mark.parametrize("xdt", [torch.float64, torch.float32])
-def test_haversine_matrix_and_smooth_labels(env, xdt):
-    """Transcendental path: compared with the reference formula evaluated by torch on the CPU.  Tolerance: 1e-12
-    relative when everything is fp64; with fp32 labels torch evaluates deg2rad / cos(lat) of x in fp32, and the
-    device's cosf and the host's differ by an fp32 ulp; one ulp of cos(lat) moves near-antipodal distances by up to
-    0.2 km (1e-5 relative, measured on the CPU by perturbing the host value), so 0.5 km / 3e-5 there (device vs host
-    libm -- nothing on this path is bit-exact by contract)."""
-    from pigeon_amd import geo_utils
-    g = torch.Generator().manual_seed(8)
-    N, M = 37, 10000
-    x = torch.stack([torch.rand(N, generator=g, dtype=torch.float64) * 360 - 180,
-                     torch.rand(N, generator=g, dtype=torch.float64) * 180 - 90], dim=1).to(xdt)
-    y = torch.stack([torch.rand(M, generator=g, dtype=torch.float64) * 360 - 180,
-                     torch.rand(M, generator=g, dtype=torch.float64) * 180 - 90], dim=1)
-    y[5] = x[3].double()                                                         # a zero distance
-    ref = geo_utils.haversine_matrix(x, y.t())                                   # host torch expression
-    got = geo_utils.haversine_matrix(x.to(DEV), y.to(DEV).t())                   # pg_haversine_matrix
-    assert got.dtype == torch.float64 and got.shape == (N, M)
-    rtol = 1e-12 if xdt == torch.float64 else 3e-5
-    assert torch.allclose(got.cpu(), ref, rtol=rtol, atol=1e-9 if xdt == torch.float64 else 0.5)
-    ref_s = geo_utils.smooth_labels(got.cpu(), 65)                               # same distances in: isolates the kernel
-    got_s = geo_utils.smooth_labels(got, 65)
-    assert torch.allclose(got_s.cpu(), ref_s, rtol=1e-11, atol=1e-300)
-    assert bool((got_s.cpu().max(dim=1).values == 1.0).all())                    # the nearest cell always gets 1
-    d = got.clone(); d[2, 7] = float("nan"); d[4, 9] = float("inf")
-    s = geo_utils.smooth_labels(d, 65).cpu()
-    assert bool((s[2] == 0).all()) and s[4, 9] == 0 and torch.isfinite(s).all()  # torch.min propagates NaN -> row of 0
