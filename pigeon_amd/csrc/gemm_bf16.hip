@@ -456,7 +456,7 @@ static int gemm_dispatch(GemmArgs& g, int epi, int variant, hipStream_t s) {
         case 22: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true, 2>(g, epi, s);   // no ds_reads
         case 23: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true, 3>(g, epi, s);   // neither
 #endif
-        default: pg_set_error("gemm: variant %d is not part of this build (product variants: 8, 33, 36, 56; the rest needs the "
+        default: pg_set_error("gemm: variant %d is not part of this build (product variants: 8, 33, 36, 56, 64; the rest needs the "
                               "-DPIGEON_ABLATIONS tools build, python -m pigeon_amd.build --dev)", variant); return PG_EINVAL;
     }
 }
@@ -487,6 +487,10 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
                                         : ((epi == EPI_RESID || epi == EPI_RESID_STAT ? 25.f : 10.f) + 1.63f * (K / 64));
             g.xcd_stagger_ticks = (int)(f * period_us * 100.f);              // 100 ticks per us
         }
+    }
+    if (variant == 64) {                                     // one-wave-per-SIMD persistent kernel where it exists
+        if (pg_gemm_w4_supported(epi, N, K)) return pg_gemm_w4_launch(dtype, g, epi, s);
+        variant = 36;
     }
     if (variant == 56) {                                     // 384 x 256 tiles where they exist, the product kernel elsewhere
         if (pg_gemm_pp6_supported(epi, N, K)) return pg_gemm_pp6_launch(dtype, g, epi, s);

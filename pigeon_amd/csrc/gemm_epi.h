@@ -43,6 +43,10 @@ __device__ __forceinline__ void xcd_stagger_wait(int ticks) {
     while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(16);
 }
 
+// gemm_w4.hip: persistent kernel with one wave per SIMD (4 waves, 128 x 128 wave tiles, accumulators in AGPRs; variant 64)
+bool pg_gemm_w4_supported(int epi, int N, int K);
+int pg_gemm_w4_launch(int dtype, GemmArgs g, int epi, hipStream_t s);
+
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_base_uniform) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
                                      (__attribute__((address_space(3))) void*)lds_base_uniform, 16, 0, 0);
