@@ -1,20 +1,28 @@
 // gemm_w4.hip -- persistent GEMM with ONE wave per SIMD: C[M,N] = A[M,K] * W[N,K]^T, fp16/bf16 operands, fp32 MFMA
-// accumulation, the fused epilogues of gemm_pp.hip (variant 64).
+// accumulation, the fused epilogues of gemm_pp.hip.  EXPERIMENTAL (variant 64, not the default): it matches the 8-wave
+// ping-pong kernels but does not beat them -- the measurements that came out of building it are the point.
 //
-// Why a third persistent kernel.  Round 2 calibrated the GEMMs of gemm_pp.hip / gemm_pp6.hip against hipBLASLt on the same
-// box (profiles/r02/hipblaslt_probe.txt, tools/epi_probe.py): with a plain 16-bit-store epilogue the 8-wave ping-pong
-// mainloop needs 1.72 us per 256x256x64 K tile per CU (1249 TFLOP/s chip-wide), hipBLASLt's hand-written kernel 1.45 us
-// (1481 TFLOP/s).  Its structure (read off its name and instruction mix, not its code): 256 x 256 x 64 tiles, FOUR waves per
-// workgroup -- one per SIMD -- each owning a 128 x 128 wave tile whose 256 accumulator registers live in AGPRs, operands
-// DMA'd straight into LDS, a handful of barriers per K tile, MFMAs issued back to back with the LDS reads of the next k-step
-// between them.  Against the 8-wave layout that is
-//   * one third fewer fragment reads per flop (a 128 x 128 wave tile reads 256 operand rows per k-step for 16 MFMAs, two
-//     128 x 64 wave tiles read 384),
-//   * one barrier per K tile instead of eight (no ping-pong hand-over: with a single wave per SIMD nothing competes for
-//     the matrix pipe; the wave's own LDS reads / DMA issue sit in the shadow of its MFMAs),
-//   * half the waves issuing DMA / address arithmetic.
-// This file is that structure, written from scratch on this library's building blocks (buffer-descriptor DMA with the bank
-// swizzle on the source address, lane-linear LDS image, slab-transposed epilogues, XCD-aware super-tile raster).
+// Why it was built.  Round 2 calibrated the GEMMs of gemm_pp.hip / gemm_pp6.hip against hipBLASLt on the same box
+// (profiles/r02/hipblaslt_probe.txt, epilogue_costs.txt): with a plain 16-bit-store epilogue the 8-wave ping-pong mainloop
+// needs 1.65-1.72 us per 256x256x64 K tile per CU, hipBLASLt's hand-written kernel 1.45 us.  Its structure (read off its name
+// and instruction mix, not its code): 256 x 256 x 64 tiles, FOUR waves per workgroup -- one per SIMD -- each owning a 128 x 128
+// wave tile whose 256 accumulator registers live in AGPRs, v_mfma_f32_16x16x32, operands DMA'd straight into LDS, three
+// barriers per K tile, MFMAs back to back with the LDS reads of the next k-step between them.  This file is that structure,
+// written from scratch on this library's building blocks (buffer-descriptor DMA with the bank swizzle on the source address,
+// lane-linear LDS image, slab-transposed epilogues, XCD-aware super-tile raster).
+//
+// What was measured (MI355X, 295 424 x 1024 x 4096 / x 1024, per 64 of K per CU, profiles/r02/w4_*.txt):
+//   v_mfma_f32_32x32x16, fragment reads one per MFMA pair, 16 DMAs right behind the barrier   1.98 us
+//   + reads in the first half of a k-step, 8 MFMAs before the barrier, DMAs in k-step 0       1.92 us
+//   + v_mfma_f32_16x16x32 (this file)                                                          1.72 us   (ping-pong: 1.65-1.69)
+//   ... without the operand DMA (timing-only ablation)                                         0.96 us   = 2.06 PFLOP/s chip-wide
+//   ... without the fragment reads (timing-only ablation)                                      1.50 us
+//   32-wide K tiles in four 32 KB stages, DMAs spread one per eight MFMAs                      1.92 us   (rejected)
+// i.e. the MFMA stream itself is not the limit (tools/mfma_issue.hip: 1844 TFLOP/s for 16x16x32 at the 1400 W cap, 1505 for
+// 32x32x16: the 16x16x32 form moves half as many accumulator registers per flop); the global -> LDS operand feed costs 44 % of
+// the K-tile time, and with a single wave per SIMD every non-MFMA instruction takes ~6 cycles away from the matrix pipe
+// (mfma_issue: 35.3 instead of 32 cycles per MFMA with one ds_read per two MFMAs) where the ping-pong kernels issue them from
+// the other wave of the SIMD.
 //
 // LDS map (160 KB): stage 0 [0,64K) | stage 1 [64K,128K) | spare [128K,160K).  A stage = 256 A rows then 256 W rows of one
 // 64-wide K tile (128-byte rows), 16-byte chunk c of row r stored at chunk c ^ ((r>>1)&7).  The epilogue's four per-wave
@@ -23,15 +31,16 @@
 //
 // K-tile stream and synchronisation.  One barrier per K tile: before it, every wave has waited for its own DMAs of the
 // next K tile and for its last fragment reads of the current one; after it the stage of the current K tile is free.  The
-// DMAs of K tile u + 1 are issued in k-step 0 of K tile u (one after every MFMA) into the stage freed by the barrier that
-// ended K tile u - 1, and have the rest of K tile u to land.  The stream continues across output tiles: the last K tile
+// DMAs of K tile u + 1 are issued in k-step 0 of K tile u (one after every fourth MFMA) into the stage freed by the barrier
+// that ended K tile u - 1, and have the rest of K tile u to land.  The stream continues across output tiles: the last K tile
 // (stage 1) prefetches K tile 0 of the NEXT output tile into stage 0, where it lands under the epilogue (whose slabs live in
-// stage 1).  Within a k-step the fragment reads of the next k-step sit between the first eight MFMAs, so their latency is
-// covered by the other eight; the k-step that carries the barrier issues eight MFMAs BEFORE it (the matrix pipe works
-// through them while the wave waits) and the next K tile's first fragment reads right behind it.
+// stage 1).  Within a k-step (32 of K, 64 MFMAs) the 16 fragment reads of the next k-step sit between the first 32 MFMAs, so
+// their latency is covered by the other 32; the k-step that carries the barrier issues 32 MFMAs BEFORE it (the matrix pipe
+// works through them while the wave waits) and the next K tile's first fragment reads right behind it.
 //
-// Same MFMA sequence over K as every other GEMM kernel of the library (v_mfma_f32_32x32x16, k ascending, fp32 accumulate
-// from 0): outputs are bit-identical to variants 8 / 36 / 56, and the row-statistics partials use the same 64-column slices.
+// v_mfma_f32_16x16x32 sums the k products of one instruction in another association than the 32x32x16 kernels (variants
+// 8 / 36 / 56): outputs agree with those to fp32 rounding (checked with a tolerance, tools/gemm_pp_check.py), not bit for bit;
+// the row-statistics partials use the same 64-column slices and summation order.
 #include "gemm_epi.h"
 
 namespace {

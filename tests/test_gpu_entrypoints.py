@@ -244,10 +244,11 @@ def test_geo_kernels_match_reference_outputs(env, golden_dir):
     got32 = geo_utils.haversine_matrix(x.float().to(DEV), y.to(DEV).t()).cpu().numpy()
     want32 = g["matrix_f32x"]
     # the fixture holds an exact antipode: in mixed precision the reference's `a` rounds above 1 there and arcsin gives NaN;
-    # the device (correctly rounded fp32 cos) may land on either side of 1: NaN or half the circumference
+    # the device (correctly rounded fp32 cos) may land on either side of 1: NaN, or half the circumference minus the few km an
+    # fp32 ulp of `a` is worth next to the antipode (d = 2R asin(sqrt(1 - eps)) ~ pi R - 2R sqrt(eps))
     nan = np.isnan(want32)
     assert int(nan.sum()) <= 2
-    assert all(np.isnan(v) or abs(v - np.pi * 6378.137) < 1.0 for v in got32[nan])
+    assert all(np.isnan(v) or abs(v - np.pi * 6378.137) < 15.0 for v in got32[nan])
     np.testing.assert_allclose(got32[~nan], want32[~nan], rtol=3e-5, atol=0.5)
     n = x.shape[0]
     p64 = geo_utils.haversine(x.to(DEV), y[:n].to(DEV))
