@@ -716,7 +716,9 @@ int pg_gemm_pp_launch(int dtype, GemmArgs g, int epi, int variant, hipStream_t s
     g.tilesM = (g.M + PP_BM - 1) / PP_BM;
     g.tilesN = g.N / PP_BN;
     g.ntiles = g.tilesM * g.tilesN;
-    const int nblk = g.ntiles < num_cus() ? g.ntiles : num_cus();
+    int cap = num_cus();
+    if (pg_gemm_block_cap() > 0 && pg_gemm_block_cap() < cap) cap = pg_gemm_block_cap();   // tuning: share the chip between streams
+    const int nblk = g.ntiles < cap ? g.ntiles : cap;
     if (dtype == PG_DTYPE_F16) return dispatch_pp<T_F16>(g, epi, variant, nblk, s);
     if (dtype == PG_DTYPE_BF16) return dispatch_pp<T_BF16>(g, epi, variant, nblk, s);
     pg_set_error("gemm_pp: operand dtype must be PG_DTYPE_F16 or PG_DTYPE_BF16 (got %d)", dtype);

@@ -376,7 +376,9 @@ int pg_gemm_pp6_launch(int dtype, GemmArgs g, int epi, hipStream_t s) {
     g.tilesN = g.N / P6_BN;
     g.ntiles = g.tilesM * g.tilesN;
     g.gn = (g.tilesN % 4 == 0) ? 4 : g.tilesN;               // 8 x 4 super-tiles per XCD round (gemm_pp.hip variant 36)
-    const int nblk = g.ntiles < cus6() ? g.ntiles : cus6();
+    int cap = cus6();
+    if (pg_gemm_block_cap() > 0 && pg_gemm_block_cap() < cap) cap = pg_gemm_block_cap();   // tuning: share the chip between streams
+    const int nblk = g.ntiles < cap ? g.ntiles : cap;
     if ((epi == EPI_QKV_LN || epi == EPI_GELU_LN) && (!g.ex.colsum || !g.ex.rowstat)) { pg_set_error("gemm_pp6: LN epilogue needs colsum / rowstat"); return PG_EINVAL; }
 #define P6_DISPATCH(TT)                                                          \
     switch (epi) {                                                               \

@@ -22,6 +22,7 @@ struct PgGemmExtra {
 void pg_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 int pg_check_launch(const char* what);          // hipGetLastError -> PG_EHIP + message
 int pg_default_gemm_variant();                   // env PIGEON_GEMM_VARIANT or the built-in default
+int pg_gemm_block_cap();                         // env PIGEON_GEMM_BLOCKS: cap on the persistent GEMMs' grid (0 = one block per CU)
 float pg_gemm_stagger_fraction();                // env PIGEON_GEMM_STAGGER / pg_tune_gemm_stagger: XCD start spread, fraction of a tile period
 
 #define PG_HIP(call)                                                                          \

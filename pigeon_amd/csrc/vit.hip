@@ -48,9 +48,17 @@ int pg_default_gemm_variant() {
     return v;
 }
 
+#ifndef PG_DEFAULT_VIT_STREAMS
+#define PG_DEFAULT_VIT_STREAMS 1
+#endif
 #ifndef PG_DEFAULT_GEMM_STAGGER
 #define PG_DEFAULT_GEMM_STAGGER 0.0f
 #endif
+int pg_gemm_block_cap() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PIGEON_GEMM_BLOCKS"); v = e ? atoi(e) : 0; if (v < 0) v = 0; }
+    return v;
+}
 static float g_stagger = -1.f;
 float pg_gemm_stagger_fraction() {
     if (g_stagger < 0.f) {
@@ -95,6 +103,11 @@ struct pg_vit {
     uint16_t* wpatch = nullptr;                           // [1024][640] bf16 (K zero padded)
     float *cls = nullptr, *pos = nullptr, *preg = nullptr, *preb = nullptr;
     std::vector<LayerW> layers;
+    // two half-batches on two HIP streams (env PIGEON_VIT_STREAMS=2): the tail of a persistent GEMM of one half -- a partial last
+    // round with a handful of CUs busy -- is filled by the other half's next kernel instead of idling the chip
+    int streams = 1;                                       // 1..4 parts; part 0 runs on the caller's stream
+    hipStream_t sx[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     // fp16 saturation scan (debug): device counter of 16-bit activations sitting on +-65504
     bool sat_check = false;
     unsigned long long* sat_counter = nullptr;
@@ -150,6 +163,16 @@ extern "C" int pg_vit_create(pg_vit** out, int device, const pg_vit_cfg* cfg) {
     { const char* e = getenv("PIGEON_LN_FOLD"); h->ln_fold = !(e && e[0] == '0'); }
     if (pg_default_gemm_variant() < 30) h->ln_fold = false;   // the folded epilogues exist only in the persistent GEMM
     h->layers.resize(cfg->layers);
+    { const char* e = getenv("PIGEON_VIT_STREAMS"); h->streams = e ? atoi(e) : PG_DEFAULT_VIT_STREAMS; }
+    if (h->streams < 1 || h->streams > 4) h->streams = 1;
+    if (h->streams > 1) {
+        PG_HIP(hipSetDevice(device));
+        PG_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i + 1 < h->streams; ++i) {
+            PG_HIP(hipStreamCreateWithFlags(&h->sx[i], hipStreamNonBlocking));
+            PG_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+        }
+    }
     *out = h;
     return PG_OK;
 }
@@ -319,8 +342,17 @@ static size_t ws_bytes_for(int chunk, bool ln_fold) {
     return b;
 }
 
+// two-stream mode: the batch is cut in two halves, each with a workspace of its own
+static int split_parts(const pg_vit* h, int n_images) { return (h->streams > 1 && n_images >= 32 * h->streams) ? h->streams : 1; }
 extern "C" int pg_vit_workspace_bytes(const pg_vit* h, int n_images, size_t* bytes) {
     if (!h || !bytes || n_images < 0) { pg_set_error("vit_workspace_bytes: bad argument"); return PG_EINVAL; }
+    const int parts = split_parts(h, n_images);
+    if (parts > 1) {
+        const int per = (n_images + parts - 1) / parts;
+        const int chunk = per < h->cfg.max_chunk ? per : h->cfg.max_chunk;
+        *bytes = (size_t)parts * align_up(ws_bytes_for(chunk, h->ln_fold), 256);
+        return PG_OK;
+    }
     const int chunk = n_images < h->cfg.max_chunk ? n_images : h->cfg.max_chunk;
     *bytes = ws_bytes_for(chunk > 0 ? chunk : 1, h->ln_fold);
     return PG_OK;
@@ -439,13 +471,33 @@ extern "C" int pg_vit_forward_hidden(pg_vit* h, const void* pixels, int pix_dtyp
     hipStream_t s = (hipStream_t)stream;
     const size_t esz = pix_dtype == PG_DTYPE_F32 ? 4 : 2;
     const size_t img_elems = (size_t)3 * VIT_IMG * VIT_IMG;
-    for (int s0 = 0; s0 < n_images; s0 += h->cfg.max_chunk) {
-        const int n = (n_images - s0) < h->cfg.max_chunk ? (n_images - s0) : h->cfg.max_chunk;
-        RC(vit_forward_chunk(h, (const char*)pixels + (size_t)s0 * img_elems * esz, pix_dtype, n,
-                             emb_out + (size_t)s0 * VIT_HIDDEN,
-                             hidden_out ? hidden_out + (size_t)s0 * VIT_TOKENS * VIT_HIDDEN : nullptr, (char*)workspace, s));
+    auto run_range = [&](int first, int last, char* ws, hipStream_t st) -> int {
+        for (int s0 = first; s0 < last; s0 += h->cfg.max_chunk) {
+            const int n = (last - s0) < h->cfg.max_chunk ? (last - s0) : h->cfg.max_chunk;
+            RC(vit_forward_chunk(h, (const char*)pixels + (size_t)s0 * img_elems * esz, pix_dtype, n,
+                                 emb_out + (size_t)s0 * VIT_HIDDEN,
+                                 hidden_out ? hidden_out + (size_t)s0 * VIT_TOKENS * VIT_HIDDEN : nullptr, ws, st));
+        }
+        return PG_OK;
+    };
+    const int parts = split_parts(h, n_images);
+    if (parts > 1) {
+        const int per = (n_images + parts - 1) / parts;
+        const size_t wsp = needb / parts;
+        PG_HIP(hipEventRecord(h->ev_fork, s));               // the side streams start where the caller's stream stands
+        for (int i = 0; i + 1 < parts; ++i) PG_HIP(hipStreamWaitEvent(h->sx[i], h->ev_fork, 0));
+        for (int i = 0; i < parts; ++i) {
+            const int first = i * per, last = (i + 1) * per < n_images ? (i + 1) * per : n_images;
+            if (first >= last) continue;
+            RC(run_range(first, last, (char*)workspace + (size_t)i * wsp, i == 0 ? s : h->sx[i - 1]));
+        }
+        for (int i = 0; i + 1 < parts; ++i) {                 // ... and the caller's stream continues when every part is done
+            PG_HIP(hipEventRecord(h->ev_join[i], h->sx[i]));
+            PG_HIP(hipStreamWaitEvent(s, h->ev_join[i], 0));
+        }
+        return PG_OK;
     }
-    return PG_OK;
+    return run_range(0, n_images, (char*)workspace, s);
 }
 
 extern "C" int pg_vit_forward(pg_vit* h, const void* pixels, int pix_dtype, int n_images, float* emb_out, void* workspace,
@@ -456,6 +508,8 @@ extern "C" int pg_vit_forward(pg_vit* h, const void* pixels, int pix_dtype, int 
 extern "C" int pg_vit_destroy(pg_vit* h) {
     if (!h) return PG_OK;
     for (void* p : h->allocs) (void)hipFree(p);
+    for (int i = 0; i < 3; ++i) { if (h->sx[i]) (void)hipStreamDestroy(h->sx[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     delete h;
     return PG_OK;

@@ -153,6 +153,24 @@ def test_vit24_trained_regime_both_ln_chains(env, golden_dir, monkeypatch, capsy
     assert sats["1"] == 0 and sats["0"] == 0
 
 
+def test_multi_stream_forward_is_bit_identical(env, monkeypatch):
+    """PIGEON_VIT_STREAMS=2/3: the batch is cut into parts that run on HIP streams of their own (fork / join on the caller's
+    stream); an image's embedding does not depend on the part or chunk it rides in."""
+    syn, ops = env["syn"], env["ops"]
+    sd = syn.make_vit_weights(seed=11, layers=2, affine_jitter=True)
+    px = syn.make_pixels(70, seed=6).to(DEV)
+    outs = []
+    for streams in ("1", "2", "3"):
+        monkeypatch.setenv("PIGEON_VIT_STREAMS", streams)
+        enc = ops.VitEncoder(sd, device=0)
+        emb, hid = enc.forward(px, return_hidden=True)
+        torch.cuda.synchronize()
+        outs.append((emb.clone(), hid[[0, 34, 35, 69]].clone()))
+        enc.close()
+    for e, h in outs[1:]:
+        assert torch.equal(e, outs[0][0]) and torch.equal(h, outs[0][1])
+
+
 def test_saturation_counter_counts_clamped_conversions(env):
     syn, ops = env["syn"], env["ops"]
     enc = ops.VitEncoder(syn.make_vit_weights(seed=11, layers=1), device=0)
