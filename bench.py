@@ -38,6 +38,7 @@ import time
 import numpy as np
 import torch
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -376,6 +377,14 @@ def main():
             # ---- BASELINE configs[1] / configs[2] ----
             oc = []
             try:
+                # BASELINE configs[0] is the reference's own CPU plumbing case (run.py embed on 64 images); its shape on this path:
+                from pigeon_amd.clip_embedder import CLIPEmbedding
+                with contextlib.redirect_stdout(io.StringIO()):
+                    embedder = CLIPEmbedding("random", device=str(dev), clip_model=base)
+                px64 = pixel_batches[0].reshape(-1, 3, 336, 336)[:64].contiguous()
+                t = _time_gpu(lambda: embedder(px64), 3, 1)
+                oc.append({"workload": "BASELINE configs[0] shape: CLIPEmbedding.forward on 64 single 336x336 images (the reference runs it on the CPU; "
+                                       "cpu_baseline is that leg)", "value": 64 / t, "unit": "images/s", "ms_per_step": t * 1e3})
                 single = pixel_batches[0].reshape(-1, 3, 336, 336)[:256].contiguous()
                 t = _time_gpu(lambda: base.embed(single), 3, 1)
                 oc.append({"workload": "BASELINE configs[1]: ViT-L/14-336 encoder only (+ token mean), batch 256 single-panel 336x336",
