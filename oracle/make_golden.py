@@ -149,7 +149,19 @@ def main():
             out = model(embedding=emb, labels=torch.zeros(32, 2, dtype=torch.float64),
                         labels_clf=torch.zeros(32, dtype=torch.long))
         logits = model.cell_layer(emb.mean(dim=1))
-        np.savez(os.path.join(GOLD, "head.npz"),
+        # soft labels by distance (models/super_guessr.py:469-471: haversine_matrix + smooth_labels feeding the cross entropy)
+        model_s = ns.SuperGuessr(None, panorama=True, num_candidates=50, should_smooth_labels=True)
+        with torch.no_grad():
+            model_s.cell_layer.weight.copy_(W)
+            model_s.cell_layer.bias.copy_(b)
+        model_s.eval()
+        rng = np.random.default_rng(77)
+        lab = torch.from_numpy(np.stack([rng.uniform(-180, 180, 32), rng.uniform(-90, 90, 32)], axis=1))
+        with torch.no_grad():
+            out_s = model_s(embedding=emb, labels=lab, labels_clf=torch.zeros(32, dtype=torch.long))
+            out_s32 = model_s(embedding=emb, labels=lab.float(), labels_clf=torch.zeros(32, dtype=torch.long))
+        np.savez(os.path.join(GOLD, "head.npz"), smooth_labels_in=lab.numpy(), loss_clf_smooth=float(out_s.loss_clf),
+                 loss_clf_smooth_f32labels=float(out_s32.loss_clf),
                  preds_LLH=out.preds_LLH.numpy(), preds_geocell=out.preds_geocell.numpy(),
                  topk_values=out.top5_geocells.values.numpy(), topk_indices=out.top5_geocells.indices.numpy(),
                  logits_first8=logits[:, :8].detach().numpy(), loss_clf=float(out.loss_clf),

@@ -295,6 +295,17 @@ def test_head_matches_reference(env, golden_dir, tmp_path):
     assert np.array_equal(out.preds_LLH.cpu().numpy(), g["preds_LLH"])                      # float64 gather
     np.testing.assert_allclose(out.top5_geocells.values.cpu().numpy(), g["topk_values"], rtol=1e-5)
     assert abs(float(out.loss_clf) - float(g["loss_clf"])) < 1e-4
+    # soft labels by distance (models/super_guessr.py:469-471): pg_haversine_matrix + pg_smooth_labels feed the cross entropy
+    soft = SuperGuessr(None, panorama=True, num_candidates=k, should_smooth_labels=True, geocell_path=_geocells_csv(tmp_path, C))
+    with torch.no_grad():
+        soft.cell_layer.weight.copy_(W)
+        soft.cell_layer.bias.copy_(b)
+    soft.to(DEV).eval()
+    lab = torch.from_numpy(g["smooth_labels_in"])
+    o64 = soft(embedding=emb, labels=lab, labels_clf=torch.zeros(B, dtype=torch.long))
+    o32 = soft(embedding=emb, labels=lab.float(), labels_clf=torch.zeros(B, dtype=torch.long))
+    assert abs(float(o64.loss_clf) / float(g["loss_clf_smooth"]) - 1) < 1e-6
+    assert abs(float(o32.loss_clf) / float(g["loss_clf_smooth_f32labels"]) - 1) < 1e-5      # fp32 labels: fp32 deg2rad / cos(lat)
     v = out.top5_geocells.values
     assert bool((v[:, :-1] >= v[:, 1:]).all())                                              # sorted descending
     model.serving = True

@@ -224,3 +224,28 @@ def test_evaluate_raises_on_missing_checkpoint(tmp_path):
     with pytest.raises(FileNotFoundError):
         evaluate(os.path.join(str(tmp_path), "missing.model"), [], yfcc=False, landmarks=False, refine=False,
                  geocell_path=_geo_csv(tmp_path))
+
+
+# ------------------------------------------------------------------------------------------------ fixtures are current
+@needs_reference
+def test_fast_golden_fixtures_regenerate_bit_identically(tmp_path, golden_dir, monkeypatch):
+    """oracle/make_golden.py --only head|geo|refine re-run against /root/reference reproduces the committed files bit for
+    bit (the 24-layer fixtures take minutes and are checked by hand when they change)."""
+    import importlib
+    import sys
+    from oracle import make_golden
+    importlib.reload(make_golden)
+    out = os.path.join(str(tmp_path), "golden")
+    os.makedirs(out)
+    monkeypatch.setattr(make_golden, "GOLD", out)
+    for name in ("head", "geo", "refine"):
+        monkeypatch.setattr(sys, "argv", ["make_golden.py", "--only", name])
+        make_golden.main()
+        a, b = np.load(os.path.join(out, f"{name}.npz")), np.load(os.path.join(golden_dir, f"{name}.npz"))
+        assert sorted(a.files) == sorted(b.files), name
+        for k in a.files:
+            if k in ("matrix_f32x", "pairs_f32y"):          # torch's CPU fp32 cos: last ulp depends on the thread partition
+                m = ~(np.isnan(a[k]) | np.isnan(b[k]))
+                np.testing.assert_allclose(a[k][m], b[k][m], rtol=3e-5, atol=0.5)
+                continue
+            assert np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"), (name, k)
