@@ -41,14 +41,15 @@ __global__ __launch_bounds__(THREADS) void issue_loop(const uint16_t* in, float*
         for (int i = 0; i < NC; ++i) s += acc[i][0] + acc[i][7];
         out[blockIdx.x * blockDim.x + threadIdx.x] = s + a[0];
     } else {
-        f32x4 acc[64];
+        constexpr int NC = THREADS == 256 ? 64 : 24;
+        f32x4 acc[NC];
 #pragma unroll
-        for (int i = 0; i < 64; ++i) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(acc[i]) : "v"(a), "v"(b));
+        for (int i = 0; i < NC; ++i) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(acc[i]) : "v"(a), "v"(b));
         t0 = __builtin_readcyclecounter();
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int i = 0; i < 64; ++i) {
-                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(f0), "v"(f1));
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i % NC]) : "v"(f0), "v"(f1));
                 if (LDS && (i & 7) == 7) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a) : "v"(addr), "n"(0));
             }
             if (LDS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(THREADS) void issue_loop(const uint16_t* in, float*
         t1 = __builtin_readcyclecounter();
         float s = 0;
 #pragma unroll
-        for (int i = 0; i < 64; ++i) s += acc[i][0];
+        for (int i = 0; i < NC; ++i) s += acc[i][0];
         out[blockIdx.x * blockDim.x + threadIdx.x] = s + a[0];
     }
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(THREADS) void issue_loop(const uint16_t* in, float*
 template <int KIND, bool LDS, int THREADS>
 void run(const char* name, int blocks, uint16_t* d, float* o, long long* c) {
     const int threads = THREADS;
-    const int iters = 4000;
+    const int iters = 40000;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0;
     for (int rep = 0; rep < 2; ++rep) {
@@ -97,6 +98,8 @@ int main() {
         run<1, true, 256>("16x16x32, one ds_read_b128 per eight MFMAs", blocks, d, o, c);
         run<0, false, 512>("32x32x16 (8 chains/wave), MFMA only", blocks, d, o, c);
         run<0, true, 512>("32x32x16 (8 chains/wave), ds_read per two MFMAs", blocks, d, o, c);
+        run<1, false, 512>("16x16x32 (24 chains/wave), MFMA only", blocks, d, o, c);
+        run<1, true, 512>("16x16x32 (24 chains/wave), ds_read per eight MFMAs", blocks, d, o, c);
     }
     return 0;
 }
