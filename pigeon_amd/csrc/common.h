@@ -58,6 +58,21 @@ struct T_BF16 {
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
+    // 16 x 16 x 32: half as many accumulator registers moved per flop as 32 x 32 x 16 -- 2.06-2.09 against 1.72-1.74 PFLOP/s at
+    // the 1400 W package cap (tools/mfma_issue.hip, profiles/r02/mfma_issue.txt)
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    // the same as inline asm with the accumulator TIED ("+v"): written with the builtin, hipcc picks the early-clobber form of
+    // the 4-pass MFMA for most of a phase's instructions (destination != source accumulator), which doubles the live
+    // accumulator registers of a phase and spills (first 16x16x32 build of gemm_pp6.hip: 300-430 bytes of scratch per lane).
+    // Inside asm the compiler pads no hazards: callers keep MFMA phases free of anything that reads their results.
+    static __device__ __forceinline__ void mfma16_acc(f32x4& c, const v8& a, const v8& b) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    }
+    static __device__ __forceinline__ void mfma16_init(f32x4& c, const v8& a, const v8& b) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
+    }
     // c + a.lo*b.lo + a.hi*b.hi on packed 16-bit pairs (v_dot2c_f32_bf16)
     static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
         return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
@@ -75,6 +90,15 @@ struct T_F16 {
     static __device__ __forceinline__ float val(uint16_t b) { return f16_bits_to_f32(b); }
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mfma16_acc(f32x4& c, const v8& a, const v8& b) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    }
+    static __device__ __forceinline__ void mfma16_init(f32x4& c, const v8& a, const v8& b) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
     }
     static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
         return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), c, false);

@@ -105,26 +105,37 @@ __device__ __forceinline__ void issue_dma(const TileCtx& c, char* stage, int wav
     }
 }
 
-template <typename T> struct Frag { typename T::v8 a[4], b[2]; };
+// MFMA shape: v_mfma_f32_16x16x32 (round 2; 2.06-2.09 PF/s against 1.72-1.74 for 32x32x16 at the power cap, tools/mfma_issue.hip).
+// A k-step of 32 is computed in TWO halves of the wave's 128 rows, so the four {LOAD; barrier; MFMA; barrier} phases per 64-wide
+// K tile of the 32x32x16 version stay as they were (256 matrix-pipe cycles each) at the price of 8 more fragment registers:
+// phase (s, half) reads the four 16-row A blocks of rows [64 half, 64 half + 64) at k-step s (and, in the first half, the four
+// 16-column W blocks, kept for the second half) and runs 16 MFMAs into accumulator blocks [4 half, 4 half + 4) x [0, 4).
+typedef f32x4 AccPP[8][4];
+template <typename T> struct Frag { typename T::v8 a[4], b[4]; };
 
-template <typename T>
+template <typename T, bool WITH_B>
 __device__ __forceinline__ void load_frag(Frag<T>& f, const char* sa, const char* sb, int xo) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f.a[i] = *(const typename T::v8*)(sa + i * 32 * ROWB + xo);
+    for (int i = 0; i < 4; ++i) f.a[i] = *(const typename T::v8*)(sa + i * 16 * ROWB + xo);
+    if constexpr (WITH_B) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) f.b[j] = *(const typename T::v8*)(sb + j * 32 * ROWB + xo);
+        for (int j = 0; j < 4; ++j) f.b[j] = *(const typename T::v8*)(sb + j * 16 * ROWB + xo);
+    }
 }
 
-// swapped operands (weights as "A"): D[n][m] -> a lane owns output row m = lane&31 and column quads
+// swapped operands (weights as "A"): D[n][m] -> a lane owns output row m = lane & 15 of a 16 x 16 block and the 4 consecutive
+// columns 4 (lane >> 4) ..  The MFMAs are inline asm with the accumulator tied (common.h mfma16_acc).
 // ZERO: first k-step of an output tile -- the accumulator operand is the inline constant 0, so the tile loop does not
 // spend 128 v_mov per wave (~512 cycles, 2.5 % of a K = 1024 tile) clearing registers between the epilogue and the mainloop.
-template <typename T, bool ZERO = false>
-__device__ __forceinline__ void mma8(f32x16 (&acc)[4][2], const Frag<T>& f) {
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+template <typename T, bool ZERO, int HALF>
+__device__ __forceinline__ void mma16(AccPP& acc, const Frag<T>& f) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma(f.b[j], f.a[i], ZERO ? zero16 : acc[i][j]);
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (ZERO) T::mfma16_init(acc[HALF * 4 + i][j], f.b[j], f.a[i]);
+            else T::mfma16_acc(acc[HALF * 4 + i][j], f.b[j], f.a[i]);
+        }
 }
 
 __device__ __forceinline__ void wait_lgkm0() {
@@ -184,20 +195,24 @@ __device__ __forceinline__ void fetch_xrows(u32x4 (&dst)[8], const XCtx& x, int 
 // vmcnt(16) at the end of phase 3 still means "my DMAs of the next K tile have landed").
 // XF 2: EPI_RESID_STAT fetches slab 0 only (eight loads in phase 3; its slab-ahead double buffer covers the rest).
 template <typename T, int D0, int D1, int D2, int ABL, int XF = 0, bool ZERO = false>
-__device__ __forceinline__ void ktile_pp(f32x16 (&acc)[4][2], const char* cur, char* nxt, int a_base, int b_base,
-                                         const int (&xoff)[4], const TileCtx& c, int wave, const int (&voffA)[4],
+__device__ __forceinline__ void ktile_pp(AccPP& acc, const char* cur, char* nxt, int a_base, int b_base,
+                                         const int (&xoff)[2], const TileCtx& c, int wave, const int (&voffA)[4],
                                          const int (&voffW)[4], int soff_next, bool has_next, bool xf, const XCtx& xc,
                                          u32x4 (&xq)[4][8]) {
     constexpr int D3 = 8 - D0 - D1 - D2;
     static_assert(D3 >= 0, "DMA schedule");
     Frag<T> f;
     if constexpr ((ABL & 4) != 0) {                          // ablation: fragments read once per K tile (wrong results)
-        load_frag<T>(f, cur + a_base, cur + b_base, xoff[0]);
-        asm volatile("" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]));
+        load_frag<T, true>(f, cur + a_base, cur + b_base, xoff[0]);
+        asm volatile("" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.b[2]), "+v"(f.b[3]));
     }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-        if constexpr ((ABL & 4) == 0) load_frag<T>(f, cur + a_base, cur + b_base, xoff[kk]);
+        // phase kk = (k-step s = kk >> 1, half = kk & 1)
+        if constexpr ((ABL & 4) == 0) {
+            if ((kk & 1) == 0) load_frag<T, true>(f, cur + a_base, cur + b_base, xoff[kk >> 1]);
+            else load_frag<T, false>(f, cur + a_base + 64 * ROWB, cur + b_base, xoff[kk >> 1]);
+        }
         if (has_next && (ABL & 1) == 0) {                    // ABL&1: ablation, no DMA inside the K loop (wrong results)
             constexpr int SKIP = (ABL & 8) ? 0x80 : ((ABL & 16) ? 0x88 : 0);
             if (kk == 0) issue_dma<0, D0, SKIP>(c, nxt, wave, voffA, voffW, soff_next);
@@ -220,8 +235,10 @@ __device__ __forceinline__ void ktile_pp(f32x16 (&acc)[4][2], const char* cur, c
         wait_lgkm0();
         raw_barrier();
         __builtin_amdgcn_s_setprio(1);
-        if (ZERO && kk == 0) mma8<T, true>(acc, f);
-        else mma8<T>(acc, f);
+        if (kk == 0) mma16<T, ZERO, 0>(acc, f);
+        if (kk == 1) mma16<T, ZERO, 1>(acc, f);
+        if (kk == 2) mma16<T, false, 0>(acc, f);
+        if (kk == 3) mma16<T, false, 1>(acc, f);
         __builtin_amdgcn_s_setprio(0);
         raw_barrier();
     }
@@ -230,23 +247,27 @@ __device__ __forceinline__ void ktile_pp(f32x16 (&acc)[4][2], const char* cur, c
 // Free-running form of the same K tile (MODE 0): one barrier per K tile (taken by the caller), fragments double
 // buffered in registers, the DMAs of the next tile spread 2 per k-step between the MFMA groups (= gemm_bf16 variant 8).
 template <typename T, bool ZERO = false>
-__device__ __forceinline__ void ktile_free(f32x16 (&acc)[4][2], const char* cur, char* nxt, int a_base, int b_base,
-                                           const int (&xoff)[4], const TileCtx& c, int wave, const int (&voffA)[4],
+__device__ __forceinline__ void ktile_free(AccPP& acc, const char* cur, char* nxt, int a_base, int b_base,
+                                           const int (&xoff)[2], const TileCtx& c, int wave, const int (&voffA)[4],
                                            const int (&voffW)[4], int soff_next, bool has_next) {
-    Frag<T> f[2];
-    load_frag<T>(f[0], cur + a_base, cur + b_base, xoff[0]);
+    // (tools build only, variant 30; since the 16x16x32 conversion the fragments are read per phase, not double buffered)
+    Frag<T> f;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-        if (kk < 3) load_frag<T>(f[(kk + 1) & 1], cur + a_base, cur + b_base, xoff[kk < 3 ? kk + 1 : 3]);
+        if ((kk & 1) == 0) load_frag<T, true>(f, cur + a_base, cur + b_base, xoff[kk >> 1]);
+        else load_frag<T, false>(f, cur + a_base + 64 * ROWB, cur + b_base, xoff[kk >> 1]);
         if (has_next) {
             if (kk == 0) issue_dma<0, 2>(c, nxt, wave, voffA, voffW, soff_next);
             if (kk == 1) issue_dma<2, 2>(c, nxt, wave, voffA, voffW, soff_next);
             if (kk == 2) issue_dma<4, 2>(c, nxt, wave, voffA, voffW, soff_next);
             if (kk == 3) issue_dma<6, 2>(c, nxt, wave, voffA, voffW, soff_next);
         }
+        wait_lgkm0();
         __builtin_amdgcn_s_setprio(1);
-        if (ZERO && kk == 0) mma8<T, true>(acc, f[0]);
-        else mma8<T>(acc, f[kk & 1]);
+        if (kk == 0) mma16<T, ZERO, 0>(acc, f);
+        if (kk == 1) mma16<T, ZERO, 1>(acc, f);
+        if (kk == 2) mma16<T, false, 0>(acc, f);
+        if (kk == 3) mma16<T, false, 1>(acc, f);
         __builtin_amdgcn_s_setprio(0);
     }
 }
@@ -318,7 +339,7 @@ __device__ __forceinline__ float row8_sum(float v) {
 }
 
 template <typename T, int EPI, int XEARLY, typename PREFETCH>
-__device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs& g, char* smem, int wave, int lane,
+__device__ __forceinline__ void pp_epilogue(AccPP& acc, const GemmArgs& g, char* smem, int wave, int lane,
                                             int row0, int col0, const EpiBias<EPI>& bias, const u32x2 (&rs)[4][4],
                                             PREFETCH&& prefetch_next, const XCtx& xc, u32x4 (&xq)[4][8]) {
     constexpr bool OUT16 = epi_out16<EPI>();
@@ -330,7 +351,7 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs&
     constexpr int ESZ = OUT16 ? 2 : 4;
     constexpr int CPL = WIDE ? 8 : 4;                        // columns per lane on the row-major side
     constexpr int LPR = 64 / CPL, RPI = 64 / LPR, ITS = 32 / RPI;
-    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int l15 = lane & 15, lq = lane >> 4;               // MFMA side: row inside a 16-row block, column quad
     float* slab = (float*)(smem + PP_SLAB_OFF + wave * PP_SLAB_BYTES);
     const int rr = lane / LPR, cc = (lane % LPR) * CPL;
     const int col = col0 + cc;
@@ -342,12 +363,9 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs&
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                    *(f32x4*)(slab + lrow * ROWPF + j * 32 + q * 8 + 4 * lhalf) = v;
-                }
+                for (int j = 0; j < 4; ++j) *(f32x4*)(slab + (ib * 16 + l15) * ROWPF + j * 16 + 4 * lq) = acc[2 * i + ib][j];
             wave_lds_fence();
 #pragma unroll
             for (int it = 0; it < ITS; ++it) {
@@ -410,12 +428,9 @@ __device__ __forceinline__ void pp_epilogue(f32x16 (&acc)[4][2], const GemmArgs&
         for (int i = 0; i < 4; ++i) {
             if constexpr (XEARLY != 1) { if (i + 1 < 4) fetch_x(i + 1, (i + 1) & 1); }
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                    *(f32x4*)(slab + lrow * ROWPF + j * 32 + q * 8 + 4 * lhalf) = v;
-                }
+                for (int j = 0; j < 4; ++j) *(f32x4*)(slab + (ib * 16 + l15) * ROWPF + j * 16 + 4 * lq) = acc[2 * i + ib][j];
             // slabs 0 / 1 came in during the mainloop; with their accumulators parked, fetch the rows of slab i + 2
             if constexpr (XEARLY == 1) { if (i + 2 < 4) fetch_xrows(xq[i + 2], xc, i + 2); }
             wave_lds_fence();
@@ -512,13 +527,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         voffA[i] = r * (int)g.lda * 2 + c * 16;
         voffW[i] = r * (int)g.ldw * 2 + c * 16;
     }
-    const int lrow = lane & 31, lhalf = lane >> 5;
+    // fragment row lane & 15 of a 16-row block, k chunk (16 bytes) 4 s + (lane >> 4) of k-step s, XOR-swizzled with the row
+    const int l15 = lane & 15, lq = lane >> 4;
     const int sw = (lane >> 1) & 7;
-    int xoff[4];
+    int xoff[2];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) xoff[kk] = ((kk * 2 + lhalf) ^ sw) << 4;
-    const int a_base = (wm * 128 + lrow) * ROWB;
-    const int b_base = PP_W_OFF + (wn * 64 + lrow) * ROWB;
+    for (int ks = 0; ks < 2; ++ks) xoff[ks] = ((ks * 4 + lq) ^ sw) << 4;
+    const int a_base = (wm * 128 + l15) * ROWB;
+    const int b_base = PP_W_OFF + (wn * 64 + l15) * ROWB;
 
     constexpr int ECPL = epi_wide<EPI>() ? 8 : 4;
     const int ecc = (lane % (64 / ECPL)) * ECPL;             // the lane's first column inside the wave's 64 on the store side
@@ -550,7 +566,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     bool first = true;
 
     while (true) {
-        f32x16 acc[4][2];                                    // not cleared: the first k-step of the tile runs with C = 0
+        AccPP acc;                                           // not cleared: the first k-step of the tile runs with C = 0
 
         if (first || NST == 0) {
             wait_vm0();
@@ -585,11 +601,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
                 t0 = 2;
             } else {                                          // K = 128: one pair, which may carry the early residual fetch
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 8; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
             }
             for (int t = t0; t < nt; t += 2) {
                 const bool xf = XEARLY != 0 && (t + 2 == nt);
@@ -602,6 +618,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
             if (MODE == 1 && !follower) raw_barrier();       // re-align: every wave has left the mainloop
         }
 
+        // the MFMAs are inline asm, so hipcc pads no "matrix-pipe write -> VALU / LDS read" hazard for the accumulators; a
+        // follower wave comes here straight from its last MFMA phase (one barrier, which normally covers the 4-pass latency)
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
         const int row0 = c.m0 + wm * 128, col0 = c.n0 + wn * 64;
         L += nblk;
         const bool more = L < g.ntiles;

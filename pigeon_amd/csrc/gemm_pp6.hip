@@ -97,46 +97,64 @@ __device__ __forceinline__ void issue_dma6(const Tile6& c, char* stage, int wave
     }
 }
 
-template <typename T> struct Frag6 { typename T::v8 a[P6_TM], b[2]; };
+// MFMA shape: v_mfma_f32_16x16x32 (round 2).  A k-step of 32 is computed in TWO halves of the wave's 192 rows, so that the
+// phase structure of the 32x32x16 version is kept as it was -- four {LOAD; barrier; MFMA; barrier} phases per 64-wide K tile,
+// 384 matrix-pipe cycles each -- with 8 more fragment registers: phase (s, half) reads the six 16-row A blocks of rows
+// [96 half, 96 half + 96) at k-step s (and, in the first half, the four 16-column W blocks, kept for the second half) and
+// runs 24 MFMAs into accumulator blocks [6 half, 6 half + 6) x [0, 4).
+constexpr int P6_RB = 2 * P6_TM;                           // 16-row accumulator blocks per wave along M (12)
+typedef f32x4 Acc6[P6_RB][4];
+template <typename T> struct Frag6 { typename T::v8 a[P6_TM], b[4]; };
 
 // Fragment reads as inline asm from ONE address register per operand: written as C++ loads, hipcc precomputes and keeps
 // live an address VGPR per (stage, k-step, operand) -- 16 registers this kernel does not have (it spilled 73).  The
-// k-step's chunk is an XOR on the address (disjoint bits, see ktile6), the 32-row blocks are immediates (<= 20 KB).
+// k-step's chunk is an XOR on the address (disjoint bits, see ktile6), the 16-row blocks are immediates (<= 10 KB).
 template <int OFF, typename V>
 __device__ __forceinline__ void lds_read_b128(V& dst, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
-template <typename T>
+template <typename T, bool WITH_B>
 __device__ __forceinline__ void load_frag6(Frag6<T>& f, uint32_t aA, uint32_t aB) {
-    lds_read_b128<0 * 32 * ROWB>(f.a[0], aA); lds_read_b128<1 * 32 * ROWB>(f.a[1], aA); lds_read_b128<2 * 32 * ROWB>(f.a[2], aA);
-    lds_read_b128<3 * 32 * ROWB>(f.a[3], aA); lds_read_b128<4 * 32 * ROWB>(f.a[4], aA); lds_read_b128<5 * 32 * ROWB>(f.a[5], aA);
-    lds_read_b128<0>(f.b[0], aB); lds_read_b128<32 * ROWB>(f.b[1], aB);
+    lds_read_b128<0 * 16 * ROWB>(f.a[0], aA); lds_read_b128<1 * 16 * ROWB>(f.a[1], aA); lds_read_b128<2 * 16 * ROWB>(f.a[2], aA);
+    lds_read_b128<3 * 16 * ROWB>(f.a[3], aA); lds_read_b128<4 * 16 * ROWB>(f.a[4], aA);
+    if constexpr (P6_TM > 5) lds_read_b128<5 * 16 * ROWB>(f.a[P6_TM > 5 ? 5 : 0], aA);
+    if constexpr (WITH_B) {
+        lds_read_b128<0 * 16 * ROWB>(f.b[0], aB); lds_read_b128<1 * 16 * ROWB>(f.b[1], aB);
+        lds_read_b128<2 * 16 * ROWB>(f.b[2], aB); lds_read_b128<3 * 16 * ROWB>(f.b[3], aB);
+    }
 }
 
-template <typename T, bool ZERO>
-__device__ __forceinline__ void mma12(f32x16 (&acc)[P6_TM][2], const Frag6<T>& f) {
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+// 24 MFMAs of one phase; swapped operands (weights first): a lane owns output row lane & 15 of a 16 x 16 block and the 4
+// consecutive columns 4 (lane >> 4) ..
+template <typename T, bool ZERO, int HALF>
+__device__ __forceinline__ void mma24(Acc6& acc, const Frag6<T>& f) {
 #pragma unroll
     for (int i = 0; i < P6_TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma(f.b[j], f.a[i], ZERO ? zero16 : acc[i][j]);
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (ZERO) T::mfma16_init(acc[HALF * P6_TM + i][j], f.b[j], f.a[i]);
+            else T::mfma16_acc(acc[HALF * P6_TM + i][j], f.b[j], f.a[i]);
+        }
 }
 
 // One K tile in ping-pong form; the wave's 10 DMAs of the next K tile go 5 / 5 in the first two LOAD phases.
-// baseA / baseB: LDS byte addresses of this lane's fragment row in STAGE 0 at k-step 0 (chunk (lhalf ^ sw) << 4); k-step kk
-// reads chunk (2 kk + lhalf) ^ sw = chunk0 ^ (kk << 1), i.e. address ^ (kk << 5) (disjoint bits).  The per-k-step
-// addresses are formed by asm (one v_add / v_xor each) so that they are NOT hoisted into 16 live registers.
+// baseA / baseB: LDS byte addresses of this lane's fragment row (lane & 15 of block 0) in STAGE 0 at k-step 0 (chunk
+// ((lane >> 4) ^ sw) << 4); k-step s reads chunk (4 s + (lane >> 4)) ^ sw = chunk0 ^ (4 s), i.e. address ^ (s << 6) (disjoint
+// bits).  The per-phase addresses are formed by asm (one v_add / v_xor each) so that they are NOT hoisted into live registers.
 template <typename T, bool ZERO, int STAGE>
-__device__ __forceinline__ void ktile6(f32x16 (&acc)[P6_TM][2], char* smem, uint32_t baseA, uint32_t baseB, const Tile6& c,
+__device__ __forceinline__ void ktile6(Acc6& acc, char* smem, uint32_t baseA, uint32_t baseB, const Tile6& c,
                                        int wave, int voffA, int voffW, int soff_next, bool has_next) {
     char* nxt = smem + (STAGE ? 0 : P6_STAGE);
     Frag6<T> f;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
+        // phase kk = (k-step s = kk >> 1, half = kk & 1)
         uint32_t aA, aB;
-        asm volatile("v_add_u32 %0, %2, %1\n\tv_xor_b32 %0, %3, %0" : "=&v"(aA) : "v"(baseA), "n"(STAGE * P6_STAGE), "n"(kk << 5));
-        asm volatile("v_add_u32 %0, %2, %1\n\tv_xor_b32 %0, %3, %0" : "=&v"(aB) : "v"(baseB), "n"(STAGE * P6_STAGE), "n"(kk << 5));
-        load_frag6<T>(f, aA, aB);
+        asm volatile("v_add_u32 %0, %2, %1\n\tv_xor_b32 %0, %3, %0" : "=&v"(aA) : "v"(baseA),
+                     "n"(STAGE * P6_STAGE + (kk & 1) * P6_TM * 16 * ROWB), "n"((kk >> 1) << 6));
+        asm volatile("v_add_u32 %0, %2, %1\n\tv_xor_b32 %0, %3, %0" : "=&v"(aB) : "v"(baseB), "n"(STAGE * P6_STAGE), "n"((kk >> 1) << 6));
+        if ((kk & 1) == 0) load_frag6<T, true>(f, aA, aB);
+        else load_frag6<T, false>(f, aA, aB);
         if (has_next) {
             if (kk == 0) issue_dma6<0, 5>(c, nxt, wave, voffA, voffW, soff_next);
             if (kk == 1) issue_dma6<5, 5>(c, nxt, wave, voffA, voffW, soff_next);
@@ -145,8 +163,10 @@ __device__ __forceinline__ void ktile6(f32x16 (&acc)[P6_TM][2], char* smem, uint
         wait_lgkm0();
         raw_barrier();
         __builtin_amdgcn_s_setprio(1);
-        if (ZERO && kk == 0) mma12<T, true>(acc, f);
-        else mma12<T, false>(acc, f);
+        if (kk == 0) mma24<T, ZERO, 0>(acc, f);
+        if (kk == 1) mma24<T, ZERO, 1>(acc, f);
+        if (kk == 2) mma24<T, false, 0>(acc, f);
+        if (kk == 3) mma24<T, false, 1>(acc, f);
         __builtin_amdgcn_s_setprio(0);
         raw_barrier();
     }
@@ -183,12 +203,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rowstat_rsrc6(const GemmArgs& 
 // pp_epilogue, WIDE geometry: 8 lanes per row, 8 rows per store instruction, 4 instructions per slab).
 // LN: colsum (cs) and the row statistics of slab 0 (rs0) were fetched right after the last MFMA phase.
 template <typename T, int EPI, typename PREFETCH_DMA, typename PREFETCH_BIAS>
-__device__ __forceinline__ void epilogue6(f32x16 (&acc)[P6_TM][2], const GemmArgs& g, char* smem, int wave, int lane, int row0,
+__device__ __forceinline__ void epilogue6(Acc6& acc, const GemmArgs& g, char* smem, int wave, int lane, int row0,
                                           int col0, const Bias6& bias, const Bias6& cs, const RowStat6& rs0,
                                           __amdgpu_buffer_rsrc_t rrs, PREFETCH_DMA&& prefetch_dma, PREFETCH_BIAS&& prefetch_bias) {
     constexpr int ROWPF = P6_SLAB_ROWF;
     constexpr bool LN = ln6<EPI>();
-    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int l15 = lane & 15, lq = lane >> 4;               // MFMA side: row inside a 16-row block, column quad
     float* slab = (float*)(smem + P6_SLAB_OFF + wave * P6_SLAB_BYTES);
     const int rr = lane >> 3, cc = (lane & 7) * 8;
     const int col = col0 + cc;
@@ -207,12 +227,9 @@ __device__ __forceinline__ void epilogue6(f32x16 (&acc)[P6_TM][2], const GemmArg
     for (int i = 0; i < P6_TM; ++i) {
         if constexpr (LN) { if (i + 1 < P6_TM) load_rowstat6(rs[(i + 1) & 1], rrs, rr, i + 1); }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                *(f32x4*)(slab + lrow * ROWPF + j * 32 + q * 8 + 4 * lhalf) = v;
-            }
+            for (int j = 0; j < 4; ++j) *(f32x4*)(slab + (ib * 16 + l15) * ROWPF + j * 16 + 4 * lq) = acc[2 * i + ib][j];
         wave_lds_fence();
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -266,11 +283,11 @@ __global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
     const int ch = (lane & 7) ^ ((r0 >> 1) & 7);
     const int voffA = r0 * (int)g.lda * 2 + ch * 16;
     const int voffW = r0 * (int)g.ldw * 2 + ch * 16;
-    const int lrow = lane & 31, lhalf = lane >> 5;
-    const int xo0 = (lhalf ^ ((lane >> 1) & 7)) << 4;
+    const int l15 = lane & 15;
+    const int xo0 = ((lane >> 4) ^ ((lane >> 1) & 7)) << 4;  // k-step 0's chunk (lane >> 4) of the lane's fragment row, swizzled
     const uint32_t smem0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const uint32_t baseA = smem0 + (wm * (P6_TM * 32) + lrow) * ROWB + xo0;
-    const uint32_t baseB = smem0 + P6_W_OFF + (wn * 64 + lrow) * ROWB + xo0;
+    const uint32_t baseA = smem0 + (wm * (P6_TM * 32) + l15) * ROWB + xo0;
+    const uint32_t baseB = smem0 + P6_W_OFF + (wn * 64 + l15) * ROWB + xo0;
     const int ecc = (lane & 7) * 8;
 
     const int nt = g.K / BK;                                 // even, >= 4 (checked on the host)
@@ -289,7 +306,7 @@ __global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
     bool first = true;
 
     while (true) {
-        f32x16 acc[P6_TM][2];                                // not cleared: the first k-step of the tile runs with C = 0
+        Acc6 acc;                                            // not cleared: the first k-step of the tile runs with C = 0
         if (first) {
             wait_vm0();
         } else {
@@ -318,6 +335,8 @@ __global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
             load_rowstat6(rs0, rrs, lane >> 3, 0);
         }
         if (!follower) raw_barrier();                        // re-align: every wave has left the mainloop
+        // inline-asm MFMAs: hipcc pads no "matrix-pipe write -> VALU / LDS read" hazard for the accumulators (see gemm_pp.hip)
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
 
         L += nblk;
         const bool more = L < g.ntiles;

@@ -3,8 +3,9 @@
    python tools/gemm_pp_check.py --variants 56,36,30 [--time] [--images 512]
 
 Every variant runs in its own subprocess under a timeout (a wrong barrier count would hang the GPU), the parent only
-collects the printed lines.  The accumulation order of every output element is identical across variants (same MFMA
-sequence over K), so outputs must be BIT-identical, not merely close.
+collects the printed lines.  Variants built on the same MFMA instruction accumulate every output element in the same order
+and must be BIT-identical; since round 2 the persistent kernels (33, 36, 56, 64) use v_mfma_f32_16x16x32 while variant 8 keeps
+32x32x16, so against variant 8 they are held to fp32 rounding (TOL_VARIANTS).
 """
 import argparse
 import os
@@ -15,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-TOL_VARIANTS = (64,)       # v_mfma_f32_16x16x32: same math, different association inside the instruction
+TOL_VARIANTS = (64, 56, 36, 33)       # v_mfma_f32_16x16x32: same math, different association inside the instruction
 
 
 def child(args):
