@@ -109,6 +109,10 @@ int pg_vit_profile_reset(pg_vit* h);
  * XCDs x/8 * fraction of a tile period late, so that the epilogue (HBM) phase of one XCD overlaps the mainloop (MFMA)
  * phases of the others; 0 = all blocks start together.  Changes timing only, never results. */
 int pg_tune_gemm_stagger(float fraction);
+/* Tuning knob (also env PIGEON_GEMM_TAIL_ROWS; default 768): when a GEMM's tiles do not fill the last round of the persistent
+ * kernels and at most `rows` rows lie beyond the last whole round, those rows go to a small-tile kernel (csrc/gemm_tail.hip)
+ * that spreads them over all CUs; 0 = never.  Both kernels produce the same bits for a row: timing only, never results. */
+int pg_tune_gemm_tail_rows(int rows);
 int pg_vit_saturation_check(pg_vit* h, int on);
 int pg_vit_saturation_read(pg_vit* h, int64_t* count, int reset);
 

@@ -50,6 +50,7 @@ SIGNATURES = {
     "pg_vit_profile_read": (_I, [_P, C.POINTER(_I64), C.POINTER(_D)]),
     "pg_vit_profile_reset": (_I, [_P]),
     "pg_tune_gemm_stagger": (_I, [_F]),
+    "pg_tune_gemm_tail_rows": (_I, [_I]),
     "pg_vit_saturation_check": (_I, [_P, _I]),
     "pg_vit_saturation_read": (_I, [_P, C.POINTER(_I64), _I]),
     "pg_comm_unique_id": (_I, [_P]),

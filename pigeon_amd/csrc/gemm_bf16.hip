@@ -456,7 +456,7 @@ static int gemm_dispatch(GemmArgs& g, int epi, int variant, hipStream_t s) {
         case 22: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true, 2>(g, epi, s);   // no ds_reads
         case 23: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true, 3>(g, epi, s);   // neither
 #endif
-        default: pg_set_error("gemm: variant %d is not part of this build (product variants: 8, 33, 36, 56, 64; the rest needs the "
+        default: pg_set_error("gemm: variant %d is not part of this build (product variants: 8, 33, 36, 56, 64, 70; the rest needs the "
                               "-DPIGEON_ABLATIONS tools build, python -m pigeon_amd.build --dev)", variant); return PG_EINVAL;
     }
 }
@@ -486,6 +486,37 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
             const float period_us = six ? ((epi == EPI_GELU || epi == EPI_GELU_LN ? 12.f : 8.f) + 2.44f * (K / 64))
                                         : ((epi == EPI_RESID || epi == EPI_RESID_STAT ? 25.f : 10.f) + 1.63f * (K / 64));
             g.xcd_stagger_ticks = (int)(f * period_us * 100.f);              // 100 ticks per us
+        }
+    }
+    if (g.ex.stat_rows <= 0) g.ex.stat_rows = M;
+    if (variant == 70) {                                     // the whole problem through the small-tile tail kernel (tests, tools)
+        if (!pg_gemm_tail_supported(epi, N, K)) { pg_set_error("gemm: variant 70 (gemm_tail) does not support epi=%d N=%d K=%d", epi, N, K); return PG_EINVAL; }
+        return pg_gemm_tail_launch(dtype, g, epi, 0, s);
+    }
+    {
+        // Tail split (gemm_tail.hip): if the tiles do not fill the persistent kernel's last round and the rows beyond the last
+        // whole round are few, the persistent kernel gets the rows that make whole rounds and the small-tile kernel the rest.
+        // Both produce the same bits for a row, so the cut changes timing only.
+        const bool six = variant == 56 && pg_gemm_pp6_supported(epi, N, K);
+        const bool pp = !six && (variant == 56 || (variant >= 30 && variant < 50)) && N % 256 == 0 && K % 128 == 0;
+        const int tail_max = pg_gemm_tail_rows();
+        if ((six || pp) && tail_max > 0 && pg_gemm_tail_supported(epi, N, K)) {
+            const int bm = six ? 384 : 256;
+            int ncu = pg_num_cus();
+            if (pg_gemm_block_cap() > 0 && pg_gemm_block_cap() < ncu) ncu = pg_gemm_block_cap();
+            const int tilesN = N / 256;
+            const int64_t ntiles = (int64_t)((M + bm - 1) / bm) * tilesN;
+            const int64_t rounds = ntiles / ncu;
+            if (rounds >= 1 && ntiles % ncu != 0) {
+                const int64_t m_main = (rounds * ncu / tilesN) * bm;         // row panels that fit into `rounds` whole rounds
+                if (m_main > 0 && m_main < M && M - m_main <= tail_max) {
+                    GemmArgs gm = g;
+                    gm.M = (int)m_main;
+                    const int rc = six ? pg_gemm_pp6_launch(dtype, gm, epi, s) : pg_gemm_pp_launch(dtype, gm, epi, variant == 56 ? 36 : variant, s);
+                    if (rc != PG_OK) return rc;
+                    return pg_gemm_tail_launch(dtype, g, epi, (int)m_main, s);
+                }
+            }
         }
     }
     if (variant == 64) {                                     // one-wave-per-SIMD persistent kernel where it exists

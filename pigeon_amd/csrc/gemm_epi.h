@@ -47,6 +47,11 @@ __device__ __forceinline__ void xcd_stagger_wait(int ticks) {
 bool pg_gemm_w4_supported(int epi, int N, int K);
 int pg_gemm_w4_launch(int dtype, GemmArgs g, int epi, hipStream_t s);
 
+// gemm_tail.hip: rows [m_begin, M) of a problem in 32 x 64 one-wave tiles, bit-identical to the persistent kernels (variant 70
+// runs a whole problem through it; pg_gemm_launch uses it for the rows that do not fill the persistent kernels' last round)
+bool pg_gemm_tail_supported(int epi, int N, int K);
+int pg_gemm_tail_launch(int dtype, GemmArgs g, int epi, int m_begin, hipStream_t s);
+
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_base_uniform) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
                                      (__attribute__((address_space(3))) void*)lds_base_uniform, 16, 0, 0);

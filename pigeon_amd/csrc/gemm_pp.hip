@@ -400,7 +400,7 @@ __device__ __forceinline__ void pp_epilogue(AccPP& acc, const GemmArgs& g, char*
         if constexpr (STAT) {
             const uint32_t nb16 = rv > 0 ? (uint32_t)(((int64_t)(rv - 1) * g.ldc + 64) * 2) : 0u;
             rx16 = make_rsrc((const char*)g.ex.x16 + ((int64_t)row0 * g.ldc + col0) * 2, nb16);
-            stat_base = g.ex.statpart + ((int64_t)(col0 / 64) * g.M + row0) * 2;
+            stat_base = g.ex.statpart + ((int64_t)(col0 / 64) * g.ex.stat_rows + row0) * 2;
         }
         // LN epilogues issue the next tile's prefetch after slab 0 (their row statistics were loaded at the tile top and
         // must be consumed without waiting for anything younger); everything else issues it first.

@@ -332,7 +332,7 @@ __device__ __forceinline__ void epilogue4(Acc4& acc, const GemmArgs& g, char* sm
     if constexpr (STAT) {
         const uint32_t nb16 = rv > 0 ? (uint32_t)(((int64_t)(rv - 1) * g.ldc + 128) * 2) : 0u;
         rx16 = make_rsrc((const char*)g.ex.x16 + ((int64_t)row0 * g.ldc + col0) * 2, nb16);
-        stat_base = g.ex.statpart + ((int64_t)(col0 / 64 + lhalf) * g.M + row0) * 2;     // this lane's slice on the write-out
+        stat_base = g.ex.statpart + ((int64_t)(col0 / 64 + lhalf) * g.ex.stat_rows + row0) * 2;     // this lane's slice on the write-out
     }
     if constexpr (LN) rrs = make_rsrc((const char*)g.ex.rowstat + (int64_t)row0 * 8, (uint32_t)rv * 8u);
 

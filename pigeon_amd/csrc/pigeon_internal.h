@@ -16,13 +16,16 @@ struct PgGemmExtra {
     const float* rowstat = nullptr;    // [M][2] EPI_*_LN: (rstd, mean*rstd) per A row
     void* x16 = nullptr;               // [M][ldx] EPI_RESID_STAT: 16-bit copy of the updated residual rows
     int64_t ldx = 0;
-    float* statpart = nullptr;         // [M][N/64][2] EPI_RESID_STAT: partial (sum, sum of squares) per 64-column slice
+    float* statpart = nullptr;         // [N/64][stat_rows][2] EPI_RESID_STAT: partial (sum, sum of squares) per 64-column slice
+    int64_t stat_rows = 0;             // rows per slice of statpart; 0 = M (pg_gemm_launch fills it in before it splits a problem)
 };
 
 void pg_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 int pg_check_launch(const char* what);          // hipGetLastError -> PG_EHIP + message
 int pg_default_gemm_variant();                   // env PIGEON_GEMM_VARIANT or the built-in default
 int pg_gemm_block_cap();                         // env PIGEON_GEMM_BLOCKS: cap on the persistent GEMMs' grid (0 = one block per CU)
+int pg_num_cus();                               // compute units of the current device (256 on MI355X)
+int pg_gemm_tail_rows();                         // env PIGEON_GEMM_TAIL_ROWS / pg_tune_gemm_tail_rows: most rows handed to gemm_tail.hip (0 = never)
 float pg_gemm_stagger_fraction();                // env PIGEON_GEMM_STAGGER / pg_tune_gemm_stagger: XCD start spread, fraction of a tile period
 
 #define PG_HIP(call)                                                                          \

@@ -59,6 +59,33 @@ int pg_gemm_block_cap() {
     if (v < 0) { const char* e = getenv("PIGEON_GEMM_BLOCKS"); v = e ? atoi(e) : 0; if (v < 0) v = 0; }
     return v;
 }
+int pg_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+// Rows pg_gemm_launch may hand to gemm_tail.hip instead of giving them a (mostly idle) last round of the persistent kernels.
+// 768 = two 384-row panels: above that the small tiles' lower efficiency starts to eat the round they save.
+#define PG_DEFAULT_GEMM_TAIL_ROWS 768
+static int g_tail_rows = -1;
+int pg_gemm_tail_rows() {
+    if (g_tail_rows < 0) {
+        const char* e = getenv("PIGEON_GEMM_TAIL_ROWS");
+        g_tail_rows = e ? atoi(e) : PG_DEFAULT_GEMM_TAIL_ROWS;
+        if (g_tail_rows < 0) g_tail_rows = 0;
+    }
+    return g_tail_rows;
+}
+extern "C" int pg_tune_gemm_tail_rows(int rows) {
+    if (rows < 0 || rows > (1 << 20)) { pg_set_error("tune_gemm_tail_rows: rows must be in [0, 2^20]"); return PG_EINVAL; }
+    g_tail_rows = rows;
+    return PG_OK;
+}
 static float g_stagger = -1.f;
 float pg_gemm_stagger_fraction() {
     if (g_stagger < 0.f) {

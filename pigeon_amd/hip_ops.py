@@ -61,6 +61,11 @@ def gemm16(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: 
     return out
 
 
+def tune_gemm_tail_rows(rows: int) -> None:
+    """pg_tune_gemm_tail_rows: most rows pg_gemm_launch hands to the small-tile tail kernel (0 = never split).  Timing only."""
+    check(load().pg_tune_gemm_tail_rows(int(rows)), "pg_tune_gemm_tail_rows")
+
+
 def rowstat_cast(x: torch.Tensor, out_dtype: torch.dtype = torch.float16, eps: float = 1e-5):
     """x fp32 (rows,1024) -> (16-bit copy, rowstat (rows,2) = (rstd, mean*rstd))."""
     _dev(x, torch.float32)

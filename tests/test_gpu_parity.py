@@ -122,6 +122,78 @@ def test_gemm_persistent_many_tiles_bit_identical(env):
         assert torch.equal(outs[2], outs[3]), f"epilogue {epi}: 36 vs 56"     # 384-row tiles: same instruction, same K order
 
 
+def _gemm_all_epilogues(ops, L, A, W, bias, X0, cs, rs, M, variant):
+    """Every epilogue of one (A, W) problem through `variant`; outputs carry 3 guard rows where the caller owns the buffer."""
+    N = W.shape[0]
+    outs = []
+    for epi in (L.EPI_QKV, L.EPI_GELU, L.EPI_RESID, L.EPI_F32):
+        if epi in (L.EPI_QKV, L.EPI_GELU):
+            o = torch.full((M + 3, N), 7.0, dtype=A.dtype, device=DEV)
+        elif epi == L.EPI_RESID:
+            o = torch.cat([X0, torch.full((3, N), 7.0, device=DEV)]).contiguous()
+        else:
+            o = torch.full((M + 3, N), 7.0, device=DEV)
+        ops.gemm16(A, W, bias, o, epi, qscale=0.25, qcols=256, variant=variant, M=M)
+        outs.append(o)
+    for epi in (L.EPI_QKV_LN, L.EPI_GELU_LN):
+        outs.append(ops.gemm16_ln(A, W, bias, cs, rs, epi, qscale=0.25, qcols=256, variant=variant))
+    X = X0.clone()
+    x16, part = ops.gemm16_resid_stat(A, W, bias, X, variant=variant)
+    outs += [X, x16, part]
+    torch.cuda.synchronize()
+    return outs
+
+
+def _tail_problem(M, N, K, seed, dt=torch.float16):
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn((M, K), generator=g).to(dt).to(DEV)
+    W = (torch.randn((N, K), generator=g) * 0.05).to(dt).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    X0 = torch.randn((M, N), generator=g).to(DEV)
+    rs = torch.stack([torch.rand(M, generator=g) + 0.5, torch.randn(M, generator=g)], dim=1).contiguous().to(DEV)
+    cs = torch.randn(N, generator=g).to(DEV)
+    return A, W, bias, X0, cs, rs
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_gemm_tail_kernel_bit_identical_to_persistent(env, dt):
+    """gemm_tail.hip (variant 70 = a whole problem through it): 32 x 64 one-wave tiles, operands straight from L2.  Same MFMA
+    chain over k and the same epilogue expressions as the persistent kernel, so every epilogue -- 16-bit, fp32, residual,
+    LayerNorm-fold, residual + 16-bit copy + row statistics -- must come out BIT-identical, ragged M, guard rows untouched."""
+    ops, L = env["ops"], env["lib"]
+    M, N, K = 1000 + 13, 1024, 512
+    A, W, bias, X0, cs, rs = _tail_problem(M, N, K, 21, dt)
+    ref = _gemm_all_epilogues(ops, L, A, W, bias, X0, cs, rs, M, 36)
+    got = _gemm_all_epilogues(ops, L, A, W, bias, X0, cs, rs, M, 70)
+    names = ("qkv", "gelu", "resid", "f32", "qkv_ln", "gelu_ln", "resid_stat.X", "resid_stat.x16", "resid_stat.part")
+    for n, a, b in zip(names, ref, got):
+        assert torch.equal(a, b), n
+    for o in got[:4]:
+        assert bool((o[M:].float() == 7.0).all())
+
+
+def test_gemm_tail_split_changes_nothing(env):
+    """pg_gemm_launch cuts a problem whose tiles do not fill the persistent kernel's last round: whole rounds to the persistent
+    kernel, the few rows beyond them to gemm_tail.hip.  With the split switched off (tail rows 0) the same call must give the
+    same bits -- 256-row tiles (N = 1024: 264 tiles on 256 CUs -> 16384 + 300 rows) and 384-row tiles (N = 3072: 528 tiles ->
+    16128 + 556 rows)."""
+    ops, L = env["ops"], env["lib"]
+    M, K = 64 * 256 + 300, 256
+    try:
+        for N, variant in ((1024, 36), (3072, 56)):
+            A, W, bias, X0, cs, rs = _tail_problem(M, N, K, 22 + N)
+            ops.tune_gemm_tail_rows(0)
+            ref = _gemm_all_epilogues(ops, L, A, W, bias, X0, cs, rs, M, variant)
+            ops.tune_gemm_tail_rows(768)
+            got = _gemm_all_epilogues(ops, L, A, W, bias, X0, cs, rs, M, variant)
+            for i, (a, b) in enumerate(zip(ref, got)):
+                assert torch.equal(a, b), (N, variant, i)
+            for o in got[:4]:
+                assert bool((o[M:].float() == 7.0).all())
+    finally:
+        ops.tune_gemm_tail_rows(768)
+
+
 def test_gemm_w4_one_wave_per_simd_kernel(env):
     """gemm_w4.hip (variant 64, experimental): v_mfma_f32_16x16x32 sums the k products of an instruction in another
     association than the 32x32x16 kernels, so it is held to fp32 rounding against variant 36 -- every epilogue incl. the
