@@ -461,6 +461,12 @@ static int gemm_dispatch(GemmArgs& g, int epi, int variant, hipStream_t s) {
     }
 }
 
+#ifdef PIGEON_ABLATIONS
+static void* g_dbg_ts = nullptr;
+// tools build: arm (buf != null) / disarm the PG_TS time stamps of the persistent kernels; buf = 2 * 16 * 8 * 12 uint64 on the device
+extern "C" int pg_dbg_timestamps(void* buf) { g_dbg_ts = buf; return PG_OK; }
+#endif
+
 int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldc,
                    int M, int N, int K, int epi, float qscale, int qcols, const float* aux, int variant,
                    hipStream_t s, const PgGemmExtra* extra) {
@@ -489,6 +495,9 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
         }
     }
     if (g.ex.stat_rows <= 0) g.ex.stat_rows = M;
+#ifdef PIGEON_ABLATIONS
+    if (g_dbg_ts && epi != EPI_PATCH) { g.aux = (const float*)g_dbg_ts; g.stagger = -7; }
+#endif
     if (variant == 70) {                                     // the whole problem through the small-tile tail kernel (tests, tools)
         if (!pg_gemm_tail_supported(epi, N, K)) { pg_set_error("gemm: variant 70 (gemm_tail) does not support epi=%d N=%d K=%d", epi, N, K); return PG_EINVAL; }
         return pg_gemm_tail_launch(dtype, g, epi, 0, s);

@@ -52,6 +52,19 @@ int pg_gemm_w4_launch(int dtype, GemmArgs g, int epi, hipStream_t s);
 bool pg_gemm_tail_supported(int epi, int N, int K);
 int pg_gemm_tail_launch(int dtype, GemmArgs g, int epi, int m_begin, hipStream_t s);
 
+// Tools build only: wall-clock stamps (100 MHz) from inside the persistent kernels, blocks 0 and 100, every wave, first 16 tiles:
+// buf[((blk * 16 + tile) * 8 + wave) * 12 + slot].  Armed by pg_dbg_timestamps(buf) (gemm_bf16.hip), read by tools/epi_timeline.py.
+#ifdef PIGEON_ABLATIONS
+#define PG_TS(g, iter, wave, slot)                                                                                             \
+    do {                                                                                                                       \
+        if ((g).stagger == -7 && (blockIdx.x == 0 || blockIdx.x == 100) && (threadIdx.x & 63) == 0 && (iter) < 16)             \
+            ((unsigned long long*)(g).aux)[(((blockIdx.x ? 1 : 0) * 16 + (iter)) * 8 + (wave)) * 12 + (slot)] =                \
+                __builtin_amdgcn_s_memrealtime();                                                                              \
+    } while (0)
+#else
+#define PG_TS(g, iter, wave, slot) do {} while (0)
+#endif
+
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_base_uniform) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
                                      (__attribute__((address_space(3))) void*)lds_base_uniform, 16, 0, 0);

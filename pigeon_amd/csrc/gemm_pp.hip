@@ -168,8 +168,8 @@ __device__ __forceinline__ XCtx make_xctx(const GemmArgs& g, int row0, int col0,
     int rv = g.M - row0; rv = rv < 0 ? 0 : (rv > 128 ? 128 : rv);
     const uint32_t nbytes = rv > 0 ? (uint32_t)(((int64_t)(rv - 1) * g.ldc + 64) * 4) : 0u;
     x.ro = make_rsrc((const char*)g.out + ((int64_t)row0 * g.ldc + col0) * 4, nbytes);
-    if (WIDE) {
-        x.voff = ((lane >> 3) * (int)g.ldc + (lane & 7) * 8) * 4;
+    if (WIDE) {                                              // EPI_RESID_STAT: split-halves geometry, see pp_epilogue
+        x.voff = ((lane >> 3) * (int)g.ldc + (lane & 7) * 4) * 4;
         x.rstep = 8 * (int)g.ldc * 4;
     } else {
         x.voff = ((lane >> 4) * (int)g.ldc + (lane & 15) * 4) * 4;
@@ -183,7 +183,7 @@ __device__ __forceinline__ void fetch_xrows_wide(u32x4 (&dst)[8], const XCtx& x)
 #pragma unroll
     for (int it = 0; it < 4; ++it)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) dst[it * 2 + h] = __builtin_amdgcn_raw_buffer_load_b128(x.ro, x.voff + 16 * h, it * x.rstep, 0);
+        for (int h = 0; h < 2; ++h) dst[it * 2 + h] = __builtin_amdgcn_raw_buffer_load_b128(x.ro, x.voff + 128 * h, it * x.rstep, 0);
 }
 __device__ __forceinline__ void fetch_xrows(u32x4 (&dst)[8], const XCtx& x, int slab) {
 #pragma unroll
@@ -299,7 +299,7 @@ __device__ __forceinline__ void load_bias(EpiBias<EPI>& b, const GemmArgs& g, in
     b.lo = z; b.hi = z; b.slo = z; b.shi = z;
     if (g.bias) {
         b.lo = *(const f32x4*)(g.bias + col);
-        if (epi_wide<EPI>()) b.hi = *(const f32x4*)(g.bias + col + 4);
+        if (epi_wide<EPI>()) b.hi = *(const f32x4*)(g.bias + col + (EPI == EPI_RESID_STAT ? 32 : 4));
     }
     if constexpr (epi_ln<EPI>()) {
         b.slo = *(const f32x4*)(g.ex.colsum + col);
@@ -341,7 +341,7 @@ __device__ __forceinline__ float row8_sum(float v) {
 template <typename T, int EPI, int XEARLY, typename PREFETCH>
 __device__ __forceinline__ void pp_epilogue(AccPP& acc, const GemmArgs& g, char* smem, int wave, int lane,
                                             int row0, int col0, const EpiBias<EPI>& bias, const u32x2 (&rs)[4][4],
-                                            PREFETCH&& prefetch_next, const XCtx& xc, u32x4 (&xq)[4][8]) {
+                                            PREFETCH&& prefetch_next, const XCtx& xc, u32x4 (&xq)[4][8], int dbg_iter = 0) {
     constexpr bool OUT16 = epi_out16<EPI>();
     constexpr bool LN = epi_ln<EPI>();
     constexpr bool STAT = (EPI == EPI_RESID_STAT);
@@ -353,7 +353,13 @@ __device__ __forceinline__ void pp_epilogue(AccPP& acc, const GemmArgs& g, char*
     constexpr int LPR = 64 / CPL, RPI = 64 / LPR, ITS = 32 / RPI;
     const int l15 = lane & 15, lq = lane >> 4;               // MFMA side: row inside a 16-row block, column quad
     float* slab = (float*)(smem + PP_SLAB_OFF + wave * PP_SLAB_BYTES);
-    const int rr = lane / LPR, cc = (lane % LPR) * CPL;
+    // EPI_RESID_STAT, "split halves": a lane holds columns 4k..4k+3 and 32+4k..32+4k+3 (k = lane & 7) of its row instead of the
+    // 8 consecutive ones the 16-bit epilogues need.  Every fp32 load / store instruction then covers 8 rows x 128 CONTIGUOUS
+    // bytes; with 8 consecutive columns per lane the two 16-byte halves of a lane were 32 bytes apart, each instruction touched
+    // 64 half-used 32-byte pieces, and the CU's memory pipeline -- not HBM -- set the epilogue time (tools/epi_timeline.py: the
+    // epilogue took 13 us per tile even with 16 of 256 CUs running).  The 16-bit copy becomes two 8-byte stores per lane.
+    constexpr int HOFF = STAT ? 32 : 4;                      // column distance between the lane's two f32x4
+    const int rr = lane / LPR, cc = STAT ? (lane & 7) * 4 : (lane % LPR) * CPL;
     const int col = col0 + cc;
     const float qsc = (EPI == EPI_QKV || EPI == EPI_QKV_LN) && col < g.qcols ? g.qscale : 1.f;
 
@@ -414,7 +420,7 @@ __device__ __forceinline__ void pp_epilogue(AccPP& acc, const GemmArgs& g, char*
                 for (int it = 0; it < ITS; ++it)
 #pragma unroll
                     for (int h = 0; h < XPI; ++h)
-                        xr[set][it][h] = __builtin_amdgcn_raw_buffer_load_b128(ro, voff + 16 * h, i * sstep + it * rstep, 0);
+                        xr[set][it][h] = __builtin_amdgcn_raw_buffer_load_b128(ro, voff + HOFF * 4 * h, i * sstep + it * rstep, 0);
             }
         };
         if constexpr (XEARLY == 0) fetch_x(0, 0);
@@ -439,7 +445,7 @@ __device__ __forceinline__ void pp_epilogue(AccPP& acc, const GemmArgs& g, char*
                 const int r = it * RPI + rr;
                 f32x4 lo = *(const f32x4*)(slab + r * ROWPF + cc);
                 f32x4 hi = lo;
-                if constexpr (WIDE) hi = *(const f32x4*)(slab + r * ROWPF + cc + 4);
+                if constexpr (WIDE) hi = *(const f32x4*)(slab + r * ROWPF + cc + HOFF);
                 // The row offset of every store goes into the VGPR offset, NOT the SGPR soffset: with a register soffset
                 // hipcc pads no wait states after a >64-bit buffer store and lets the next VALU overwrite the data
                 // registers while the store is still reading them (measured on gfx950: dword 3 of ~3 % of such stores
@@ -482,11 +488,12 @@ __device__ __forceinline__ void pp_epilogue(AccPP& acc, const GemmArgs& g, char*
                     if constexpr (STAT) {
                         f32x4 y = __builtin_bit_cast(f32x4, xr[i & 1][it][1]);
                         y += hi + bias.hi;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, ooff + 16, 0, 0);
-                        u32x4 h4;
-                        h4[0] = pack16x2<T>(x[0], x[1]); h4[1] = pack16x2<T>(x[2], x[3]);
-                        h4[2] = pack16x2<T>(y[0], y[1]); h4[3] = pack16x2<T>(y[2], y[3]);
-                        __builtin_amdgcn_raw_buffer_store_b128(h4, rx16, ooff >> 1, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, ooff + HOFF * 4, 0, 0);
+                        u32x2 hx, hy;
+                        hx[0] = pack16x2<T>(x[0], x[1]); hx[1] = pack16x2<T>(x[2], x[3]);
+                        hy[0] = pack16x2<T>(y[0], y[1]); hy[1] = pack16x2<T>(y[2], y[3]);
+                        __builtin_amdgcn_raw_buffer_store_b64(hx, rx16, ooff >> 1, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(hy, rx16, (ooff >> 1) + HOFF * 2, 0, 0);
                         const float s1 = row8_sum(((x[0] + x[1]) + (x[2] + x[3])) + ((y[0] + y[1]) + (y[2] + y[3])));
                         const float s2 = row8_sum(((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3])) +
                                                   ((y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3])));
@@ -502,6 +509,7 @@ __device__ __forceinline__ void pp_epilogue(AccPP& acc, const GemmArgs& g, char*
                     *(u32x2*)(stat_base + (i * 32 + lane) * 2) = *(const u32x2*)(slab + lane * ROWPF + 64);
                 wave_lds_fence();
             }
+            PG_TS(g, dbg_iter, wave, 3 + i);
             if constexpr (LN) { if (i == 0) prefetch_next(); }
         }
     }
@@ -537,7 +545,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     const int b_base = PP_W_OFF + (wn * 64 + l15) * ROWB;
 
     constexpr int ECPL = epi_wide<EPI>() ? 8 : 4;
-    const int ecc = (lane % (64 / ECPL)) * ECPL;             // the lane's first column inside the wave's 64 on the store side
+    // the lane's first column inside the wave's 64 on the store side (EPI_RESID_STAT: split halves, second f32x4 32 columns on)
+    const int ecc = EPI == EPI_RESID_STAT ? (lane & 7) * 4 : (lane % (64 / ECPL)) * ECPL;
     const int nt = g.K / BK;                                 // even (checked on the host)
     const int nblk = gridDim.x;
     int L = xcd_remap(blockIdx.x, nblk);
@@ -564,6 +573,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     // (EPI_RESID_STAT issues more; 16 is a safe lower bound.  The LN epilogues prefetch after slab 0: 12 stores follow.)
     constexpr int NST = (EPI == EPI_PATCH) ? 0 : (EPI == EPI_F32 ? 32 : (epi_ln<EPI>() ? 12 : 16));
     bool first = true;
+    int dbg_iter = 0;                                        // tile counter of the tools build's time stamps (dead code otherwise)
 
     while (true) {
         AccPP acc;                                           // not cleared: the first k-step of the tile runs with C = 0
@@ -576,6 +586,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         }
         wait_lgkm0();
         raw_barrier();                                       // B_0: K tile 0 visible, previous epilogue's slabs released
+        PG_TS(g, dbg_iter, wave, 0);
         u32x2 rs[4][4];
         if constexpr (epi_ln<EPI>()) load_rowstat<EPI>(rs, g, c.m0 + wm * 128, err);
         constexpr int XEARLY = (MODE == 0 || ABL != 0) ? 0 : (EPI == EPI_RESID ? 1 : (EPI == EPI_RESID_STAT ? 2 : 0));
@@ -615,12 +626,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
                 ktile_pp<T, D0, D1, D2, ABL, 0>(acc, smem + PP_STAGE, smem, a_base, b_base, xoff, c, wave, voffA, voffW,
                                                     (t + 2) * ROWB, t + 2 < nt, false, xc, xq);
             }
+            PG_TS(g, dbg_iter, wave, 1);
             if (MODE == 1 && !follower) raw_barrier();       // re-align: every wave has left the mainloop
         }
 
         // the MFMAs are inline asm, so hipcc pads no "matrix-pipe write -> VALU / LDS read" hazard for the accumulators; a
         // follower wave comes here straight from its last MFMA phase (one barrier, which normally covers the 4-pass latency)
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+        PG_TS(g, dbg_iter, wave, 2);
         const int row0 = c.m0 + wm * 128, col0 = c.n0 + wn * 64;
         L += nblk;
         const bool more = L < g.ntiles;
@@ -634,7 +647,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
             issue_dma<0, 8>(c, smem, wave, voffA, voffW, 0);      // next output tile's K tile 0 -> stage 0 (free since K tile nt-2)
             load_bias<EPI>(bias_next, g, c.n0 + wn * 64 + ecc);   // older than the epilogue's last stores: see NST
         };
-        pp_epilogue<T, EPI, XEARLY>(acc, g, smem, wave, lane, row0, col0, bias, rs, prefetch_next, xc, xq);
+        pp_epilogue<T, EPI, XEARLY>(acc, g, smem, wave, lane, row0, col0, bias, rs, prefetch_next, xc, xq, dbg_iter);
+        PG_TS(g, dbg_iter, wave, 9);
+        ++dbg_iter;
         if (!more) break;
         pin_bias<EPI>(bias_next);
         bias = bias_next;

@@ -205,7 +205,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rowstat_rsrc6(const GemmArgs& 
 template <typename T, int EPI, typename PREFETCH_DMA, typename PREFETCH_BIAS>
 __device__ __forceinline__ void epilogue6(Acc6& acc, const GemmArgs& g, char* smem, int wave, int lane, int row0,
                                           int col0, const Bias6& bias, const Bias6& cs, const RowStat6& rs0,
-                                          __amdgpu_buffer_rsrc_t rrs, PREFETCH_DMA&& prefetch_dma, PREFETCH_BIAS&& prefetch_bias) {
+                                          __amdgpu_buffer_rsrc_t rrs, PREFETCH_DMA&& prefetch_dma, PREFETCH_BIAS&& prefetch_bias,
+                                          int dbg_iter = 0) {
     constexpr int ROWPF = P6_SLAB_ROWF;
     constexpr bool LN = ln6<EPI>();
     const int l15 = lane & 15, lq = lane >> 4;               // MFMA side: row inside a 16-row block, column quad
@@ -265,6 +266,7 @@ __device__ __forceinline__ void epilogue6(Acc6& acc, const GemmArgs& g, char* sm
             __builtin_amdgcn_raw_buffer_store_b128(pk, ro, ooff, 0, 0);
         }
         wave_lds_fence();                                    // slab reads retired before the next slab overwrites it
+        PG_TS(g, dbg_iter, wave, 3 + i);
         if (i == 0) prefetch_bias();                         // next tile's bias (/ nothing else): 32 registers are free now
     }
 }
@@ -304,6 +306,7 @@ __global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
     // operations of an epilogue, at least 5 x 4 stores (+ the bias / row-statistics loads) are younger than all of them
     constexpr int NST = (P6_TM - 1) * 4;
     bool first = true;
+    int dbg_iter = 0;                                        // tile counter of the tools build's time stamps (dead code otherwise)
 
     while (true) {
         Acc6 acc;                                            // not cleared: the first k-step of the tile runs with C = 0
@@ -315,6 +318,7 @@ __global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
         }
         wait_lgkm0();
         raw_barrier();                                       // B_0: K tile 0 visible, previous epilogue's slabs released
+        PG_TS(g, dbg_iter, wave, 0);
         if (follower) raw_barrier();
         ktile6<T, true, 0>(acc, smem, baseA, baseB, c, wave, voffA, voffW, ROWB, true);
         ktile6<T, false, 1>(acc, smem, baseA, baseB, c, wave, voffA, voffW, 2 * ROWB, true);
@@ -322,6 +326,7 @@ __global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
             ktile6<T, false, 0>(acc, smem, baseA, baseB, c, wave, voffA, voffW, (t + 1) * ROWB, true);
             ktile6<T, false, 1>(acc, smem, baseA, baseB, c, wave, voffA, voffW, (t + 2) * ROWB, t + 2 < nt);
         }
+        PG_TS(g, dbg_iter, wave, 1);
         // LN epilogues: colsum of the lane's 8 columns and the row statistics of slab 0, fetched as soon as the 32 fragment
         // registers are dead (after the last MFMA phase); they land under the re-align barrier, the prefetch and slab 0's parking
         const int row0 = c.m0 + wm * (P6_TM * 32), col0 = c.n0 + wn * 64;
@@ -337,6 +342,7 @@ __global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
         if (!follower) raw_barrier();                        // re-align: every wave has left the mainloop
         // inline-asm MFMAs: hipcc pads no "matrix-pipe write -> VALU / LDS read" hazard for the accumulators (see gemm_pp.hip)
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+        PG_TS(g, dbg_iter, wave, 2);
 
         L += nblk;
         const bool more = L < g.ntiles;
@@ -347,7 +353,9 @@ __global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
             issue_dma6<0, P6_NDMA>(c, smem, wave, voffA, voffW, 0);
         };
         auto prefetch_bias = [&]() { load_bias6(bias_next, g, c.n0 + wn * 64 + ecc); };
-        epilogue6<T, EPI>(acc, g, smem, wave, lane, row0, col0, bias, cs, rs0, rrs, prefetch_dma, prefetch_bias);
+        epilogue6<T, EPI>(acc, g, smem, wave, lane, row0, col0, bias, cs, rs0, rrs, prefetch_dma, prefetch_bias, dbg_iter);
+        PG_TS(g, dbg_iter, wave, 9);
+        ++dbg_iter;
         if (!more) break;
         pin_bias6(bias_next);
         bias = bias_next;

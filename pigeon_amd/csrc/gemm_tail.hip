@@ -123,11 +123,13 @@ __global__ __launch_bounds__(64) void gemm_tail_kernel(GemmArgs g, int m_begin) 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 
-    const int rr = lane >> 3, cc = (lane & 7) * 8;
+    // EPI_RESID_STAT uses pp_epilogue's split-halves geometry (columns 4k.. and 32 + 4k.. per lane), everything else 8 consecutive
+    constexpr int HOFF = STAT ? 32 : 4;
+    const int rr = lane >> 3, cc = STAT ? (lane & 7) * 4 : (lane & 7) * 8;
     const int col = col0 + cc;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 b_lo = zero4, b_hi = zero4, s_lo = zero4, s_hi = zero4;
-    if (g.bias) { b_lo = *(const f32x4*)(g.bias + col); b_hi = *(const f32x4*)(g.bias + col + 4); }
+    if (g.bias) { b_lo = *(const f32x4*)(g.bias + col); b_hi = *(const f32x4*)(g.bias + col + HOFF); }
     if constexpr (LN) { s_lo = *(const f32x4*)(g.ex.colsum + col); s_hi = *(const f32x4*)(g.ex.colsum + col + 4); }
     const float qsc = ((EPI == EPI_QKV || EPI == EPI_QKV_LN) && col < g.qcols) ? g.qscale : 1.f;
 
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(64) void gemm_tail_kernel(GemmArgs g, int m_begin) 
         const int row = row0 + r;
         if (row >= g.M) continue;
         f32x4 lo = *(const f32x4*)(slab + r * TL_ROWPF + cc);
-        f32x4 hi = *(const f32x4*)(slab + r * TL_ROWPF + cc + 4);
+        f32x4 hi = *(const f32x4*)(slab + r * TL_ROWPF + cc + HOFF);
         if constexpr (OUT16) {
             if constexpr (LN) {
                 const u32x2 rs = *(const u32x2*)(g.ex.rowstat + (int64_t)row * 2);
@@ -166,16 +168,18 @@ __global__ __launch_bounds__(64) void gemm_tail_kernel(GemmArgs g, int m_begin) 
         } else if constexpr (RESID) {
             float* p = (float*)g.out + (int64_t)row * g.ldc + col;
             f32x4 x = *(const f32x4*)p;
-            f32x4 y = *(const f32x4*)(p + 4);
+            f32x4 y = *(const f32x4*)(p + HOFF);
             x += lo + b_lo;
             y += hi + b_hi;
             *(f32x4*)p = x;
-            *(f32x4*)(p + 4) = y;
+            *(f32x4*)(p + HOFF) = y;
             if constexpr (STAT) {
-                u32x4 h4;
-                h4[0] = pack16x2<T>(x[0], x[1]); h4[1] = pack16x2<T>(x[2], x[3]);
-                h4[2] = pack16x2<T>(y[0], y[1]); h4[3] = pack16x2<T>(y[2], y[3]);
-                *(u32x4*)((uint16_t*)g.ex.x16 + (int64_t)row * g.ldc + col) = h4;
+                u32x2 hx, hy;
+                hx[0] = pack16x2<T>(x[0], x[1]); hx[1] = pack16x2<T>(x[2], x[3]);
+                hy[0] = pack16x2<T>(y[0], y[1]); hy[1] = pack16x2<T>(y[2], y[3]);
+                uint16_t* p16 = (uint16_t*)g.ex.x16 + (int64_t)row * g.ldc + col;
+                *(u32x2*)p16 = hx;
+                *(u32x2*)(p16 + HOFF) = hy;
                 const float s1 = tl_row8_sum(((x[0] + x[1]) + (x[2] + x[3])) + ((y[0] + y[1]) + (y[2] + y[3])));
                 const float s2 = tl_row8_sum(((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3])) +
                                              ((y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3])));
