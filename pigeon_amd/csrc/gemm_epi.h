@@ -77,6 +77,31 @@ __device__ __forceinline__ float quick_gelu(float v) {
     return v * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// Packed-fp32 forms (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two IEEE fp32 operations per instruction, bit-identical to the
+// scalar ones).  They run at the plain VALU rate when no MFMA stream is active on the CU (tools/pipe_rate.hip: 5 cycles alone, 37
+// next to MFMAs -- they share the matrix pipe), which is exactly the situation of a persistent kernel's epilogue: the 16-bit
+// epilogues are VALU-bound there (gemm_pp6.hip, tools/epi_timeline.py), so halving their fma / mul / add count is time saved.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 quick_gelu2(f32x2 v) {
+    const f32x2 t = v * -2.4554669595930157f;
+    f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    e = 1.0f + e;
+    const f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+    return v * r;
+}
+// y = acc * rstd + (-(mean rstd) * colsum + c) on 4 columns, as two packed pairs (same two roundings per element as the fmaf form)
+__device__ __forceinline__ f32x4 ln_fold4(f32x4 acc, float rstd, float mrs, const f32x4& colsum, const f32x4& c) {
+    const f32x2 r2 = {rstd, rstd}, m2 = {-mrs, -mrs};
+    const f32x2 a0 = pk_fma(f32x2{acc[0], acc[1]}, r2, pk_fma(m2, f32x2{colsum[0], colsum[1]}, f32x2{c[0], c[1]}));
+    const f32x2 a1 = pk_fma(f32x2{acc[2], acc[3]}, r2, pk_fma(m2, f32x2{colsum[2], colsum[3]}, f32x2{c[2], c[3]}));
+    return f32x4{a0[0], a0[1], a1[0], a1[1]};
+}
+__device__ __forceinline__ f32x4 quick_gelu4(f32x4 v) {
+    const f32x2 a0 = quick_gelu2(f32x2{v[0], v[1]}), a1 = quick_gelu2(f32x2{v[2], v[3]});
+    return f32x4{a0[0], a0[1], a1[0], a1[1]};
+}
+
 // Apply the epilogue to 4 consecutive columns [col, col+4) of one output row (fp32-out epilogues).
 template <int EPI>
 __device__ __forceinline__ void epi_store_f32x4(const GemmArgs& g, int row, int col, f32x4 v, const f32x4& b4) {

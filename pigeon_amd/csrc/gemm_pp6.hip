@@ -246,19 +246,15 @@ __device__ __forceinline__ void epilogue6(Acc6& acc, const GemmArgs& g, char* sm
                 float rstd, mrs;
                 asm("v_mov_b32 %0, %1" : "=v"(rstd) : "v"(rs[i & 1].v[it][0]));
                 asm("v_mov_b32 %0, %1" : "=v"(mrs) : "v"(rs[i & 1].v[it][1]));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    lo[e] = fmaf(lo[e], rstd, fmaf(-mrs, cs.lo[e], bias.lo[e]));
-                    hi[e] = fmaf(hi[e], rstd, fmaf(-mrs, cs.hi[e], bias.hi[e]));
-                }
+                lo = ln_fold4(lo, rstd, mrs, cs.lo, bias.lo);    // packed fp32: the epilogue is VALU-bound (gemm_epi.h)
+                hi = ln_fold4(hi, rstd, mrs, cs.hi, bias.hi);
             } else {
                 lo += bias.lo; hi += bias.hi;
             }
             if constexpr (qkv6<EPI>()) {
                 if (col0 < g.qcols) { lo *= qsc; hi *= qsc; }
             } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { lo[e] = quick_gelu(lo[e]); hi[e] = quick_gelu(hi[e]); }
+                lo = quick_gelu4(lo); hi = quick_gelu4(hi);
             }
             u32x4 pk;
             pk[0] = pack16x2<T>(lo[0], lo[1]); pk[1] = pack16x2<T>(lo[2], lo[3]);
