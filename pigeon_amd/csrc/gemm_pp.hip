@@ -166,6 +166,7 @@ template <bool WIDE = false>
 __device__ __forceinline__ XCtx make_xctx(const GemmArgs& g, int row0, int col0, int lane) {
     XCtx x;
     int rv = g.M - row0; rv = rv < 0 ? 0 : (rv > 128 ? 128 : rv);
+    rv = __builtin_amdgcn_readfirstlane(rv);   // descriptor stays in SGPRs (hipcc clamps with v_med3_i32, see gemm_pp6.hip rowstat_rsrc6)
     const uint32_t nbytes = rv > 0 ? (uint32_t)(((int64_t)(rv - 1) * g.ldc + 64) * 4) : 0u;
     x.ro = make_rsrc((const char*)g.out + ((int64_t)row0 * g.ldc + col0) * 4, nbytes);
     if (WIDE) {                                              // EPI_RESID_STAT: split-halves geometry, see pp_epilogue
@@ -183,11 +184,14 @@ __device__ __forceinline__ void fetch_xrows_wide(u32x4 (&dst)[8], const XCtx& x)
 #pragma unroll
     for (int it = 0; it < 4; ++it)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) dst[it * 2 + h] = __builtin_amdgcn_raw_buffer_load_b128(x.ro, x.voff + 128 * h, it * x.rstep, 0);
+        for (int h = 0; h < 2; ++h)      // (readfirstlane: the context is built under a wave-uniform `if`, hipcc keeps rstep in a VGPR and
+            dst[it * 2 + h] =            //  wraps every load in a waterfall loop otherwise)
+                __builtin_amdgcn_raw_buffer_load_b128(x.ro, x.voff + 128 * h, __builtin_amdgcn_readfirstlane(it * x.rstep), 0);
 }
 __device__ __forceinline__ void fetch_xrows(u32x4 (&dst)[8], const XCtx& x, int slab) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) dst[it] = __builtin_amdgcn_raw_buffer_load_b128(x.ro, x.voff, slab * x.sstep + it * x.rstep, 0);
+    for (int it = 0; it < 8; ++it)
+        dst[it] = __builtin_amdgcn_raw_buffer_load_b128(x.ro, x.voff, __builtin_amdgcn_readfirstlane(slab * x.sstep + it * x.rstep), 0);
 }
 
 // One K tile in ping-pong form.  D0..D2 = number of this wave's 8 DMAs issued in LOAD phases 0..2 (rest in phase 3).
@@ -310,6 +314,7 @@ __device__ __forceinline__ void load_bias(EpiBias<EPI>& b, const GemmArgs& g, in
 template <int EPI>
 __device__ __forceinline__ void load_rowstat(u32x2 (&rs)[4][4], const GemmArgs& g, int row0, int rr) {
     int rvs = g.M - row0; rvs = rvs < 0 ? 0 : (rvs > 128 ? 128 : rvs);
+    rvs = __builtin_amdgcn_readfirstlane(rvs);   // descriptor stays in SGPRs (hipcc clamps with v_med3_i32, see gemm_pp6.hip rowstat_rsrc6)
     __amdgpu_buffer_rsrc_t rr_s = make_rsrc((const char*)g.ex.rowstat + (int64_t)row0 * 8, (uint32_t)rvs * 8u);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -388,6 +393,7 @@ __device__ __forceinline__ void pp_epilogue(AccPP& acc, const GemmArgs& g, char*
         // rows past M fail the bounds check (stores dropped, loads return 0), so there is no exec-mask branching and
         // no per-store 64-bit address arithmetic: voffset is one VGPR, the slab/iteration row offset is an SGPR.
         int rv = g.M - row0; rv = rv < 0 ? 0 : (rv > 128 ? 128 : rv);
+        rv = __builtin_amdgcn_readfirstlane(rv);   // descriptor stays in SGPRs (hipcc clamps with v_med3_i32, see gemm_pp6.hip rowstat_rsrc6)
         const uint32_t nbytes = rv > 0 ? (uint32_t)(((int64_t)(rv - 1) * g.ldc + 64) * ESZ) : 0u;
         __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)g.out + ((int64_t)row0 * g.ldc + col0) * ESZ, nbytes);
         const int voff = (rr * (int)g.ldc + cc) * ESZ;

@@ -196,6 +196,9 @@ __device__ __forceinline__ void load_rowstat6(RowStat6& rs, __amdgpu_buffer_rsrc
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rowstat_rsrc6(const GemmArgs& g, int row0) {
     int rvs = g.M - row0; rvs = rvs < 0 ? 0 : (rvs > P6_TM * 32 ? P6_TM * 32 : rvs);
+    // wave-uniform, but hipcc clamps with v_med3_i32 (there is no scalar med3): the record count, and with it the whole
+    // descriptor, would sit in VGPRs and every statistics load of the epilogue would be wrapped in a waterfall loop
+    rvs = __builtin_amdgcn_readfirstlane(rvs);
     return make_rsrc((const char*)g.ex.rowstat + (int64_t)row0 * 8, (uint32_t)rvs * 8u);
 }
 
@@ -215,6 +218,7 @@ __device__ __forceinline__ void epilogue6(Acc6& acc, const GemmArgs& g, char* sm
     const int col = col0 + cc;
     const float qsc = (qkv6<EPI>() && col < g.qcols) ? g.qscale : 1.f;
     int rv = g.M - row0; rv = rv < 0 ? 0 : (rv > P6_TM * 32 ? P6_TM * 32 : rv);
+    rv = __builtin_amdgcn_readfirstlane(rv);   // descriptor stays in SGPRs (hipcc clamps with v_med3_i32, see gemm_pp6.hip rowstat_rsrc6)
     const uint32_t nbytes = rv > 0 ? (uint32_t)(((int64_t)(rv - 1) * g.ldc + 64) * 2) : 0u;
     __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)g.out + ((int64_t)row0 * g.ldc + col0) * 2, nbytes);
     const int voff = (rr * (int)g.ldc + cc) * 2;

@@ -321,6 +321,8 @@ __device__ __forceinline__ void epilogue4(Acc4& acc, const GemmArgs& g, char* sm
     const float qsc = ((EPI == EPI_QKV || EPI == EPI_QKV_LN) && col < g.qcols) ? g.qscale : 1.f;
 
     int rv = g.M - row0; rv = rv < 0 ? 0 : (rv > 128 ? 128 : rv);
+
+    rv = __builtin_amdgcn_readfirstlane(rv);   // descriptor stays in SGPRs (hipcc clamps with v_med3_i32, see gemm_pp6.hip rowstat_rsrc6)
     const uint32_t nbytes = rv > 0 ? (uint32_t)(((int64_t)(rv - 1) * g.ldc + 128) * ESZ) : 0u;
     __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)g.out + ((int64_t)row0 * g.ldc + col0) * ESZ, nbytes);
     const int voff = (rr * (int)g.ldc + cc) * ESZ;
