@@ -113,6 +113,9 @@ int pg_tune_gemm_stagger(float fraction);
  * kernels and at most `rows` rows lie beyond the last whole round, those rows go to a small-tile kernel (csrc/gemm_tail.hip)
  * that spreads them over all CUs; 0 = never.  Both kernels produce the same bits for a row: timing only, never results. */
 int pg_tune_gemm_tail_rows(int rows);
+/* ... and only for GEMMs with K >= min_k or N >= min_n (env PIGEON_GEMM_TAIL_MIN_K / PIGEON_GEMM_TAIL_MIN_N; defaults 2048 / 4096:
+ * of the model's four GEMMs the split pays for fc2 and fc1 only).  (0, 0) = every shape.  Timing only, never results. */
+int pg_tune_gemm_tail_shape(int min_k, int min_n);
 int pg_vit_saturation_check(pg_vit* h, int on);
 int pg_vit_saturation_read(pg_vit* h, int64_t* count, int reset);
 

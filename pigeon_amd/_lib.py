@@ -51,6 +51,7 @@ SIGNATURES = {
     "pg_vit_profile_reset": (_I, [_P]),
     "pg_tune_gemm_stagger": (_I, [_F]),
     "pg_tune_gemm_tail_rows": (_I, [_I]),
+    "pg_tune_gemm_tail_shape": (_I, [_I, _I]),
     "pg_vit_saturation_check": (_I, [_P, _I]),
     "pg_vit_saturation_read": (_I, [_P, C.POINTER(_I64), _I]),
     "pg_comm_unique_id": (_I, [_P]),

@@ -509,7 +509,7 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
         const bool six = variant == 56 && pg_gemm_pp6_supported(epi, N, K);
         const bool pp = !six && (variant == 56 || (variant >= 30 && variant < 50)) && N % 256 == 0 && K % 128 == 0;
         const int tail_max = pg_gemm_tail_rows();
-        if ((six || pp) && tail_max > 0 && pg_gemm_tail_supported(epi, N, K)) {
+        if ((six || pp) && tail_max > 0 && (K >= pg_gemm_tail_min_k() || N >= pg_gemm_tail_min_n()) && pg_gemm_tail_supported(epi, N, K)) {
             const int bm = six ? 384 : 256;
             int ncu = pg_num_cus();
             if (pg_gemm_block_cap() > 0 && pg_gemm_block_cap() < ncu) ncu = pg_gemm_block_cap();

@@ -25,6 +25,8 @@ int pg_check_launch(const char* what);          // hipGetLastError -> PG_EHIP + 
 int pg_default_gemm_variant();                   // env PIGEON_GEMM_VARIANT or the built-in default
 int pg_gemm_block_cap();                         // env PIGEON_GEMM_BLOCKS: cap on the persistent GEMMs' grid (0 = one block per CU)
 int pg_num_cus();                               // compute units of the current device (256 on MI355X)
+int pg_gemm_tail_min_n();                        // env PIGEON_GEMM_TAIL_MIN_N: ... or smallest N
+int pg_gemm_tail_min_k();                        // env PIGEON_GEMM_TAIL_MIN_K: smallest K for which the tail split is used
 int pg_gemm_tail_rows();                         // env PIGEON_GEMM_TAIL_ROWS / pg_tune_gemm_tail_rows: most rows handed to gemm_tail.hip (0 = never)
 float pg_gemm_stagger_fraction();                // env PIGEON_GEMM_STAGGER / pg_tune_gemm_stagger: XCD start spread, fraction of a tile period
 

@@ -69,21 +69,30 @@ int pg_num_cus() {
     }
     return n;
 }
-// Rows pg_gemm_launch may hand to gemm_tail.hip instead of giving them a (mostly idle) last round of the persistent kernels.
-// 768 = two 384-row panels: above that the small tiles' lower efficiency starts to eat the round they save.
+// Tail split of pg_gemm_launch (gemm_tail.hip).  ROWS: most rows handed to the small-tile kernel instead of giving them a (mostly
+// idle) last round of the persistent kernels; 768 = two 384-row panels.  The split is used only where it measured positive on the
+// 512-image step (profiles/r02/gemm_tail.txt): K >= 2048 (fc2: a 120 us round saved for a 43 us tail launch, +0.4 % end to end)
+// or N >= 4096 (fc1, +0.1 %); for out-projection and QKV the tail launch costs what the half-idle round did (-0.2 % with all four).
 #define PG_DEFAULT_GEMM_TAIL_ROWS 768
-static int g_tail_rows = -1;
-int pg_gemm_tail_rows() {
-    if (g_tail_rows < 0) {
-        const char* e = getenv("PIGEON_GEMM_TAIL_ROWS");
-        g_tail_rows = e ? atoi(e) : PG_DEFAULT_GEMM_TAIL_ROWS;
-        if (g_tail_rows < 0) g_tail_rows = 0;
-    }
-    return g_tail_rows;
+#define PG_DEFAULT_GEMM_TAIL_MIN_K 2048
+#define PG_DEFAULT_GEMM_TAIL_MIN_N 4096
+static int g_tail_rows = -1, g_tail_min_k = -1, g_tail_min_n = -1;
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : dflt;
+    return v < 0 ? 0 : v;
 }
+int pg_gemm_tail_rows() { if (g_tail_rows < 0) g_tail_rows = env_int("PIGEON_GEMM_TAIL_ROWS", PG_DEFAULT_GEMM_TAIL_ROWS); return g_tail_rows; }
+int pg_gemm_tail_min_k() { if (g_tail_min_k < 0) g_tail_min_k = env_int("PIGEON_GEMM_TAIL_MIN_K", PG_DEFAULT_GEMM_TAIL_MIN_K); return g_tail_min_k; }
+int pg_gemm_tail_min_n() { if (g_tail_min_n < 0) g_tail_min_n = env_int("PIGEON_GEMM_TAIL_MIN_N", PG_DEFAULT_GEMM_TAIL_MIN_N); return g_tail_min_n; }
 extern "C" int pg_tune_gemm_tail_rows(int rows) {
     if (rows < 0 || rows > (1 << 20)) { pg_set_error("tune_gemm_tail_rows: rows must be in [0, 2^20]"); return PG_EINVAL; }
     g_tail_rows = rows;
+    return PG_OK;
+}
+extern "C" int pg_tune_gemm_tail_shape(int min_k, int min_n) {
+    if (min_k < 0 || min_n < 0) { pg_set_error("tune_gemm_tail_shape: negative threshold"); return PG_EINVAL; }
+    g_tail_min_k = min_k; g_tail_min_n = min_n;
     return PG_OK;
 }
 static float g_stagger = -1.f;

@@ -66,6 +66,11 @@ def tune_gemm_tail_rows(rows: int) -> None:
     check(load().pg_tune_gemm_tail_rows(int(rows)), "pg_tune_gemm_tail_rows")
 
 
+def tune_gemm_tail_shape(min_k: int, min_n: int) -> None:
+    """pg_tune_gemm_tail_shape: the tail split is used for GEMMs with K >= min_k or N >= min_n ((0, 0) = all).  Timing only."""
+    check(load().pg_tune_gemm_tail_shape(int(min_k), int(min_n)), "pg_tune_gemm_tail_shape")
+
+
 def rowstat_cast(x: torch.Tensor, out_dtype: torch.dtype = torch.float16, eps: float = 1e-5):
     """x fp32 (rows,1024) -> (16-bit copy, rowstat (rows,2) = (rstd, mean*rstd))."""
     _dev(x, torch.float32)

@@ -180,6 +180,7 @@ def test_gemm_tail_split_changes_nothing(env):
     ops, L = env["ops"], env["lib"]
     M, K = 64 * 256 + 300, 256
     try:
+        ops.tune_gemm_tail_shape(0, 0)                       # the product default splits only K >= 2048 or N >= 4096 (where it pays)
         for N, variant in ((1024, 36), (3072, 56)):
             A, W, bias, X0, cs, rs = _tail_problem(M, N, K, 22 + N)
             ops.tune_gemm_tail_rows(0)
@@ -192,6 +193,7 @@ def test_gemm_tail_split_changes_nothing(env):
                 assert bool((o[M:].float() == 7.0).all())
     finally:
         ops.tune_gemm_tail_rows(768)
+        ops.tune_gemm_tail_shape(2048, 4096)
 
 
 def test_gemm_w4_one_wave_per_simd_kernel(env):
