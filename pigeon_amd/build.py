@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libpigeon_hip.so")
-SOURCES = ["vit.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_pp6.hip", "gemm_w4.hip", "gemm_tail.hip", "attention.hip", "rowops.hip", "preprocess.hip", "geo_proto.hip", "head.hip", "refine.hip", "comm.hip"]
+SOURCES = ["vit.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_pp6.hip", "gemm_w4.hip", "gemm_tail.hip", "gemm_wg2.hip", "attention.hip", "rowops.hip", "preprocess.hip", "geo_proto.hip", "head.hip", "refine.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "pigeon_internal.h"), os.path.join(CSRC, "gemm_epi.h"),
            os.path.join(os.path.dirname(HERE), "include", "pigeon_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

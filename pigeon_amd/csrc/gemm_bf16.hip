@@ -498,6 +498,12 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
 #ifdef PIGEON_ABLATIONS
     if (g_dbg_ts && epi != EPI_PATCH) { g.aux = (const float*)g_dbg_ts; g.stagger = -7; }
 #endif
+#ifdef PIGEON_ABLATIONS
+    if (variant == 72) {                                     // experimental: two workgroups per CU (gemm_wg2.hip)
+        if (!pg_gemm_wg2_supported(epi, N, K)) { pg_set_error("gemm: variant 72 (gemm_wg2) does not support epi=%d N=%d K=%d", epi, N, K); return PG_EINVAL; }
+        return pg_gemm_wg2_launch(dtype, g, epi, s);
+    }
+#endif
     if (variant == 70) {                                     // the whole problem through the small-tile tail kernel (tests, tools)
         if (!pg_gemm_tail_supported(epi, N, K)) { pg_set_error("gemm: variant 70 (gemm_tail) does not support epi=%d N=%d K=%d", epi, N, K); return PG_EINVAL; }
         return pg_gemm_tail_launch(dtype, g, epi, 0, s);

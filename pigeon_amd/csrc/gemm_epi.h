@@ -52,6 +52,12 @@ int pg_gemm_w4_launch(int dtype, GemmArgs g, int epi, hipStream_t s);
 bool pg_gemm_tail_supported(int epi, int N, int K);
 int pg_gemm_tail_launch(int dtype, GemmArgs g, int epi, int m_begin, hipStream_t s);
 
+// gemm_wg2.hip (tools build only, variant 72, experimental): two independent 4-wave workgroups per CU, 128 x 256 tiles
+#ifdef PIGEON_ABLATIONS
+bool pg_gemm_wg2_supported(int epi, int N, int K);
+int pg_gemm_wg2_launch(int dtype, GemmArgs g, int epi, hipStream_t s);
+#endif
+
 // Tools build only: wall-clock stamps (100 MHz) from inside the persistent kernels, blocks 0 and 100, every wave, first 16 tiles:
 // buf[((blk * 16 + tile) * 8 + wave) * 12 + slot].  Armed by pg_dbg_timestamps(buf) (gemm_bf16.hip), read by tools/epi_timeline.py.
 #ifdef PIGEON_ABLATIONS
