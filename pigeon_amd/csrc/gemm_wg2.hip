@@ -12,8 +12,8 @@
 //                (128 accumulator registers, <= 256 VGPRs in all so that two workgroups fit a CU)
 //   K tile     = 32 (ONE k-step), LDS rows of 64 bytes; stage = A 128 rows + W 256 rows = 24 KB, THREE stages = 72 KB per
 //                workgroup (two workgroups: 144 of 160 KB); the epilogue slabs (4 x 8.5 KB) overlay the stages
-//   pipeline   = free running: per K tile { wait for my DMAs of this tile; barrier; issue the DMAs of tile + 2; 8 + 4 fragment
-//                reads and 32 MFMAs in two halves }, one barrier per 32 MFMAs per wave
+//   pipeline   = free running: per K tile { wait for my DMAs of this tile; barrier; issue the DMAs of tile + 2; twelve fragment
+//                reads, then 32 MFMAs in two halves }, one barrier per 32 MFMAs per wave
 //   operands   = direct-to-LDS DMA, one instruction = 16 rows x 64 bytes; bank swizzle on the source address: the 16-byte chunk c
 //                of row r sits in slot c ^ ((r >> 2) & 1) (rows r and r + 4 share banks with a 64-byte pitch)
 //   price      = the weight panel is fetched per 128 instead of 256 (384) rows: +50 % (+80 %) operand bytes per flop.  Whether the
@@ -203,17 +203,23 @@ __global__ __launch_bounds__(256, 2) void gemm_wg2_kernel(GemmArgs g) {
             const int kn = min(kt + 2, nkt - 1);
             issue_dma2(c, smem + refill * G2_STAGE, wave, voffA, voffW, stepA, stepW, kn * G2_ROWB);
             const char* st = smem + stage * G2_STAGE;
-            typename T::v8 fa[4], fb[4];
+            // all twelve fragment reads first (hipcc otherwise serialises {one A read, wait, four MFMAs} to save registers and the
+            // wave stalls on the LDS latency eight times per K tile); the second half's reads land under the first half's MFMAs
+            typename T::v8 fa[2][4], fb[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) fb[j] = *(const typename T::v8*)(st + b_off + j * 16 * G2_ROWB);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = *(const typename T::v8*)(st + a_off + (h * 64 + i * 16) * G2_ROWB);
+                for (int i = 0; i < 4; ++i) fa[h][i] = *(const typename T::v8*)(st + a_off + (h * 64 + i * 16) * G2_ROWB);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[h * 4 + i][j] = T::mfma16(fb[j], fa[i], acc[h * 4 + i][j]);
+                    for (int j = 0; j < 4; ++j) acc[h * 4 + i][j] = T::mfma16(fb[j], fa[h][i], acc[h * 4 + i][j]);
+                __builtin_amdgcn_sched_barrier(0);
             }
             stage = stage == 2 ? 0 : stage + 1;
             refill = refill == 2 ? 0 : refill + 1;
