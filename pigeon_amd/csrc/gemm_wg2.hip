@@ -19,6 +19,10 @@
 //   price      = the weight panel is fetched per 128 instead of 256 (384) rows: +50 % (+80 %) operand bytes per flop.  Whether the
 //                hidden epilogue pays for that is the experiment.
 //
+// To check when it runs: the epilogue uses the packed-fp32 forms (ln_fold4 / quick_gelu4), which share the matrix pipe -- fine in
+// the 8-wave kernels, whose epilogues have the CU to themselves, but here the other workgroup's MFMAs run next to them (37 instead
+// of 5 cycles per packed instruction in tools/pipe_rate.hip); the scalar forms give the same bits.
+//
 // Same MFMA chain per output element as gemm_pp.hip (k-steps ascending, first step onto 0) and the epilogue expressions of
 // gemm_tail.hip / pp_epilogue: results are meant to be bit-identical to variants 36 / 56 / 70.
 #include "gemm_epi.h"
