@@ -11,8 +11,14 @@ from __future__ import annotations
 import os
 from typing import Iterable, Iterator, List, Optional
 
-import torch
-import torch.distributed as dist
+# dmabuf IPC: the host driver of these boxes supports no legacy IPC handles, and RCCL's intra-node transport (and any CUDA-tensor
+# sharing across processes) fails with "hipIpcGetMemHandle: invalid argument" without it.  It has to be in the environment
+# before the HIP runtime initialises, i.e. before the first torch.cuda call of the process -- hence at import time, here and in
+# pigeon_amd/__init__.py, not in init_from_env.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 class Communicator:
@@ -85,6 +91,10 @@ class Communicator:
         rank-major and contiguous -- no packing, no unpacking copies."""
         if self.world_size == 1:
             return list(tensors)
+        devs = {t.device for t in tensors}
+        if len(devs) != 1:
+            # a host tensor (or one on another GPU) among device tensors would hand RCCL a pointer it cannot read
+            raise ValueError(f"gather_many: all tensors must live on ONE device, got {sorted(str(d) for d in devs)}")
         srcs = [t.contiguous() for t in tensors]
         outs = [torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in srcs]
         if srcs[0].is_cuda:
@@ -132,25 +142,62 @@ def init_from_env(backend: Optional[str] = None) -> Communicator:
     return Communicator()
 
 
+def _is_sample_list(b) -> bool:
+    """A per-sample python sequence leaf, e.g. the list of file names default_collate puts next to the tensors."""
+    return isinstance(b, (list, tuple)) and not hasattr(b, "_fields") and len(b) > 0 and not any(
+        torch.is_tensor(x) or isinstance(x, (dict, list, tuple)) for x in b)
+
+
 def _tree_map(fn, *bs):
+    """Apply fn(*leaves) to the per-sample leaves of parallel batches: tensors, and python lists of per-sample scalars /
+    strings (both support `+`-style concatenation and slicing, which is all the padding below needs).  Containers (dict,
+    list, tuple, namedtuple) are rebuilt; anything else (python scalars, None) is carried over from the first batch."""
     b = bs[0]
-    if torch.is_tensor(b):
+    if torch.is_tensor(b) or _is_sample_list(b):
         return fn(*bs)
     if isinstance(b, dict):
         return {k: _tree_map(fn, *[x[k] for x in bs]) for k in b}
     if isinstance(b, (list, tuple)):
-        return type(b)(_tree_map(fn, *[x[i] for x in bs]) for i in range(len(b)))
-    return fn(*[torch.as_tensor(x) for x in bs])
+        items = [_tree_map(fn, *[x[i] for x in bs]) for i in range(len(b))]
+        return type(b)(*items) if hasattr(b, "_fields") else type(b)(items)            # namedtuple batches
+    return b                                                           # python scalars, None, strings: per-batch, not per-sample
+
+
+def _cat(*leaves):
+    if torch.is_tensor(leaves[0]):
+        return torch.cat([x.to(leaves[0].dtype) for x in leaves], dim=0)
+    out = []
+    for x in leaves:
+        out.extend(x)
+    return type(leaves[0])(out)
+
+
+def _first_tensor(b):
+    """First tensor leaf anywhere in a (nested dict / list / tuple) batch, or None."""
+    if torch.is_tensor(b):
+        return b
+    if isinstance(b, dict):
+        it = b.values()
+    elif isinstance(b, (list, tuple)):
+        it = b
+    else:
+        return None
+    for v in it:
+        t = _first_tensor(v)
+        if t is not None:
+            return t
+    return None
 
 
 def _batch_len(b) -> int:
-    if torch.is_tensor(b):
-        return int(b.shape[0])
-    if isinstance(b, dict):
-        return _batch_len(next(iter(b.values())))
+    """Samples in a batch = leading dimension of its first TENSOR leaf (a dict whose first value is a list of strings,
+    or a scalar, must not decide it); a flat list of non-tensors counts its items; an opaque object is dealt whole."""
+    t = _first_tensor(b)
+    if t is not None:
+        return int(t.shape[0]) if t.dim() > 0 else 1
     if isinstance(b, (list, tuple)):
-        return _batch_len(b[0])
-    return 1                                                         # opaque batch object: dealt whole
+        return len(b)
+    return 1
 
 
 def shard_batches(batches: Iterable, rank: int, world_size: int, even: bool = True) -> Iterator:
@@ -185,16 +232,19 @@ def shard_batches(batches: Iterable, rank: int, world_size: int, even: bool = Tr
         if rank < len(group):
             yield group[rank]
         return
-    if not (torch.is_tensor(head[0]) or isinstance(head[0], (dict, list, tuple))):
+    if _first_tensor(head[0]) is None and not _is_sample_list(head[0]):
+        if isinstance(head[0], (dict, list, tuple)):
+            raise ValueError("shard_batches(even=True): the batch holds no tensor leaf to take the batch size from; "
+                             "pass tensors (or a flat list of samples), or even=False")
         i = 0                                                            # opaque batches: whole-batch wrap-around
         while len(group) < world_size:
             group.append(head[i % len(head)])
             i += 1
         yield group[rank]
         return
-    pool = _tree_map(lambda *ts: torch.cat(ts, dim=0), *head)
+    pool = _tree_map(_cat, *head)
     while _batch_len(pool) < bs * (world_size + 1):                 # enough samples for one padded + W-1 filler batches
-        pool = _tree_map(lambda a, b_: torch.cat([a, b_], dim=0), pool, pool)
+        pool = _tree_map(_cat, pool, pool)
     cursor = 0
 
     def take(n):
@@ -206,7 +256,7 @@ def shard_batches(batches: Iterable, rank: int, world_size: int, even: bool = Tr
     last = group[-1]
     short = bs - _batch_len(last)
     if short > 0:
-        group[-1] = _tree_map(lambda a, b_: torch.cat([a, b_.to(a.dtype)], dim=0), last, take(short))
+        group[-1] = _tree_map(_cat, last, take(short))
     while len(group) < world_size:
         group.append(take(bs))
     yield group[rank]

@@ -161,9 +161,13 @@ def evaluate(model: str, dataset, yfcc: bool, landmarks: bool, base_model=None, 
 
 class PanoramaPipeline:
     """The data-parallel inference step (BASELINE.json configs[3]/[4]): every rank runs the ViT + geocell head on
-    its shard of panoramas, ONE all-gather moves per-image embeddings (B,4,1024) f32 + top-k candidates + initial
+    its shard of panoramas, ONE grouped all-gather moves per-image embeddings (B,4,1024) f32 + top-k candidates + initial
     predictions + sample indices to every rank (the reference's accelerator.gather, preprocessing/embed.py:36-37),
-    then each rank refines its 1/W slice of the gathered batch against its replica of the prototype bank."""
+    each rank refines its 1/W slice of the gathered batch against its replica of the prototype bank, and a second, tiny
+    grouped all-gather (12 bytes per panorama) concatenates the refined (lng,lat) / geocell of all slices, so that every
+    rank -- rank 0 in particular -- holds the whole batch's result as the reference's collection loop does
+    (training/train_eval_loop.py:98-112).  All outputs are rank-major; `distributed.restore_order(res['index'], ...)`
+    puts them back in sample order."""
 
     def __init__(self, model: SuperGuessr, refiner: Optional[ProtoRefiner], comm: Optional[Communicator] = None):
         self.model, self.refiner = model, refiner
@@ -178,9 +182,10 @@ class PanoramaPipeline:
             index = torch.arange(B, device=out.embedding.device) + self.comm.rank * B
         emb, topi, topv, llh, idx = self.comm.gather_many([out.embedding, out.top5_geocells.indices,
                                                            out.top5_geocells.values, out.preds_LLH, index.to(out.embedding.device)])
-        res = dict(embedding=emb, index=idx, preds_geocell=topi[:, 0], preds_LLH=llh)
+        res = dict(embedding=emb, index=idx, preds_geocell=topi[:, 0], preds_LLH=llh,
+                   topk_indices=topi, topk_values=topv)
         if self.refiner is not None:
-            r, W = self.comm.rank, self.comm.world_size
+            r = self.comm.rank
             sl = slice(r * B, (r + 1) * B)                                        # this rank's slice of the gathered batch
             if self.refine_events is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -190,5 +195,5 @@ class PanoramaPipeline:
             if self.refine_events is not None:
                 ev[1].record()
                 self.refine_events.append(ev)
-            res['refined_LLH'], res['refined_geocell'] = ref_llh, ref_cell
+            res['refined_LLH'], res['refined_geocell'] = self.comm.gather_many([ref_llh, ref_cell])
         return res

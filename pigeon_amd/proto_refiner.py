@@ -195,13 +195,11 @@ class ProtoRefiner(nn.Module):
         self._device = device
 
     def _temperature_value(self) -> float:
-        """float(temperature) without a device sync per call: the Parameter is read back once and re-read only when its
-        storage was replaced or modified in place (version counter)."""
-        t = self.temperature
-        key = (t.data_ptr(), t._version)
-        if getattr(self, '_temp_key', None) != key:
-            self._temp_key, self._temp_val = key, float(t.data.item())
-        return self._temp_val
+        """float(temperature), read on EVERY call as the reference does (`self.temperature` enters the softmax of each
+        forward, proto_refiner.py:187): an in-place edit through `.data` bumps no version counter, so nothing may be cached.
+        The Parameter normally lives on the host (neither the reference nor evaluate() moves the refiner to the GPU), where
+        this costs nothing; on a device it is one scalar D2H read per forward."""
+        return float(self.temperature.data)
 
     def _device_bank(self, device) -> hip_ops.DeviceBank:
         if self._dbank is None:

@@ -1,0 +1,78 @@
+"""bench.py's multi-rank control flow on the CPU (no GPU here): `--dry-run` swaps the HIP model / refiner for stubs and RCCL for
+gloo, everything else -- self-launch of the N ranks, interleaved sample ids, the two grouped all-gathers of
+PanoramaPipeline.step, restore_order on rank 0, barrier-bracketed timing with max over ranks, ONE JSON line -- is the code the
+GPU run executes (reference launch: accelerate owns process creation, preprocessing/embed.py:55-56,68; collection of all
+ranks' results: training/train_eval_loop.py:98-112)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _check(stdout, n, steps, warmup, launcher):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout                                  # exactly ONE JSON line, from rank 0
+    r = json.loads(lines[0])
+    for k in CONTRACT:
+        assert k in r, k
+    assert r["n_gpus"] == n and r["steps"] == steps and r["warmup"] == warmup and r["dry_run"] is True
+    assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["unit"] == "images/s" and r["vs_baseline"] is None
+    assert r["config"]["images_per_step"] == 6 * 4 * n and r["config"]["parallelism"] == f"dp{n}"
+    assert r["config"]["launcher"] == launcher
+    assert abs(r["value"] - r["config"]["images_per_step"] / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+    g = r["gathered_results"]                                       # rank 0 holds the refined output of ALL ranks, in sample order
+    assert g == {"panoramas": 6 * n, "ranks": n, "refined_shape": [6 * n, 2], "complete_and_in_sample_order": True}
+    assert r["collective"]["nranks"] == n
+    return r
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return env
+
+
+def test_bench_gpus2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the shape of the driver's 1-GPU command."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--panoramas", "6",
+                        "--cells", "50", "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=_env())
+    assert p.returncode == 0, p.stderr[-2000:]
+    _check(p.stdout, 2, 3, 1, "self")
+
+
+def test_bench_under_torchrun():
+    """The driver's N>1 command line: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2."""
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run",
+                        "--panoramas", "6", "--cells", "50", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=_env())
+    assert p.returncode == 0, p.stderr[-2000:]
+    _check(p.stdout, 2, 2, 1, "torchrun")
+
+
+def test_bench_single_rank_dry_run_and_world_mismatch():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--panoramas", "6", "--cells", "50",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=_env())
+    assert p.returncode == 0, p.stderr[-2000:]
+    _check(p.stdout, 1, 2, 1, "direct")
+    env = dict(_env(), WORLD_SIZE="1", RANK="0")                    # a launcher that disagrees with --gpus: loud, not silent
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert p.returncode != 0 and "--gpus 2 but WORLD_SIZE is 1" in p.stderr
+
+
+def test_bench_self_launch_propagates_a_rank_failure():
+    """A rank that dies (here: more ranks than the stub allows via an impossible flag) must fail the launcher, not hang it."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--panoramas", "6", "--cells", "3",
+                        "--topk", "5"], capture_output=True, text=True, timeout=300, env=_env())   # topk > cells: torch.topk raises
+    assert p.returncode != 0

@@ -111,14 +111,20 @@ def _worker(rank, world, port, outdir):
     assert torch.equal(res["index"], torch.cat([torch.arange(B) * world + r for r in range(world)]))
     assert torch.equal(res["preds_geocell"], (want_v.long() * 10))
     assert torch.equal(Refiner.calls[-1], torch.arange(B, dtype=torch.float32) + 100 * rank)   # refined ITS slice only
-    assert torch.equal(res["refined_LLH"][:, 0], (torch.arange(B) + 100 * rank + 0.25).float())
-    assert torch.equal(res["refined_geocell"], (torch.arange(B) + 100 * rank) * 10 + 1)
-    ordered_emb, ordered_llh = distributed.restore_order(res["index"], res["embedding"], res["preds_LLH"])
+    # refined results of ALL ranks are gathered by the step itself (second, tiny grouped all-gather), rank-major
+    assert res["refined_LLH"].shape == (B * world, 2) and res["refined_geocell"].shape == (B * world,)
+    assert torch.equal(res["refined_LLH"][:, 0], (want_v + 0.25).float())
+    assert torch.equal(res["refined_geocell"], want_v.long() * 10 + 1)
+    ordered_emb, ordered_llh, oc = distributed.restore_order(res["index"], res["embedding"], res["preds_LLH"], res["refined_geocell"])
     assert torch.equal(ordered_emb[:, 0, 0], torch.tensor([0., 100., 1., 101., 2., 102.]))
-    # refined results of all ranks, gathered and re-ordered the same way
-    all_cells, = comm.gather_many([res["refined_geocell"]])
-    oc, = distributed.restore_order(res["index"], all_cells)
     assert oc.tolist() == [1, 1001, 11, 1011, 21, 1021]
+    # a host tensor among the gathered ones is refused instead of being handed to the collective as a device pointer
+    # (exercised with the meta device standing in for "another device")
+    try:
+        comm.gather_many([torch.zeros(2, 2), torch.zeros(2, device="meta")])
+        raise AssertionError("mixed-device gather_many must raise")
+    except ValueError:
+        pass
     torch.distributed.destroy_process_group()
 
 
@@ -136,3 +142,34 @@ def test_single_process_communicator_is_identity():
     assert list(shard_batches([1, 2, 3], 0, 1)) == [1, 2, 3]
     assert list(shard_batches(range(5), 1, 2)) == [1, 3, 0]             # batch 4 goes to rank 0; rank 1 wraps to batch 0
     assert list(shard_batches(range(5), 0, 2)) == [0, 2, 4]
+
+
+def test_shard_batches_takes_the_batch_size_from_a_tensor_leaf():
+    """dict batches whose FIRST value is a list of strings (default_collate of file names), namedtuple batches, and a
+    ragged final batch: every rank gets full batches, the string leaves are padded with the same wrap-around samples."""
+    import collections
+    sys.path.insert(0, ROOT)
+    from pigeon_amd.distributed import shard_batches, _batch_len
+
+    def batches():
+        n = 0
+        for bs in (4, 4, 4, 2):
+            yield {"name": [f"img{n + i}" for i in range(bs)], "x": torch.arange(n, n + bs).float()[:, None],
+                   "idx": torch.arange(n, n + bs), "scale": 2.0}
+            n += bs
+    assert _batch_len(next(batches())) == 4
+    r0, r1 = [list(shard_batches(batches(), r, 2)) for r in range(2)]
+    assert [b["idx"].tolist() for b in r0] == [[0, 1, 2, 3], [8, 9, 10, 11]]
+    assert [b["idx"].tolist() for b in r1] == [[4, 5, 6, 7], [12, 13, 0, 1]]
+    assert r1[1]["name"] == ["img12", "img13", "img0", "img1"] and r1[1]["x"][:, 0].tolist() == [12., 13., 0., 1.]
+    NT = collections.namedtuple("NT", "x idx")
+
+    def nt():
+        n = 0
+        for bs in (3, 3, 1):
+            yield NT(torch.arange(n, n + bs).float(), torch.arange(n, n + bs))
+            n += bs
+    out = [list(shard_batches(nt(), r, 2)) for r in range(2)]
+    assert isinstance(out[0][1], NT) and out[0][1].idx.tolist() == [6, 0, 1] and out[1][1].idx.tolist() == [2, 3, 4]
+    with pytest.raises(ValueError):
+        list(shard_batches([{"a": None}, {"a": None}, {"a": None}], 0, 2))
