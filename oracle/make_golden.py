@@ -1,7 +1,7 @@
 """Generate tests/golden/*.npz by running the REAL reference (from /root/reference) on seeded synthetic
 inputs.  Authoring-container only (the GPU box has no /root/reference); the outputs are committed.
 
-    python oracle/make_golden.py [--only vit2|vit24|vit24_trained|head|pipeline|pipeline24|pipeline24_wide|refine|geo]
+    python oracle/make_golden.py [--only vit2|vit24|vit24_trained|head|pipeline|pipeline24|pipeline24_wide|refine|geo|refiner_cache]
 
 Every fixture stores only small tensors (inputs are regenerated from their seeds by
 ``pigeon_amd.synthetic`` on both sides).  What runs for each fixture:
@@ -498,6 +498,37 @@ def main():
                  topk_values=out.top5_geocells.values.numpy(), topk_indices=out.top5_geocells.indices.numpy(),
                  top8_logits=top8.values.detach().numpy(), top8_cells=top8.indices.numpy(), logit_margin=margin.numpy(),
                  default_LLH=llh.numpy(), default_cell=cell.numpy(), default_params=np.array([5, 1.6, 1000], dtype=np.float64))
+
+    if want("refiner_cache"):
+        # The refiner cache exactly as the reference writes it: evaluation/evaluate.py:72-75 builds
+        # ProtoRefiner(20, False, 10000, proto_path, dataset_path, temperature=1) and `torch.save(refiner, proto_model_path)`s the whole
+        # module; a later run reads `torch.load(proto_model_path).protos` (:65-69).  60 cells x 3 prototypes (1.3 MB); the GPU
+        # box has no /root/reference, so the file itself is the fixture (pigeon_amd.proto_refiner.load_refiner_cache reads it
+        # without the reference package).  The bank / training rows are regenerated from the seeds in the side-car .npz.
+        import types
+        C, ppc, bseed = 60, 3, 2
+        bank_rc = synthetic.make_bank(C, ppc, seed=bseed, empty_frac=0.05)
+        csv_rc, ds_rc = os.path.join(tmp, "protos_rc.csv"), os.path.join(tmp, "hf_train_rc")
+        synthetic.write_bank_reference_files(bank_rc, csv_rc, ds_rc)
+        geo_rc = os.path.join(tmp, "geocells_rc.csv")
+        synthetic.write_geocell_csv(geo_rc, synthetic.make_geocells(C, seed=0))
+        ns = reference_loader.load(geo_rc, csv_rc, ds_rc)
+        ref = ns.ProtoRefiner(20, False, 10000, proto_path=csv_rc, dataset_path=ds_rc, temperature=1)
+        mods = {"models": types.ModuleType("models"), "models.proto_refiner": types.ModuleType("models.proto_refiner")}
+        mods["models.proto_refiner"].ProtoRefiner = ns.ProtoRefiner
+        saved = {k: sys.modules.get(k) for k in mods}
+        sys.modules.update(mods)
+        try:
+            torch.save(ref, os.path.join(GOLD, "proto.refiner"))
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v
+        np.savez(os.path.join(GOLD, "refiner_cache.npz"), meta=np.array([C, ppc, bseed]),
+                 n_empty=np.array(int((np.diff(bank_rc.cell_off) == 0).sum())))
+        print("refiner_cache: pickled reference refiner,", os.path.getsize(os.path.join(GOLD, "proto.refiner")), "bytes")
 
     print("golden fixtures written to", GOLD)
 

@@ -14,7 +14,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libpigeon_hip.so")
-SOURCES = ["vit.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_pp6.hip", "gemm_w4.hip", "gemm_tail.hip", "gemm_wg2.hip", "attention.hip", "rowops.hip", "preprocess.hip", "geo_proto.hip", "head.hip", "refine.hip", "comm.hip"]
+# the product library: production kernels only
+SOURCES = ["vit.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_pp6.hip", "gemm_tail.hip", "attention.hip", "rowops.hip",
+           "preprocess.hip", "geo_proto.hip", "head.hip", "refine.hip", "comm.hip"]
+# additionally in the tools build (--dev): experimental kernel generations kept for A/B work (variant 64, gemm_w4.hip)
+DEV_SOURCES = ["gemm_w4.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "pigeon_internal.h"), os.path.join(CSRC, "gemm_epi.h"),
            os.path.join(os.path.dirname(HERE), "include", "pigeon_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -43,10 +47,10 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
     obj_dir = os.path.join(CSRC, "build_dev" if dev else "build")
     lib = os.path.join(HERE, "libpigeon_hip_dev.so" if dev else "libpigeon_hip.so")
     flags = FLAGS + (["-DPIGEON_ABLATIONS"] if dev else [])
-    return _build(obj_dir, lib, flags, force, verbose)
+    return _build(obj_dir, lib, flags, force, verbose, SOURCES + (DEV_SOURCES if dev else []))
 
 
-def _build(OBJ: str, LIB: str, FLAGS, force: bool, verbose: bool) -> str:
+def _build(OBJ: str, LIB: str, FLAGS, force: bool, verbose: bool, SOURCES) -> str:
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
     jobs = []

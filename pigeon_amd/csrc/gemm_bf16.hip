@@ -456,7 +456,7 @@ static int gemm_dispatch(GemmArgs& g, int epi, int variant, hipStream_t s) {
         case 22: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true, 2>(g, epi, s);   // no ds_reads
         case 23: g.gn = 1 << 20; return launch_cfg<T, 256, 256, 2, 4, false, true, 3>(g, epi, s);   // neither
 #endif
-        default: pg_set_error("gemm: variant %d is not part of this build (product variants: 8, 33, 36, 56, 64, 70; the rest needs the "
+        default: pg_set_error("gemm: variant %d is not part of this build (product variants: 8, 33, 36, 56, 70; the rest needs the "
                               "-DPIGEON_ABLATIONS tools build, python -m pigeon_amd.build --dev)", variant); return PG_EINVAL;
     }
 }
@@ -498,12 +498,6 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
 #ifdef PIGEON_ABLATIONS
     if (g_dbg_ts && epi != EPI_PATCH) { g.aux = (const float*)g_dbg_ts; g.stagger = -7; }
 #endif
-#ifdef PIGEON_ABLATIONS
-    if (variant == 72) {                                     // experimental: two workgroups per CU (gemm_wg2.hip)
-        if (!pg_gemm_wg2_supported(epi, N, K)) { pg_set_error("gemm: variant 72 (gemm_wg2) does not support epi=%d N=%d K=%d", epi, N, K); return PG_EINVAL; }
-        return pg_gemm_wg2_launch(dtype, g, epi, s);
-    }
-#endif
     if (variant == 70) {                                     // the whole problem through the small-tile tail kernel (tests, tools)
         if (!pg_gemm_tail_supported(epi, N, K)) { pg_set_error("gemm: variant 70 (gemm_tail) does not support epi=%d N=%d K=%d", epi, N, K); return PG_EINVAL; }
         return pg_gemm_tail_launch(dtype, g, epi, 0, s);
@@ -534,9 +528,14 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
             }
         }
     }
-    if (variant == 64) {                                     // one-wave-per-SIMD persistent kernel where it exists
+    if (variant == 64) {                                     // one-wave-per-SIMD persistent kernel (tools build only)
+#ifdef PIGEON_ABLATIONS
         if (pg_gemm_w4_supported(epi, N, K)) return pg_gemm_w4_launch(dtype, g, epi, s);
         variant = 36;
+#else
+        pg_set_error("gemm: variant 64 (gemm_w4) is experimental and not part of the product library (python -m pigeon_amd.build --dev)");
+        return PG_EINVAL;
+#endif
     }
     if (variant == 56) {                                     // 384 x 256 tiles where they exist, the product kernel elsewhere
         if (pg_gemm_pp6_supported(epi, N, K)) return pg_gemm_pp6_launch(dtype, g, epi, s);

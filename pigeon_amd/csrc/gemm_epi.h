@@ -43,20 +43,17 @@ __device__ __forceinline__ void xcd_stagger_wait(int ticks) {
     while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(16);
 }
 
-// gemm_w4.hip: persistent kernel with one wave per SIMD (4 waves, 128 x 128 wave tiles, accumulators in AGPRs; variant 64)
+// gemm_w4.hip (tools build only, variant 64, experimental): persistent kernel with one wave per SIMD (4 waves, 128 x 128 wave
+// tiles, accumulators in AGPRs).  Level with the ping-pong kernels per K tile, slower end to end.
+#ifdef PIGEON_ABLATIONS
 bool pg_gemm_w4_supported(int epi, int N, int K);
 int pg_gemm_w4_launch(int dtype, GemmArgs g, int epi, hipStream_t s);
+#endif
 
 // gemm_tail.hip: rows [m_begin, M) of a problem in 32 x 64 one-wave tiles, bit-identical to the persistent kernels (variant 70
 // runs a whole problem through it; pg_gemm_launch uses it for the rows that do not fill the persistent kernels' last round)
 bool pg_gemm_tail_supported(int epi, int N, int K);
 int pg_gemm_tail_launch(int dtype, GemmArgs g, int epi, int m_begin, hipStream_t s);
-
-// gemm_wg2.hip (tools build only, variant 72, experimental): two independent 4-wave workgroups per CU, 128 x 256 tiles
-#ifdef PIGEON_ABLATIONS
-bool pg_gemm_wg2_supported(int epi, int N, int K);
-int pg_gemm_wg2_launch(int dtype, GemmArgs g, int epi, hipStream_t s);
-#endif
 
 // Tools build only: wall-clock stamps (100 MHz) from inside the persistent kernels, blocks 0 and 100, every wave, first 16 tiles:
 // buf[((blk * 16 + tile) * 8 + wave) * 12 + slot].  Armed by pg_dbg_timestamps(buf) (gemm_bf16.hip), read by tools/epi_timeline.py.
@@ -106,6 +103,72 @@ __device__ __forceinline__ f32x4 ln_fold4(f32x4 acc, float rstd, float mrs, cons
 __device__ __forceinline__ f32x4 quick_gelu4(f32x4 v) {
     const f32x2 a0 = quick_gelu2(f32x2{v[0], v[1]}), a1 = quick_gelu2(f32x2{v[2], v[3]});
     return f32x4{a0[0], a0[1], a1[0], a1[1]};
+}
+
+// ==== ONE definition of the fused epilogue ARITHMETIC for the slab-transposing kernels (gemm_pp / gemm_pp6 / gemm_tail, and
+// gemm_w4 in the tools build).  Round 2 kept a hand copy of these expressions in every file and held them together with
+// bit-compare tests only; a row's value must not depend on which kernel (persistent tile, tail tile) computed it, so the
+// expressions -- including the association order of the row statistics -- live here and nowhere else.  A lane holds 8 outputs of
+// one row as two f32x4 (`lo`, `hi`); which columns those are (8 consecutive, or 4k.. and 32+4k.. for EPI_RESID_STAT) is the
+// caller's geometry, the arithmetic does not depend on it.
+template <int EPI> constexpr bool epi_is_ln() { return EPI == EPI_QKV_LN || EPI == EPI_GELU_LN; }
+template <int EPI> constexpr bool epi_is_qkv() { return EPI == EPI_QKV || EPI == EPI_QKV_LN; }
+template <int EPI> constexpr bool epi_is_out16() { return EPI == EPI_QKV || EPI == EPI_GELU || EPI == EPI_QKV_LN || EPI == EPI_GELU_LN; }
+
+// 16-bit-output epilogues (EPI_QKV, EPI_GELU and their LayerNorm-fold forms): 8 accumulators -> 8 packed 16-bit outputs.
+//   plain: y = acc + b;   LN fold: y = rstd * acc - (mean rstd) * colsum + c   (c = beta.W^T + b, s = colsum)
+//   QKV:   the Q strip (q_strip: the tile's columns are below qcols -- qcols is a multiple of 8, so a lane's 8 columns are all in
+//          or all out) is scaled by qsc; K / V strips skip the multiply;   GELU: QuickGELU.
+// (rstd, mrs) must come through registers of their own (callers move each half of the loaded pair through an asm v_mov:
+// hipcc, ROCm 7.2, SLP-packs fmas whose multipliers are the two halves of one dwordx2 and drops the op_sel of the high half).
+template <typename T, int EPI>
+__device__ __forceinline__ u32x4 epi16_finish(f32x4 lo, f32x4 hi, const f32x4& b_lo, const f32x4& b_hi, const f32x4& s_lo,
+                                              const f32x4& s_hi, float rstd, float mrs, bool q_strip, float qsc) {
+    if constexpr (epi_is_ln<EPI>()) {
+        lo = ln_fold4(lo, rstd, mrs, s_lo, b_lo);
+        hi = ln_fold4(hi, rstd, mrs, s_hi, b_hi);
+    } else {
+        lo += b_lo; hi += b_hi;
+    }
+    if constexpr (epi_is_qkv<EPI>()) {
+        if (q_strip) { lo *= qsc; hi *= qsc; }
+    } else {
+        lo = quick_gelu4(lo); hi = quick_gelu4(hi);
+    }
+    u32x4 pk;
+    pk[0] = pack16x2<T>(lo[0], lo[1]); pk[1] = pack16x2<T>(lo[2], lo[3]);
+    pk[2] = pack16x2<T>(hi[0], hi[1]); pk[3] = pack16x2<T>(hi[2], hi[3]);
+    return pk;
+}
+
+// fp32 residual epilogues (EPI_RESID, EPI_RESID_STAT): the new residual values of 4 columns
+__device__ __forceinline__ f32x4 epi_resid4(f32x4 x, const f32x4& acc, const f32x4& b) {
+    x += acc + b;
+    return x;
+}
+// EPI_RESID_STAT: 16-bit copy of 4 new residual values
+template <typename T>
+__device__ __forceinline__ u32x2 epi_copy16x4(const f32x4& x) {
+    u32x2 h;
+    h[0] = pack16x2<T>(x[0], x[1]); h[1] = pack16x2<T>(x[2], x[3]);
+    return h;
+}
+// EPI_RESID_STAT: this lane's share (its 8 new values x, y) of the row's partial (sum, sum of squares) over 64 columns -- the
+// association order is part of the result; the 8 lanes of a row are then combined by row8_sum below.
+__device__ __forceinline__ void epi_stat8(const f32x4& x, const f32x4& y, float& s1, float& s2) {
+    s1 = ((x[0] + x[1]) + (x[2] + x[3])) + ((y[0] + y[1]) + (y[2] + y[3]));
+    s2 = ((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3])) + ((y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]));
+}
+// sum over the 8 lanes (lane & 7 = 0..7) that hold one row, fixed association: pairs, quads, then the two quads
+template <int CTRL>
+__device__ __forceinline__ float epi_dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row8_sum(float v) {
+    v += epi_dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += epi_dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += epi_dpp_mov<0x141>(v);      // row_half_mirror: lane i <-> 7 - i inside each group of 8
+    return v;
 }
 
 // Apply the epilogue to 4 consecutive columns [col, col+4) of one output row (fp32-out epilogues).

@@ -332,16 +332,7 @@ __device__ __forceinline__ void pin_bias(EpiBias<EPI>& b) {
 
 // Sum over the 8 consecutive lanes that hold one output row on the 8-columns-per-lane store side, result in every lane;
 // fixed association order, so the row statistics depend on nothing but the data.
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float row8_sum(float v) {
-    v += dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141>(v);      // row_half_mirror: lane i <-> 7 - i inside each group of 8
-    return v;
-}
+// (row8_sum and the epilogue element functions: gemm_epi.h)
 
 template <typename T, int EPI, int XEARLY, typename PREFETCH>
 __device__ __forceinline__ void pp_epilogue(AccPP& acc, const GemmArgs& g, char* smem, int wave, int lane,
@@ -458,51 +449,28 @@ __device__ __forceinline__ void pp_epilogue(AccPP& acc, const GemmArgs& g, char*
                 // corrupted).
                 const int ooff = voff + (i * sstep + it * rstep);
                 if constexpr (OUT16) {
+                    // (rstd, mean * rstd) through an asm move into registers of their own: with the two halves of the loaded
+                    // dwordx2 used directly, hipcc (ROCm 7.2) SLP-packs the fmas and broadcasts the LOW half for both (op_sel of
+                    // the high half dropped): every row used rstd in place of mean*rstd (caught by test_ln_fold_building_blocks).
+                    float rstd = 0.f, mrs = 0.f;
                     if constexpr (LN) {
-                        // LayerNorm applied after the product: rstd * acc - (mean * rstd) * colsum + (beta.W^T + b).
-                        // Both scalars go through an asm move into registers of their own: with (rstd, mean*rstd) left as
-                        // the two halves of the loaded dwordx2, hipcc (ROCm 7.2) SLP-packs the fmas below into
-                        // v_pk_fma_f32 and broadcasts the LOW half for both (op_sel of the high half dropped): every row
-                        // used rstd in place of mean*rstd (caught by test_ln_fold_building_blocks).
-                        float rstd, mrs;
                         asm("v_mov_b32 %0, %1" : "=v"(rstd) : "v"(rs[i][it][0]));
                         asm("v_mov_b32 %0, %1" : "=v"(mrs) : "v"(rs[i][it][1]));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            lo[e] = fmaf(lo[e], rstd, fmaf(-mrs, bias.slo[e], bias.lo[e]));
-                            hi[e] = fmaf(hi[e], rstd, fmaf(-mrs, bias.shi[e], bias.hi[e]));
-                        }
-                    } else {
-                        lo += bias.lo; hi += bias.hi;
                     }
-                    if constexpr (EPI == EPI_QKV || EPI == EPI_QKV_LN) {
-                        // qcols is a multiple of 8, so a lane's 8 columns are all inside or all outside; the factor is a
-                        // per-lane constant of the tile (x * 1.0f is exact) and K / V strips skip the multiply altogether
-                        if (col0 < g.qcols) { lo *= qsc; hi *= qsc; }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { lo[e] = quick_gelu(lo[e]); hi[e] = quick_gelu(hi[e]); }
-                    }
-                    u32x4 pk;
-                    pk[0] = pack16x2<T>(lo[0], lo[1]); pk[1] = pack16x2<T>(lo[2], lo[3]);
-                    pk[2] = pack16x2<T>(hi[0], hi[1]); pk[3] = pack16x2<T>(hi[2], hi[3]);
+                    const u32x4 pk = epi16_finish<T, EPI>(lo, hi, bias.lo, bias.hi, bias.slo, bias.shi, rstd, mrs, col0 < g.qcols, qsc);
                     __builtin_amdgcn_raw_buffer_store_b128(pk, ro, ooff, 0, PP_STORE_AUX);
                 } else if constexpr (RESID) {
-                    f32x4 x = __builtin_bit_cast(f32x4, XEARLY == 1 ? xq[i][it] : xr[i & 1][it][0]);
-                    x += lo + bias.lo;                       // same expression as epi_store_f32x4<EPI_RESID>
+                    const f32x4 x = epi_resid4(__builtin_bit_cast(f32x4, XEARLY == 1 ? xq[i][it] : xr[i & 1][it][0]), lo, bias.lo);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), ro, ooff, 0, PP_STORE_AUX);
                     if constexpr (STAT) {
-                        f32x4 y = __builtin_bit_cast(f32x4, xr[i & 1][it][1]);
-                        y += hi + bias.hi;
+                        const f32x4 y = epi_resid4(__builtin_bit_cast(f32x4, xr[i & 1][it][1]), hi, bias.hi);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, ooff + HOFF * 4, 0, 0);
-                        u32x2 hx, hy;
-                        hx[0] = pack16x2<T>(x[0], x[1]); hx[1] = pack16x2<T>(x[2], x[3]);
-                        hy[0] = pack16x2<T>(y[0], y[1]); hy[1] = pack16x2<T>(y[2], y[3]);
-                        __builtin_amdgcn_raw_buffer_store_b64(hx, rx16, ooff >> 1, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b64(hy, rx16, (ooff >> 1) + HOFF * 2, 0, 0);
-                        const float s1 = row8_sum(((x[0] + x[1]) + (x[2] + x[3])) + ((y[0] + y[1]) + (y[2] + y[3])));
-                        const float s2 = row8_sum(((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3])) +
-                                                  ((y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3])));
+                        __builtin_amdgcn_raw_buffer_store_b64(epi_copy16x4<T>(x), rx16, ooff >> 1, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(epi_copy16x4<T>(y), rx16, (ooff >> 1) + HOFF * 2, 0, 0);
+                        float s1, s2;
+                        epi_stat8(x, y, s1, s2);
+                        s1 = row8_sum(s1);
+                        s2 = row8_sum(s2);
                         if ((lane & 7) == 0) { slab[r * ROWPF + 64] = s1; slab[r * ROWPF + 65] = s2; }
                     }
                 } else {                                     // EPI_F32

@@ -244,25 +244,14 @@ __device__ __forceinline__ void epilogue6(Acc6& acc, const GemmArgs& g, char* sm
             // row offset in the VGPR offset, not the SGPR soffset (hipcc pads no wait states after a >64-bit buffer store
             // with a register soffset: gemm_pp.hip)
             const int ooff = voff + (i * sstep + it * rstep);
+            // LN: each scalar through an asm move of its own (hipcc SLP-packs the fmas into v_pk_fma_f32 and drops the op_sel of the
+            // high half of the loaded pair: gemm_pp.hip); the arithmetic itself is gemm_epi.h epi16_finish (packed fp32 forms)
+            float rstd = 0.f, mrs = 0.f;
             if constexpr (LN) {
-                // rstd * acc - (mean * rstd) * colsum + (beta.W^T + b); each scalar through an asm move of its own (hipcc
-                // SLP-packs the fmas into v_pk_fma_f32 and drops the op_sel of the high half of the loaded pair: gemm_pp.hip)
-                float rstd, mrs;
                 asm("v_mov_b32 %0, %1" : "=v"(rstd) : "v"(rs[i & 1].v[it][0]));
                 asm("v_mov_b32 %0, %1" : "=v"(mrs) : "v"(rs[i & 1].v[it][1]));
-                lo = ln_fold4(lo, rstd, mrs, cs.lo, bias.lo);    // packed fp32: the epilogue is VALU-bound (gemm_epi.h)
-                hi = ln_fold4(hi, rstd, mrs, cs.hi, bias.hi);
-            } else {
-                lo += bias.lo; hi += bias.hi;
             }
-            if constexpr (qkv6<EPI>()) {
-                if (col0 < g.qcols) { lo *= qsc; hi *= qsc; }
-            } else {
-                lo = quick_gelu4(lo); hi = quick_gelu4(hi);
-            }
-            u32x4 pk;
-            pk[0] = pack16x2<T>(lo[0], lo[1]); pk[1] = pack16x2<T>(lo[2], lo[3]);
-            pk[2] = pack16x2<T>(hi[0], hi[1]); pk[3] = pack16x2<T>(hi[2], hi[3]);
+            const u32x4 pk = epi16_finish<T, EPI>(lo, hi, bias.lo, bias.hi, cs.lo, cs.hi, rstd, mrs, col0 < g.qcols, qsc);
             __builtin_amdgcn_raw_buffer_store_b128(pk, ro, ooff, 0, 0);
         }
         wave_lds_fence();                                    // slab reads retired before the next slab overwrites it

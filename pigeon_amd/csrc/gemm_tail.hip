@@ -10,8 +10,8 @@
 //
 // RESULTS ARE BIT-IDENTICAL to the persistent kernels (tests/test_gpu_parity.py::test_gemm_tail_*): every output element is
 // the same chain of v_mfma_f32_16x16x32 over ascending k (same operand roles, first step onto 0), the accumulators go through
-// an LDS slab into the same 8-columns-per-lane geometry, and the epilogue expressions (incl. the association order of the
-// row statistics) are those of gemm_pp.hip pp_epilogue.  So a row's value still does not depend on where in a batch it sits.
+// an LDS slab into the same 8-columns-per-lane geometry, and the epilogue arithmetic (incl. the association order of the
+// row statistics) is the ONE definition in gemm_epi.h that gemm_pp.hip pp_epilogue uses too.  So a row's value still does not depend on where in a batch it sits.
 //
 // No LDS staging of the operands: a wave reads its fragments straight from L2 / HBM into registers (16 rows x 64 contiguous
 // bytes per load instruction), eight k-steps ahead.  A 512-row tail is 1 - 4 GFLOP; the kernel is latency-, not
@@ -39,18 +39,6 @@ __device__ __forceinline__ void load_frag_tl(FragTL<T>& f, __amdgpu_buffer_rsrc_
     for (int i = 0; i < 2; ++i) f.a[i] = __builtin_bit_cast(typename T::v8, __builtin_amdgcn_raw_buffer_load_b128(ra, va[i], kbytes, 0));
 #pragma unroll
     for (int j = 0; j < 4; ++j) f.b[j] = __builtin_bit_cast(typename T::v8, __builtin_amdgcn_raw_buffer_load_b128(rw, vw[j], kbytes, 0));
-}
-
-template <int CTRL>
-__device__ __forceinline__ float tl_dpp_mov(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
-}
-// gemm_pp.hip row8_sum: sum over the 8 lanes of a row, fixed association
-__device__ __forceinline__ float tl_row8_sum(float v) {
-    v += tl_dpp_mov<0xB1>(v);
-    v += tl_dpp_mov<0x4E>(v);
-    v += tl_dpp_mov<0x141>(v);
-    return v;
 }
 
 template <int EPI> constexpr bool tl_out16() { return EPI == EPI_QKV || EPI == EPI_GELU || EPI == EPI_QKV_LN || EPI == EPI_GELU_LN; }
@@ -141,48 +129,29 @@ __global__ __launch_bounds__(64) void gemm_tail_kernel(GemmArgs g, int m_begin) 
         f32x4 lo = *(const f32x4*)(slab + r * TL_ROWPF + cc);
         f32x4 hi = *(const f32x4*)(slab + r * TL_ROWPF + cc + HOFF);
         if constexpr (OUT16) {
+            float rstd = 0.f, mrs = 0.f;
             if constexpr (LN) {
                 const u32x2 rs = *(const u32x2*)(g.ex.rowstat + (int64_t)row * 2);
-                // (the asm moves: see gemm_pp.hip -- hipcc SLP-packs the fmas below and broadcasts the wrong half otherwise)
-                float rstd, mrs;
+                // (the asm moves: see gemm_pp.hip -- hipcc SLP-packs the fmas and broadcasts the wrong half otherwise)
                 asm("v_mov_b32 %0, %1" : "=v"(rstd) : "v"(rs[0]));
                 asm("v_mov_b32 %0, %1" : "=v"(mrs) : "v"(rs[1]));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    lo[e] = fmaf(lo[e], rstd, fmaf(-mrs, s_lo[e], b_lo[e]));
-                    hi[e] = fmaf(hi[e], rstd, fmaf(-mrs, s_hi[e], b_hi[e]));
-                }
-            } else {
-                lo += b_lo; hi += b_hi;
             }
-            if constexpr (EPI == EPI_QKV || EPI == EPI_QKV_LN) {
-                if (col0 < g.qcols) { lo *= qsc; hi *= qsc; }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { lo[e] = quick_gelu(lo[e]); hi[e] = quick_gelu(hi[e]); }
-            }
-            u32x4 pk;
-            pk[0] = pack16x2<T>(lo[0], lo[1]); pk[1] = pack16x2<T>(lo[2], lo[3]);
-            pk[2] = pack16x2<T>(hi[0], hi[1]); pk[3] = pack16x2<T>(hi[2], hi[3]);
-            *(u32x4*)((uint16_t*)g.out + (int64_t)row * g.ldc + col) = pk;
+            *(u32x4*)((uint16_t*)g.out + (int64_t)row * g.ldc + col) =
+                epi16_finish<T, EPI>(lo, hi, b_lo, b_hi, s_lo, s_hi, rstd, mrs, col0 < g.qcols, qsc);
         } else if constexpr (RESID) {
             float* p = (float*)g.out + (int64_t)row * g.ldc + col;
-            f32x4 x = *(const f32x4*)p;
-            f32x4 y = *(const f32x4*)(p + HOFF);
-            x += lo + b_lo;
-            y += hi + b_hi;
+            const f32x4 x = epi_resid4(*(const f32x4*)p, lo, b_lo);
+            const f32x4 y = epi_resid4(*(const f32x4*)(p + HOFF), hi, b_hi);
             *(f32x4*)p = x;
             *(f32x4*)(p + HOFF) = y;
             if constexpr (STAT) {
-                u32x2 hx, hy;
-                hx[0] = pack16x2<T>(x[0], x[1]); hx[1] = pack16x2<T>(x[2], x[3]);
-                hy[0] = pack16x2<T>(y[0], y[1]); hy[1] = pack16x2<T>(y[2], y[3]);
                 uint16_t* p16 = (uint16_t*)g.ex.x16 + (int64_t)row * g.ldc + col;
-                *(u32x2*)p16 = hx;
-                *(u32x2*)(p16 + HOFF) = hy;
-                const float s1 = tl_row8_sum(((x[0] + x[1]) + (x[2] + x[3])) + ((y[0] + y[1]) + (y[2] + y[3])));
-                const float s2 = tl_row8_sum(((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3])) +
-                                             ((y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3])));
+                *(u32x2*)p16 = epi_copy16x4<T>(x);
+                *(u32x2*)(p16 + HOFF) = epi_copy16x4<T>(y);
+                float s1, s2;
+                epi_stat8(x, y, s1, s2);
+                s1 = row8_sum(s1);
+                s2 = row8_sum(s2);
                 if ((lane & 7) == 0) {
                     float* sp = g.ex.statpart + ((int64_t)(col0 / 64) * g.ex.stat_rows + row) * 2;
                     sp[0] = s1; sp[1] = s2;

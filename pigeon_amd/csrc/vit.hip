@@ -522,16 +522,21 @@ extern "C" int pg_vit_forward_hidden(pg_vit* h, const void* pixels, int pix_dtyp
         const size_t wsp = needb / parts;
         PG_HIP(hipEventRecord(h->ev_fork, s));               // the side streams start where the caller's stream stands
         for (int i = 0; i + 1 < parts; ++i) PG_HIP(hipStreamWaitEvent(h->sx[i], h->ev_fork, 0));
-        for (int i = 0; i < parts; ++i) {
+        int rc = PG_OK;
+        for (int i = 0; i < parts && rc == PG_OK; ++i) {
             const int first = i * per, last = (i + 1) * per < n_images ? (i + 1) * per : n_images;
             if (first >= last) continue;
-            RC(run_range(first, last, (char*)workspace + (size_t)i * wsp, i == 0 ? s : h->sx[i - 1]));
+            rc = run_range(first, last, (char*)workspace + (size_t)i * wsp, i == 0 ? s : h->sx[i - 1]);
         }
-        for (int i = 0; i + 1 < parts; ++i) {                 // ... and the caller's stream continues when every part is done
-            PG_HIP(hipEventRecord(h->ev_join[i], h->sx[i]));
-            PG_HIP(hipStreamWaitEvent(s, h->ev_join[i], 0));
+        // ... and the caller's stream continues when every part is done.  Also after a failed launch in the middle: work already
+        // queued on the side streams still writes the caller's buffers, so the caller's stream must not run ahead of it (the
+        // first error code is what is returned; the join's own errors only matter if there was none).
+        for (int i = 0; i + 1 < parts; ++i) {
+            hipError_t e = hipEventRecord(h->ev_join[i], h->sx[i]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s, h->ev_join[i], 0);
+            if (e != hipSuccess && rc == PG_OK) { pg_set_error("vit_forward: joining side stream %d failed: %s", i, hipGetErrorString(e)); rc = PG_EHIP; }
         }
-        return PG_OK;
+        return rc;
     }
     return run_range(0, n_images, (char*)workspace, s);
 }

@@ -17,7 +17,7 @@ import torch
 from .config import DECAY_CONSTANT, EVAL_BATCH_SIZE_PER_GPU
 from .distributed import Communicator
 from .geo_utils import haversine_np
-from .proto_refiner import ProtoRefiner
+from .proto_refiner import ProtoRefiner, load_refiner_cache
 from .super_guessr import SuperGuessr
 
 logger = logging.getLogger('train')
@@ -122,7 +122,10 @@ def evaluate(model: str, dataset, yfcc: bool, landmarks: bool, base_model=None, 
     `base_model`: a `HipCLIPVisionModel` (or None to evaluate on precomputed embeddings).  `model` is the path of
     the head checkpoint (`full_model.load_state(model)`, :46); evaluate() uses the reference's two refiner
     parameter sets (:73-80): first build -> ProtoRefiner(20, False, 10000, temperature=1); cached prototypes ->
-    ProtoRefiner(40, False, 100000, temperature=0.6).
+    ProtoRefiner(40, False, 100000, temperature=0.6).  "Cached" means, in this order: a `bank` argument, the packed CSR
+    file `<proto_model_path>.npz` this package writes at its first build, or the reference's own pickle at
+    `proto_model_path` (`torch.save(refiner, ...)`, read with `load_refiner_cache` -- an existing
+    saved_models/refiner/proto.refiner keeps working).
     """
     import os
     from . import config as cfg
@@ -147,10 +150,19 @@ def evaluate(model: str, dataset, yfcc: bool, landmarks: bool, base_model=None, 
             proto_path, proto_model_path = cfg.PROTO_PATH_LANDMARKS, cfg.PROTO_MODEL_LANDMARKS_PATH
             dataset_path = [cfg.DATASET_PATH_YFCC, cfg.DATASET_PATH_LANDMARKS]
         packed = proto_model_path + '.npz'
+        protos = None
+        if bank is None and not os.path.exists(packed):
+            try:                                                                  # the reference's own cache (:65-69):
+                protos = load_refiner_cache(proto_model_path)                     # torch.load(proto_model_path).protos
+            except FileNotFoundError:
+                pass
         if bank is not None:
             refiner = ProtoRefiner(40, False, 100000, bank=bank, temperature=0.6)
-        elif os.path.exists(packed):                                              # cached bank (:65-69)
+        elif os.path.exists(packed):                                              # cached bank, packed CSR form
             refiner = ProtoRefiner(40, False, 100000, bank=packed, temperature=0.6, verbose=False)
+        elif protos is not None:                                                  # cached prototypes (:76-80)
+            refiner = ProtoRefiner(40, False, 100000, proto_path=proto_path, dataset_path=dataset_path,
+                                   protos=protos, temperature=0.6, verbose=False)
         else:                                                                     # first build (:72-75)
             refiner = ProtoRefiner(20, False, 10000, proto_path=proto_path, dataset_path=dataset_path, temperature=1)
             os.makedirs(os.path.dirname(packed) or '.', exist_ok=True)

@@ -162,6 +162,37 @@ def bank_from_protos(protos: List, dataset_path) -> HostBank:
                     train_emb=train_emb, train_lnglat=train_lnglat)
 
 
+def load_refiner_cache(path: str):
+    """Read the refiner cache the reference writes with `torch.save(refiner, proto_model_path)` and reads back as
+    `torch.load(proto_model_path).protos` (evaluation/evaluate.py:64-75) -- WITHOUT the reference's `models` package on the
+    path: the pickle names `models.proto_refiner.ProtoRefiner` (and, for hedged refiners, `models.layers...`), which a custom
+    unpickler maps onto an empty nn.Module shell that just receives the pickled attribute dict.  Also reads a refiner of THIS
+    package saved the same way.  Returns `.protos`: the reference's list of per-cell HF Datasets / None (feed it to
+    `ProtoRefiner(protos=...)` / `bank_from_protos`) or this package's HostBank.
+    Raises FileNotFoundError like torch.load does (the reference catches exactly that, :68)."""
+    import pickle
+    import types
+
+    class _Shell(nn.Module):
+        """stands in for any class of the reference's `models` package found in the pickle"""
+
+    class _Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module == 'models' or module.startswith('models.'):
+                return _Shell
+            return super().find_class(module, name)
+
+    pm = types.ModuleType('pigeon_amd._refiner_pickle')
+    pm.Unpickler = _Unpickler
+    pm.load = lambda f, **kw: _Unpickler(f, **kw).load()
+    pm.loads = pickle.loads
+    pm.__name__ = 'pickle'                     # torch.load only checks for the attributes it uses
+    obj = torch.load(path, map_location='cpu', pickle_module=pm, weights_only=False)
+    if not hasattr(obj, 'protos'):
+        raise ValueError(f'{path}: the pickled object has no `.protos` (not a refiner cache)')
+    return obj.protos
+
+
 class ProtoRefiner(nn.Module):
     """Proto-Net refinement model (reference models/proto_refiner.py:17-90)."""
 
@@ -181,7 +212,7 @@ class ProtoRefiner(nn.Module):
         if bank is not None:
             host = HostBank.load(bank) if isinstance(bank, str) else (HostBank(**bank) if isinstance(bank, dict) else bank)
         elif protos is not None:
-            host = bank_from_protos(protos, dataset_path)
+            host = protos if isinstance(protos, HostBank) else bank_from_protos(protos, dataset_path)
         else:
             print('Initializing ProtoRefiner. This might take a while ...')
             host = build_bank(proto_path, dataset_path, verbose)

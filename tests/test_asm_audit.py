@@ -25,3 +25,48 @@ def test_hot_kernels_have_no_waterfall_loops_and_no_spills(hip_lib):
     for name, v in hot.items():
         if "gemm_pp6_kernel" in name or "gemm_pp_kernel" in name:
             assert v["vgpr"] <= 256 and v["agpr"] == 0, name
+
+
+def test_mfma_result_hazard_detector_on_synthetic_isa():
+    """The detector itself: an asm-issued MFMA whose destination is read too early is reported; the accumulate chain, an
+    `s_nop 7` pad and unrelated instructions are not."""
+    import asm_audit
+    dis = """
+0000000000001000 <bad_kernel>:
+	v_mfma_f32_16x16x32_f16 v[0:3], v[128:131], v[160:163], v[0:3]
+	v_mfma_f32_16x16x32_f16 v[0:3], v[132:135], v[164:167], v[0:3]
+	s_nop 1
+	v_add_f32_e32 v9, v2, v8
+	s_endpgm
+0000000000002000 <good_kernel>:
+	v_mfma_f32_16x16x32_f16 v[0:3], v[128:131], v[160:163], 0
+	v_mfma_f32_16x16x32_f16 v[0:3], v[132:135], v[164:167], v[0:3]
+	v_mfma_f32_16x16x32_f16 v[4:7], v[132:135], v[164:167], v[4:7]
+	v_add_f32_e32 v9, v10, v8
+	s_nop 7
+	ds_write_b128 v20, v[0:3]
+	s_endpgm
+0000000000003000 <bad_overwrite>:
+	v_mfma_f32_32x32x16_f16 v[0:15], v[128:131], v[160:163], v[0:15]
+	s_nop 7
+	v_mov_b32_e32 v15, 0
+	s_endpgm
+"""
+    hz = asm_audit.mfma_hazards(dis)
+    assert set(hz) == {"bad_kernel", "bad_overwrite"}, hz
+    assert hz["bad_kernel"][0][2] == 3 and "v_add_f32" in hz["bad_kernel"][0][1]          # first MFMA: chained MFMA + s_nop 1 = 3 states where 8 are needed
+    assert hz["bad_overwrite"][0][2] == 8                                                  # 8 states where the 8-pass op needs 12
+
+
+def test_asm_mfma_results_are_never_touched_early(hip_lib):
+    """ADVICE r02 (common.h:69): the persistent GEMMs issue MFMAs as inline asm, where hipcc pads no hazards -- the hand-placed
+    `s_nop 7; s_nop 7` / barriers are checked in the final ISA of every kernel of the product library."""
+    import asm_audit
+    lib = os.path.join(ROOT, "pigeon_amd", "libpigeon_hip.so")
+    hz = asm_audit.audit_hazards(lib)
+    assert not hz, {k: v[:2] for k, v in hz.items()}
+    # and the scan really saw the MFMA kernels (K = 128 instantiations included: every gemm_pp / pp6 / tail kernel)
+    n = 0
+    for co in asm_audit.code_objects(lib):
+        n += co.count(b"gemm_pp6_kernel") + co.count(b"gemm_tail_kernel")
+    assert n > 0

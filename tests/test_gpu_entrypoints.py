@@ -512,3 +512,50 @@ def test_evaluate_entry_point(env, tmp_path, capsys):
         assert np.array_equal(res3["preds"], res["preds"])
     finally:
         cfg.PROTO_MODEL_PATH = old
+
+
+def test_evaluate_consumes_the_references_refiner_cache(env, golden_dir, tmp_path, capsys):
+    """evaluation/evaluate.py:64-80: with `proto_model_path` present, the reference reads `torch.load(path).protos` and builds
+    ProtoRefiner(40, False, 100000, protos=protos, temperature=0.6).  The file here IS a reference pickle
+    (tests/golden/proto.refiner, written by the reference's own class via torch.save): evaluate() must pick it up -- not rebuild
+    from the CSV, not look for this package's packed .npz only -- and refine with those settings."""
+    import shutil
+    from pigeon_amd import config as cfg
+    from pigeon_amd.clip_embedder import HipCLIPVisionModel
+    from pigeon_amd.evaluate import evaluate
+    syn, orc = env["syn"], env["orc"]
+    C, ppc, bseed = [int(x) for x in _gold(golden_dir, "refiner_cache.npz")["meta"]]
+    geo = _geocells_csv(tmp_path, C)
+    W, b = syn.make_head_weights(C, seed=5)
+    head = os.path.join(str(tmp_path), "head.model")
+    torch.save({"cell_layer.weight": W * 8, "cell_layer.bias": b}, head)
+    vit_sd = syn.make_vit_weights(seed=11, layers=1, affine_jitter=True)
+    base = HipCLIPVisionModel(vit_sd, layers=1)
+    bank = syn.make_bank(C, ppc, seed=bseed, empty_frac=0.05)
+    ds = os.path.join(str(tmp_path), "hf")
+    syn.write_bank_reference_files(bank, os.path.join(str(tmp_path), "unused_protos.csv"), ds)     # only the training rows are read
+    px = syn.make_pixels(4 * 6, seed=21, panorama=True)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self): return 6
+        def __getitem__(self, i):
+            if isinstance(i, str):
+                return {"labels": np.zeros((6, 2)), "labels_clf": np.zeros(6, dtype=np.int64)}[i]
+            return {"pixel_values": px[i], "labels": torch.zeros(2, dtype=torch.float64), "labels_clf": torch.tensor(0)}
+
+    old = cfg.PROTO_MODEL_PATH
+    cfg.PROTO_MODEL_PATH = os.path.join(str(tmp_path), "saved_models", "refiner", "proto.refiner")
+    os.makedirs(os.path.dirname(cfg.PROTO_MODEL_PATH))
+    shutil.copy(os.path.join(golden_dir, "proto.refiner"), cfg.PROTO_MODEL_PATH)
+    try:
+        res = evaluate(head, DS(), yfcc=False, landmarks=False, base_model=base, refine=True, geocell_path=geo,
+                       proto_path=os.path.join(str(tmp_path), "does_not_exist.csv"), dataset_path=ds)
+    finally:
+        cfg.PROTO_MODEL_PATH = old
+    out = capsys.readouterr().out
+    assert "topk\t\t= 40" in out and "max_refinement\t= 100000" in out and "temperature\t= 0.6" in out
+    assert not os.path.exists(os.path.join(str(tmp_path), "saved_models", "refiner", "proto.refiner.npz"))   # nothing was rebuilt
+    o = orc.super_guessr_forward(W * 8, b, torch.from_numpy(syn.make_geocells(C, seed=0)), 50, vit_sd=vit_sd, pixel_values=px)
+    assert np.array_equal(res["preds_geocells"], o["preds_geocell"].numpy())
+    r = orc.proto_refiner_forward(bank, o["embedding"], o["preds_LLH"], o["topk"].indices, o["topk"].values, 40, 0.6, 100000)
+    assert np.array_equal(res["preds"], r[1].numpy())

@@ -53,7 +53,7 @@ def _geocells_csv(tmp_path, C, seed=0):
 
 # ------------------------------------------------------------------------------------------------ kernels
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("variant,K", [(0, 384), (8, 320), (33, 384), (36, 640), (56, 640), (64, 384)])
+@pytest.mark.parametrize("variant,K", [(0, 384), (8, 320), (33, 384), (36, 640), (56, 640)])
 def test_gemm_epilogues(env, dt, variant, K):
     ops, L = env["ops"], env["lib"]
     g = torch.Generator().manual_seed(3)
@@ -81,7 +81,7 @@ def test_gemm_epilogues(env, dt, variant, K):
     assert torch.allclose(X.cpu(), X0 + acc + bias.cpu(), rtol=1e-5, atol=1e-4)
 
 
-MFMA16_VARIANTS = (33, 36, 56, 64)      # kernels built on v_mfma_f32_16x16x32 (k = 32 per instruction); the others use 32x32x16
+MFMA16_VARIANTS = (33, 36, 56)          # kernels built on v_mfma_f32_16x16x32 (k = 32 per instruction); the others use 32x32x16
 
 
 def test_gemm_persistent_many_tiles_bit_identical(env):
@@ -202,6 +202,8 @@ def test_gemm_w4_one_wave_per_simd_kernel(env):
     LayerNorm-fold ones, many tiles per block, ragged M, guard rows -- and to bit-exactness against ITSELF across batch
     positions (a row's result must not depend on which tile / block computes it)."""
     ops, L = env["ops"], env["lib"]
+    if not L.LIB_PATH.endswith("_dev.so"):
+        pytest.skip("variant 64 lives in the tools build only (PIGEON_HIP_LIB=pigeon_amd/libpigeon_hip_dev.so)")
     g = torch.Generator().manual_seed(10)
     M, N, K = 70 * 256 + 19, 1024, 256
     dt = torch.float16

@@ -9,6 +9,7 @@ Where the reference tree is present (/root/reference, authoring container) the i
 classes through oracle/reference_loader.py; the committed fixtures (tests/golden/geo.npz) cover the rest.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -152,6 +153,46 @@ def test_bank_from_protos_on_the_references_own_protos(tmp_path):
     _arrays_equal(hb, bank)
 
 
+@needs_reference
+def test_load_refiner_cache_reads_the_references_pickle(tmp_path):
+    """evaluation/evaluate.py:64-75: the reference caches the whole refiner with `torch.save(refiner, proto_model_path)` and
+    reads `torch.load(...).protos` back.  Written here by the reference's OWN class exactly that way; read back without the
+    reference package importable (the loader must not need `models.proto_refiner`), converted to the CSR bank."""
+    import types
+    from pigeon_amd.proto_refiner import ProtoRefiner, bank_from_protos, load_refiner_cache
+    C = 24
+    bank = synthetic.make_bank(C, 5, seed=3, empty_frac=0.1)
+    proto_csv = os.path.join(str(tmp_path), "protos.csv")
+    ds_dir = os.path.join(str(tmp_path), "hf_train")
+    synthetic.write_bank_reference_files(bank, proto_csv, ds_dir)
+    ns = reference_loader.load(_geo_csv(tmp_path, C), proto_csv, ds_dir)
+    ref = ns.ProtoRefiner(20, False, 10000, proto_path=proto_csv, dataset_path=ds_dir, temperature=1)     # evaluate.py:73-74
+    path = os.path.join(str(tmp_path), "proto.refiner")
+    # pickle locates classes by module path: expose the reference's module under its real name for the duration of the save
+    mods = {"models": types.ModuleType("models"), "models.proto_refiner": types.ModuleType("models.proto_refiner")}
+    mods["models.proto_refiner"].ProtoRefiner = ns.ProtoRefiner
+    saved = {k: sys.modules.get(k) for k in mods}
+    sys.modules.update(mods)
+    try:
+        torch.save(ref, path)                                                                            # evaluate.py:75
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    assert "models.proto_refiner" not in sys.modules                     # the read below cannot lean on the reference's code
+    protos = load_refiner_cache(path)
+    assert isinstance(protos, list) and len(protos) == C
+    assert sum(p is None for p in protos) == int((np.diff(bank.cell_off) == 0).sum()) > 0
+    _arrays_equal(bank_from_protos(protos, ds_dir), bank)
+    with pytest.raises(FileNotFoundError):                               # what the reference's `except FileNotFoundError` relies on
+        load_refiner_cache(os.path.join(str(tmp_path), "nope.refiner"))
+    torch.save({"not": "a refiner"}, path + ".bad")
+    with pytest.raises(ValueError):
+        load_refiner_cache(path + ".bad")
+
+
 # ------------------------------------------------------------------------------------------------ metrics
 def test_compute_geoguessr_metrics_matches_reference_fixture(golden_dir):
     """tests/golden/geo.npz holds the outputs of the reference's own percentage_within_radius / geoguessr_score /
@@ -249,3 +290,19 @@ def test_fast_golden_fixtures_regenerate_bit_identically(tmp_path, golden_dir, m
                 np.testing.assert_allclose(a[k][m], b[k][m], rtol=3e-5, atol=0.5)
                 continue
             assert np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"), (name, k)
+
+
+def test_load_refiner_cache_committed_reference_pickle(golden_dir, tmp_path):
+    """tests/golden/proto.refiner was written by the REFERENCE's ProtoRefiner through torch.save (oracle/make_golden.py --only
+    refiner_cache); this runs everywhere (no /root/reference needed): the cache is readable without the reference package and
+    converts to exactly the bank it was built from."""
+    from pigeon_amd.proto_refiner import bank_from_protos, load_refiner_cache
+    meta = np.load(os.path.join(golden_dir, "refiner_cache.npz"))
+    C, ppc, bseed = [int(x) for x in meta["meta"]]
+    assert "models.proto_refiner" not in sys.modules
+    protos = load_refiner_cache(os.path.join(golden_dir, "proto.refiner"))
+    assert len(protos) == C and sum(p is None for p in protos) == int(meta["n_empty"])
+    bank = synthetic.make_bank(C, ppc, seed=bseed, empty_frac=0.05)
+    ds_dir = os.path.join(str(tmp_path), "hf_train")
+    synthetic.write_bank_reference_files(bank, os.path.join(str(tmp_path), "protos.csv"), ds_dir)
+    _arrays_equal(bank_from_protos(protos, ds_dir), bank)

@@ -166,3 +166,28 @@ def test_pipeline24_head_and_refine_match_reference(golden_dir, tmp_path):
         assert np.array_equal(cell.numpy(), g[f"{tag}_cell"]) and np.array_equal(llh.numpy(), g[f"{tag}_LLH"])
         changed += int((g[f"{tag}_cell"] != g["preds_geocell"]).sum())
     assert changed > 0                                                      # refinement genuinely re-ranks in this fixture
+
+
+def test_pipeline24_wide_head_and_refine_match_reference(golden_dir, tmp_path):
+    """Round 3's 128-panorama fixture (one full bench step, the REAL reference from the pixels): the oracle's head + default
+    refiner, fed with the reference's embeddings, reproduce the reference's argmax / top-8 logits / margins / refined outputs."""
+    g = _load(golden_dir, "pipeline24_wide.npz")
+    wseed, layers, NP, pseed, C, ppc, bseed, maxm = [int(x) for x in g["meta"]]
+    assert NP == 128
+    W0, _ = synthetic.make_head_weights(C, seed=0)
+    cen = _geocells_like_reference(C, 0, tmp_path)
+    emb = torch.from_numpy(g["embedding"])
+    o = orc.super_guessr_forward(W0 * float(g["head_scale"]), torch.from_numpy(g["head_bias"]), cen, 50, embedding=emb)
+    assert np.array_equal(o["preds_geocell"].numpy(), g["preds_geocell"])
+    assert np.array_equal(o["topk"].indices.numpy(), g["topk_indices"])
+    top8 = torch.topk(o["logits"], 8, dim=-1)
+    assert np.array_equal(top8.indices.numpy(), g["top8_cells"])
+    np.testing.assert_allclose(top8.values.numpy(), g["top8_logits"], rtol=0, atol=2e-5)      # fp32 GEMV order on another thread count
+    margin = g["logit_margin"]
+    assert len(set(g["preds_geocell"].tolist())) >= 100 and margin.min() > 0 and (margin < 0.03).sum() >= 2   # honest near-ties inside
+    bank = synthetic.make_bank(C, ppc, seed=bseed, empty_frac=0.01, max_members=maxm, center=g["center"], radius=float(g["radius"]))
+    topk, T, mr = g["default_params"]
+    _, llh, cell = orc.proto_refiner_forward(bank, emb, torch.from_numpy(g["preds_LLH"]), torch.from_numpy(g["topk_indices"]),
+                                             torch.from_numpy(g["topk_values"]), int(topk), float(T), float(mr))
+    assert np.array_equal(cell.numpy(), g["default_cell"]) and np.array_equal(llh.numpy(), g["default_LLH"])
+    assert int((g["default_LLH"] != g["preds_LLH"].astype(np.float32)).any(axis=1).sum()) > 100              # refinement moves the points
