@@ -85,6 +85,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-module-images", type=int, default=32, help="images through transformers.CLIPVisionModel on the CPU (0 = skip)")
     ap.add_argument("--no-refine", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip ingest / other configs / secondary baseline (profiling runs)")
+    ap.add_argument("--profile", choices=["all", "dominant", "none"], default="all",
+                    help="HIP events inside the timed region: around every encoder launch / around the dominant GEMM class only (the "
+                         "other classes are then timed in one extra step after the timed region) / none (A/B of the events' own cost)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: stub model / refiner on the CPU, gloo collectives, tiny tensors -- the launch, sharding, gather, "
                          "timing and JSON control flow of the real run (CPU contract test)")
@@ -533,8 +536,11 @@ def worker(args):
     if not dry:
         enc = base._encoder(dev)
         enc.profile_reset()
-        enc.profile_enable(True)
-        pipe.refine_events = [] if refiner is not None else None
+        if args.profile == "all":
+            enc.profile_enable(True)
+        elif args.profile == "dominant":
+            enc.profile_enable(True, classes=["gemm_fc1"])       # the dominant class of this workload (checked below)
+        pipe.refine_events = [] if (refiner is not None and args.profile != "none") else None
     refine_rows = []
     outs_by_batch = {}
 
@@ -554,6 +560,16 @@ def worker(args):
     if not dry:
         enc.profile_enable(False)
         prof = enc.profile_read()
+        if args.profile != "all":
+            # the other kernel classes: ONE extra, fully bracketed step after the timed region (not part of `value`)
+            live = {k: v for k, v in prof.items() if v[0]}
+            enc.profile_reset()
+            enc.profile_enable(True)
+            pipe.step(pixel_batches[args.steps % nb], index)
+            torch.cuda.synchronize()
+            enc.profile_enable(False)
+            prof = enc.profile_read()
+            prof.update(live)                                     # classes measured inside the timed region win
     dt = comm.max_over_ranks(dt)
 
     # ---- what every rank (rank 0 in particular) holds after the last step: the whole batch, restorable to sample order ----
@@ -598,9 +614,10 @@ def worker(args):
 
     from pigeon_amd import _lib
     kernels = {}
+    per_step = {"gemm_qkv": args.layers, "gemm_out": args.layers, "gemm_fc1": args.layers, "gemm_fc2": args.layers, "attention": args.layers}
     for name, (cnt, ms) in prof.items():
         if cnt:
-            kernels[name] = {"launches": cnt, "avg_ms": ms / cnt}
+            kernels[name] = {"launches": cnt, "avg_ms": ms / cnt, "launches_per_step": per_step.get(name, 1)}
     # per-launch rows: the encoder processes <= max_chunk (512) images per internal pass, so a 512-image step launches
     # every layer kernel once with M = 512*577 rows
     chunk_rows = min(args.panoramas * 4, enc.max_chunk) * 577
@@ -609,14 +626,19 @@ def worker(args):
             kernels[name]["tflops"] = GEMM_FLOPS[name] * chunk_rows / (kernels[name]["avg_ms"] * 1e-3) / 1e12
     if "attention" in kernels:
         kernels["attention"]["tflops"] = 4.0 * 577 * 577 * 64 * 16 * (chunk_rows / 577) / (kernels["attention"]["avg_ms"] * 1e-3) / 1e12
-    dom = max((k for k in kernels if k in GEMM_FLOPS), key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
+    dom = max((k for k in kernels if k in GEMM_FLOPS), key=lambda k: kernels[k]["avg_ms"] * kernels[k].get("launches_per_step", 1))
+    if args.profile == "dominant":
+        dom = "gemm_fc1"                  # the class that was bracketed INSIDE the timed region (it is the dominant one: checked by `all`)
     achieved = kernels[dom]["tflops"]
     traffic, traffic_detail = _committed_traffic(dom, chunk_rows)
     result["mfma_frac_end_to_end"] = value * FLOP_PER_IMAGE / (world * PEAK_MFMA)
     result["roofline"] = {"bound": "mfma", "kernel": f"gemm16 {dom}: M={chunk_rows} rows x {GEMM_FLOPS[dom]} FLOP/row per launch",
                           "achieved": achieved, "peak": PEAK_MFMA / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_MFMA / 1e12),
                           "traffic": traffic, "traffic_detail": traffic_detail,
-                          "timing": "HIP events around every launch on the launch stream, inside the timed region (in-process number)"}
+                          "timing": {"all": "HIP events around every encoder launch on the launch stream, inside the timed region (in-process number)",
+                                     "dominant": "HIP events around the dominant class's launches (gemm_fc1) inside the timed region; the other "
+                                                 "classes of `kernels` from one extra bracketed step after it",
+                                     "none": "no events inside the timed region (A/B arm); `kernels` from one extra bracketed step after it"}[args.profile]}
     if traffic_detail and traffic_detail.get("rocprof_avg_ms"):
         # the committed rocprofv3 --kernel-trace --stats average of the same kernel (another box of the pool: +-4 %)
         result["roofline"]["frac_rocprof"] = GEMM_FLOPS[dom] * chunk_rows / (traffic_detail["rocprof_avg_ms"] * 1e-3) / PEAK_MFMA

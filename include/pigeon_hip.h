@@ -92,7 +92,9 @@ int pg_vit_destroy(pg_vit* h);
 int pg_vit_mma_dtype(const pg_vit* h);
 
 /* Per-kernel-class timing (HIP events on `stream`), for bench.py's roofline object.
- * pg_vit_profile_enable(h,1) makes subsequent forwards bracket every launch with events;
+ * pg_vit_profile_enable(h,1) makes subsequent forwards bracket every launch with events; a value >= 2 is a class mask
+ * shifted left by one (bit c+1 = class c, e.g. 1 << 3 = the fc1 GEMMs only): bench.py --profile dominant keeps just the
+ * dominant class's events inside its timed region; 0 switches the events off;
  * pg_vit_profile_read synchronises those events and returns, per class, launches and total milliseconds.
  * Classes: 0 gemm_qkv 1 gemm_out 2 gemm_fc1 3 gemm_fc2 4 gemm_patch 5 attention 6 layernorm 7 im2col
  *          8 token_mean  (PG_PROF_CLASSES entries). */

@@ -502,18 +502,26 @@ def main():
     if want("refiner_cache"):
         # The refiner cache exactly as the reference writes it: evaluation/evaluate.py:72-75 builds
         # ProtoRefiner(20, False, 10000, proto_path, dataset_path, temperature=1) and `torch.save(refiner, proto_model_path)`s the whole
-        # module; a later run reads `torch.load(proto_model_path).protos` (:65-69).  60 cells x 3 prototypes (1.3 MB); the GPU
+        # module; a later run reads `torch.load(proto_model_path).protos` (:65-69).  56 cells x 2 prototypes (evaluate() asks the head for 50 candidates, so C >= 50); the GPU
         # box has no /root/reference, so the file itself is the fixture (pigeon_amd.proto_refiner.load_refiner_cache reads it
         # without the reference package).  The bank / training rows are regenerated from the seeds in the side-car .npz.
         import types
-        C, ppc, bseed = 60, 3, 2
-        bank_rc = synthetic.make_bank(C, ppc, seed=bseed, empty_frac=0.05)
+        C, ppc, bseed = 56, 2, 2
+        bank_rc = synthetic.make_bank(C, ppc, seed=bseed, empty_frac=0.05, max_members=3)
         csv_rc, ds_rc = os.path.join(tmp, "protos_rc.csv"), os.path.join(tmp, "hf_train_rc")
         synthetic.write_bank_reference_files(bank_rc, csv_rc, ds_rc)
         geo_rc = os.path.join(tmp, "geocells_rc.csv")
         synthetic.write_geocell_csv(geo_rc, synthetic.make_geocells(C, seed=0))
         ns = reference_loader.load(geo_rc, csv_rc, ds_rc)
         ref = ns.ProtoRefiner(20, False, 10000, proto_path=csv_rc, dataset_path=ds_rc, temperature=1)
+        # `datasets` pickles a memory-mapped table as the PATH of its Arrow cache file, so the reference's cache is only readable
+        # on the machine that wrote it (fine for the reference: same box).  A committed fixture must travel: move every per-cell
+        # dataset into memory (same rows, same features, same torch format) before pickling.
+        import datasets as _ds
+        ref.protos = [None if p is None else _ds.Dataset.from_dict(p.with_format(None)[:], features=p.features).with_format("torch")
+                      for p in ref.protos]
+        tr = ref.dataset["train"]                     # the refiner also carries the training DatasetDict it was built from
+        ref.dataset = _ds.DatasetDict(train=_ds.Dataset.from_dict(tr.with_format(None)[:], features=tr.features).with_format(**tr.format))
         mods = {"models": types.ModuleType("models"), "models.proto_refiner": types.ModuleType("models.proto_refiner")}
         mods["models.proto_refiner"].ProtoRefiner = ns.ProtoRefiner
         saved = {k: sys.modules.get(k) for k in mods}
@@ -526,7 +534,7 @@ def main():
                     sys.modules.pop(k, None)
                 else:
                     sys.modules[k] = v
-        np.savez(os.path.join(GOLD, "refiner_cache.npz"), meta=np.array([C, ppc, bseed]),
+        np.savez(os.path.join(GOLD, "refiner_cache.npz"), meta=np.array([C, ppc, bseed, 3]),
                  n_empty=np.array(int((np.diff(bank_rc.cell_off) == 0).sum())))
         print("refiner_cache: pickled reference refiner,", os.path.getsize(os.path.join(GOLD, "proto.refiner")), "bytes")
 

@@ -97,6 +97,11 @@ def load():
         raise PigeonHipError(
             f"{LIB_PATH} not found: build it with `python -m pigeon_amd.build` (hipcc, gfx950). "
             "pigeon_amd has no CPU/PyTorch fallback for its hot path.")
+    # One HIP runtime per process: the library receives torch's streams and device pointers, so it must bind to the libamdhip64
+    # torch has loaded (torch ships its own copy).  Loaded FIRST, libpigeon_hip.so would pull /opt/rocm's runtime in under the same
+    # soname and torch would then find "No HIP GPUs" (seen when build() and smoke() ran in one process).  Importing torch here makes
+    # the order irrelevant; it is the tensor container of every caller of this module anyway.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -29,6 +29,7 @@
 #include "pigeon_internal.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 #define ATT_KT 64
 #define ATT_QB 128                       // query rows per block
@@ -604,9 +605,39 @@ __device__ __forceinline__ void att6_softmax(f32x16 (&s)[2], f32x16 (&o)[2], f32
     l = l0 + l1;
 }
 
+// ---- v7 softmax: NO per-tile maximum.  The scores arrive relative to the reference maximum (att6_qk seeds the accumulator with
+// -m), and the only thing the per-tile maximum was still needed for in v6 is the decision "has the reference fallen so far
+// behind that P = 2^(s - m) leaves the 16-bit range?".  That question answers itself: an overflowing P converts to +inf,
+// v_dot2c carries it into the row sum, so ONE compare of the new row sum (plus the wave ballot) per tile replaces 16 v_max3,
+// a lane exchange and a compare -- 17 of the ~100 VALU instructions of a tile, on a kernel that runs at the package power cap,
+// where instruction count is time.  When it does happen (wave-uniform, rare after the first tiles: the
+// reference would have to be exceeded by a factor 2^16 for fp16) the tile is simply done again the careful way: QK^T recomputed
+// from the K tile still in LDS, then att6_softmax with its maximum / rescale.  Nothing has been accumulated from the bad P:
+// l is only replaced on success and the PV MFMAs come after the check.  P up to 65504 instead of 2^8 changes no precision
+// (fp16 keeps 11 bits at any magnitude, l and O accumulate in fp32); underflow of keys > 2^24 below the stale reference drops
+// weights < 2^-24 of a key that is itself below the true maximum.
+template <typename T>
+__device__ __forceinline__ float att7_softmax_nomax(const f32x16 (&s)[2], float l, typename T::v8 (&pf)[2][2]) {
+    float l0 = l, l1 = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            u32x4 pw;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                pw[w] = T::pack2(__builtin_amdgcn_exp2f(s[kb][8 * s2 + 2 * w]), __builtin_amdgcn_exp2f(s[kb][8 * s2 + 2 * w + 1]));
+                if (w & 1) l1 = T::dot2(pw[w], AttOnes<T>::v, l1);
+                else l0 = T::dot2(pw[w], AttOnes<T>::v, l0);
+            }
+            pf[kb][s2] = __builtin_bit_cast(typename T::v8, pw);
+        }
+    return l0 + l1;
+}
+
 // KTAIL false: ten 64-key tiles, the last one masked (A/B arm).  ABL (timing-only ablations, results are garbage):
 // 1 no K/V DMA inside the tile loop, 2 no per-tile vmcnt wait / barrier.
-template <typename T, int WAVES_PER_SIMD, bool KTAIL = true, bool LAZY = true, int ABL = 0>
+template <typename T, int WAVES_PER_SIMD, bool KTAIL = true, bool LAZY = true, int ABL = 0, bool NOMAX = false>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention5_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) char smem[4 * K_TILE_BYTES];              // K0 K1 V0 V1, 8 KB each
     char* ks0 = smem;
@@ -669,7 +700,9 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention5_kernel(const u
     att5_dma(rv, vs0, wave, dvo_v, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int t = 0; t < NFULL; ++t) {
+    // one 64-key tile.  FAST (compile time, NOMAX kernels): the softmax without the per-tile maximum (att7_softmax_nomax).
+    auto tile = [&](int t, auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
         const int cur = t & 1;
         if (ABL != 1 && t + 1 < NFULL) {                      // both tiles of step t+1 land under this tile's math
             att5_dma(rk, ks0 + (cur ^ 1) * K_TILE_BYTES, wave, dvo_k, t + 1);
@@ -684,7 +717,15 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention5_kernel(const u
             if (LAZY) {
                 att6_qk<T>(sA, qf, negm, ks, kxoff, lq);
                 att5_load_v<T>(vf, vs, vbase);                // 16 transposing reads in flight under the softmax
-                att6_softmax<T>(sA, o, negm, l, pfA, t == 0);
+                if constexpr (FAST) {
+                    l = att7_softmax_nomax<T>(sA, l, pfA);
+                    // without the rescale branch of att6_softmax nothing stops hipcc from hoisting the wait for the V fragments
+                    // (and the first PV MFMAs) up between the first exps: the wave then sits on the LDS latency of 16 reads
+                    // issued a moment ago (first v7 build: 3-8 % SLOWER than v6 with 16 VALU instructions less per tile)
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    att6_softmax<T>(sA, o, negm, l, pfA, t == 0);
+                }
                 att5_wait_v(vf);
             } else {
                 att3_qk<T>(sA, qf, ks, kxoff, lq);
@@ -699,6 +740,31 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention5_kernel(const u
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's DMAs of step t+1 have landed
             __syncthreads();
         }
+    };
+    if constexpr (NOMAX) {
+        // Tile 0 establishes the reference maximum the careful way; tiles 1.. never look at a maximum again.  If the reference
+        // ever falls behind by more than the 16-bit range, a P becomes +inf, the row sum l becomes +inf (or NaN) and STAYS so:
+        // one test of l after the last tile -- block-wide, because the K/V stream is shared -- finds it, and the block then runs
+        // the whole pass again with the v6 softmax (maximum + rescale every tile).  Rare by construction; costs nothing when it
+        // does not happen (no per-tile compare, no extra registers in the hot loop).
+        tile(0, std::false_type{});
+        for (int t = 1; t < NFULL; ++t) tile(t, std::true_type{});
+        if (__syncthreads_or(wave_active && !(l < 3.0e38f))) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+            l = 0.f;
+            att5_dma(rk, ks0, wave, dvo_k, 0);
+            att5_dma(rv, vs0, wave, dvo_v, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int t = 0; t < NFULL; ++t) tile(t, std::false_type{});
+        }
+    } else {
+        for (int t = 0; t < NFULL; ++t) tile(t, std::false_type{});
     }
     if (KTAIL && wave_active) {
         // ---- key 576: s = q . k (this lane holds 32 of the 64 dims, its lane^32 partner the rest), one online-softmax step,
@@ -750,12 +816,311 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention5_kernel(const u
     }
 }
 
+// ================================================================================================================
+// v8 (variants 18 / 19): both GEMMs of the attention on v_mfma_f32_16x16x32 instead of 32x32x16.
+//
+// Why: at the 1400 W package cap the 16x16x32 form moves half as many accumulator registers per flop and sustains 2.06-2.09
+// PFLOP/s where 32x32x16 sustains 1.72-1.74 (tools/mfma_issue.hip, profiles/r02/mfma_issue.txt) -- the persistent GEMMs gained
+// 4.5 % from the same change in round 2.  The attention kernel spends ~0.41 ms of its 1.07 ms worth of energy in MFMAs.
+//
+// Geometry (r16 = lane & 15, g4 = lane >> 4):
+//   S^T = K Q^T   A = K block (16 keys x 32 d): lane holds K[key 16 kb + r16][d 32 ks + 8 g4 ..+7]     (ds_read_b128, GEMM swizzle)
+//                 B = Q block (32 d x 16 queries): lane holds Q[query 16 qb + r16][d 32 ks + 8 g4 ..+7] (registers, loaded once)
+//                 D = S^T block: lane holds keys 16 kb + 4 g4 + e (e = 0..3) of query 16 qb + r16
+//   O^T += V^T P^T  B = P block (32 keys x 16 queries): the lane's own D registers of key blocks 2j and 2j+1, packed: k index
+//                 8 g4 + e  <->  key 32 j + 4 g4 + e (e < 4), 32 j + 16 + 4 g4 + (e - 4) (e >= 4) -- any order will do as long
+//                 as A uses the same;  A = V^T block (16 d x 32 keys): two ds_read_b64_tr_b16 per fragment (keys 32 j + 4 g4 ..
+//                 and 32 j + 16 + 4 g4 .., column 16 db + r16);  D = O^T block: lane holds d 16 db + 4 g4 + e of query r16.
+//   A lane therefore holds NQB queries (one per 16-query block), 16 keys of each per tile; the 64 keys of a query are spread
+//   over the 4 lanes r16 + 16 g4.  The row sum is per-lane partial (combined once at the end); the reference maximum (first
+//   tile / careful path) needs two lane exchanges (xor 16, xor 32).
+// LDS: K tile as before (row = key, 16-byte chunk c at c ^ ((key >> 1) & 7)).  V tile row-major with the 32-byte column block
+//   db stored at db ^ ((key >> 1) & 3): one transposing read pass (lanes 0-31) then covers 8 key rows x 32 B = all 64 banks once.
+// NQB x WAVES = 2 x 4 (32 queries per wave, 3 waves per SIMD, as v5) or 4 x 2 (64 queries per wave, 2 waves per SIMD: each K / V
+//   fragment read from LDS feeds twice the MFMAs).  Block = 128 queries either way, 5 blocks per (image, head) on one XCD.
+// ================================================================================================================
+template <typename T, int NQB>
+__device__ __forceinline__ void att8_exp_pack(const f32x4 (&S)[4][NQB], float (&l)[NQB], typename T::v8 (&pf)[NQB][2]) {
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        float l0 = l[qb], l1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            u32x4 pw;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const f32x4& sv = S[2 * j + h][qb];
+                    pw[2 * h + w] = T::pack2(__builtin_amdgcn_exp2f(sv[2 * w]), __builtin_amdgcn_exp2f(sv[2 * w + 1]));
+                    if (w) l1 = T::dot2(pw[2 * h + w], AttOnes<T>::v, l1);
+                    else l0 = T::dot2(pw[2 * h + w], AttOnes<T>::v, l0);
+                }
+            pf[qb][j] = __builtin_bit_cast(typename T::v8, pw);
+        }
+        l[qb] = l0 + l1;
+    }
+}
+
+// careful softmax step: per-query maximum of the tile (relative to the reference, the scores arrive as s - m), lazy rescale
+template <typename T, int NQB>
+__device__ __forceinline__ void att8_softmax(f32x4 (&S)[4][NQB], f32x4 (&O)[4][NQB], f32x4 (&negm)[NQB], float (&l)[NQB],
+                                             typename T::v8 (&pf)[NQB][2], bool first) {
+    float tmax[NQB];
+    bool over = false;
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        float t = max3f(S[0][qb][0], S[0][qb][1], S[0][qb][2]);
+        t = max3f(t, S[0][qb][3], S[1][qb][0]);
+        t = max3f(t, S[1][qb][1], S[1][qb][2]);
+        t = max3f(t, S[1][qb][3], S[2][qb][0]);
+        t = max3f(t, S[2][qb][1], S[2][qb][2]);
+        t = max3f(t, S[2][qb][3], S[3][qb][0]);
+        t = max3f(t, S[3][qb][1], S[3][qb][2]);
+        t = __builtin_fmaxf(t, S[3][qb][3]);
+        t = __builtin_fmaxf(t, __shfl_xor(t, 16, 64));       // the 4 lanes of a query MUST agree on the reference: their P
+        t = __builtin_fmaxf(t, __shfl_xor(t, 32, 64));       // registers meet in one MFMA operand
+        tmax[qb] = t;
+        over = over || t > ATT_LAZY_THR;
+    }
+    if (first || __builtin_amdgcn_ballot_w64(over) != 0) {
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            const float delta = (first || tmax[qb] > ATT_LAZY_THR) ? tmax[qb] : 0.f;
+            const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);   // O = l = 0 before the first tile
+            const float nm = negm[qb][0] - delta;
+            negm[qb] = f32x4{nm, nm, nm, nm};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) S[kb][qb] -= delta;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) O[db][qb] *= alpha;
+            l[qb] *= alpha;
+        }
+    }
+    att8_exp_pack<T, NQB>(S, l, pf);
+}
+
+template <typename T, int NQB, int WAVES, int WPS, bool NOMAX>
+__global__ __launch_bounds__(64 * WAVES, WPS) void attention8_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
+    static_assert(NQB * WAVES * 16 == ATT_QB, "a block covers 128 queries");
+    static_assert(VIT_TOKENS == 9 * ATT_KT + 1, "key tail assumes 577 tokens");
+    __shared__ __attribute__((aligned(16))) char smem[4 * K_TILE_BYTES];              // K0 K1 V0 V1, 8 KB each
+    char* ks0 = smem;
+    char* vs0 = smem + 2 * K_TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g4 = lane >> 4;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int qblk = slot % ATT_NQB;
+    const int pair = (slot / ATT_NQB) * 8 + xcd;
+    const int img = pair >> 4, head = pair & 15;
+    const int64_t base = (int64_t)img * VIT_TOKENS;
+    const int q_first = qblk * ATT_QB + wave * (NQB * 16);   // wave-uniform
+    const bool wave_active = q_first < VIT_TOKENS;
+
+    typename T::v8 qf[NQB][2];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        int qr = q_first + 16 * qb + r16;
+        qr = qr < VIT_TOKENS ? qr : VIT_TOKENS - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[qb][ks] = *(const typename T::v8*)(qkv + (base + qr) * QKV_LD + head * 64 + ks * 32 + g4 * 8);
+    }
+    f32x4 O[4][NQB], negm[NQB];
+    float l[NQB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        negm[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        l[qb] = 0.f;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) O[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // K fragment addressing: row r16 of a 16-key block, 16-byte chunk 4 ks + g4, swizzled with the row (as the GEMM operands)
+    int kx[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) kx[ks] = r16 * K_ROWB + (((4 * ks + g4) ^ ((r16 >> 1) & 7)) << 4);
+    // V transposing reads: input lane jj = r16 of group g4 points at V[key 4 g4 + (jj >> 2) (+ 32 j + 16 h)][16 db + 4 (jj & 3) ..+3];
+    // the 32-byte block db of that row sits at db ^ ((key >> 1) & 3), and (key >> 1) & 3 = (2 g4 + (jj >> 3)) & 3 is a lane constant
+    int vb[4];
+    {
+        const int f = (2 * g4 + (r16 >> 3)) & 3;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) vb[db] = (4 * g4 + (r16 >> 2)) * K_ROWB + ((db ^ f) << 5) + ((r16 & 3) << 3);
+    }
+    __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(qkv + base * QKV_LD + 1024 + head * 64), (short)0, (int)(VIT_TOKENS * QKV_LD * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(qkv + base * QKV_LD + 2048 + head * 64), (short)0, (int)(VIT_TOKENS * QKV_LD * 2), 0x00020000);
+    constexpr int NDMA = 8 / WAVES;                          // 8-key groups of a 64-key tile this wave stages, per operand
+    int dvo_k[NDMA], dvo_v[NDMA];
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+        const int row = (wave + WAVES * i) * 8 + (lane >> 3);
+        dvo_k[i] = row * (QKV_LD * 2) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        dvo_v[i] = row * (QKV_LD * 2) + (((lane & 7) ^ (((row >> 1) & 3) << 1)) << 4);
+    }
+    auto dma = [&](__amdgpu_buffer_rsrc_t r, char* dst, const int (&dvo)[NDMA], int t) {
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (att_lds_void*)(dst + (wave + WAVES * i) * 8 * K_ROWB), 16, dvo[i],
+                                                     t * (ATT_KT * QKV_LD * 2), 0, 0);
+    };
+    constexpr int NFULL = 9;
+
+    auto tile = [&](int t, auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const int cur = t & 1;
+        if (t + 1 < NFULL) {                                  // both tiles of step t+1 land under this tile's math
+            dma(rk, ks0 + (cur ^ 1) * K_TILE_BYTES, dvo_k, t + 1);
+            dma(rv, vs0 + (cur ^ 1) * K_TILE_BYTES, dvo_v, t + 1);
+        }
+        const char* ks = ks0 + cur * K_TILE_BYTES;
+        const char* vs = vs0 + cur * K_TILE_BYTES;
+        if (wave_active) {
+            f32x4 S[4][NQB];
+            typename T::v8 pf[NQB][2];
+            {
+                typename T::v8 kf[4][2];
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int ks_ = 0; ks_ < 2; ++ks_) kf[kb][ks_] = *(const typename T::v8*)(ks + kb * 16 * K_ROWB + kx[ks_]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks_ = 0; ks_ < 2; ++ks_)
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                        for (int qb = 0; qb < NQB; ++qb)
+                            S[kb][qb] = T::mfma16(kf[kb][ks_], qf[qb][ks_], ks_ == 0 ? negm[qb] : S[kb][qb]);
+            }
+            // the 16 transposing V reads, right behind the last QK^T MFMA (inline asm: see att5_load_v)
+            u32x4 vf[4][2];
+            {
+                const uint32_t vs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)vs;
+                __builtin_amdgcn_sched_barrier(0);
+#define ATT8_TR(db, j)                                                                                        \
+                {                                                                                             \
+                    const u32x2 lo = att_tr_read<((j) * 32) * K_ROWB>(vs_lds + vb[db]);                       \
+                    const u32x2 hi = att_tr_read<((j) * 32 + 16) * K_ROWB>(vs_lds + vb[db]);                  \
+                    vf[db][j] = u32x4{lo[0], lo[1], hi[0], hi[1]};                                            \
+                }
+                ATT8_TR(0, 0) ATT8_TR(1, 0) ATT8_TR(2, 0) ATT8_TR(3, 0) ATT8_TR(0, 1) ATT8_TR(1, 1) ATT8_TR(2, 1) ATT8_TR(3, 1)
+#undef ATT8_TR
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (FAST) {
+                att8_exp_pack<T, NQB>(S, l, pf);
+                __builtin_amdgcn_sched_barrier(0);            // keep the wait for the V fragments behind the exps (attention5_kernel)
+            } else {
+                att8_softmax<T, NQB>(S, O, negm, l, pf, t == 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(vf[0][0]), "+v"(vf[1][0]), "+v"(vf[2][0]), "+v"(vf[3][0]), "+v"(vf[0][1]), "+v"(vf[1][1]),
+                           "+v"(vf[2][1]), "+v"(vf[3][1])
+                         :: "memory");
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int db = 0; db < 4; ++db)
+#pragma unroll
+                    for (int qb = 0; qb < NQB; ++qb)
+                        O[db][qb] = T::mfma16(__builtin_bit_cast(typename T::v8, vf[db][j]), pf[qb][j], O[db][qb]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMAs of step t+1 have landed
+        __syncthreads();
+    };
+
+    dma(rk, ks0, dvo_k, 0);
+    dma(rv, vs0, dvo_v, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (NOMAX) {
+        // see attention5_kernel: tile 0 fixes the reference maximum, tiles 1.. run without one, a P that leaves the 16-bit range
+        // turns the row sum into +inf / NaN for good, and ONE block-wide test after the last tile sends the block through the
+        // careful loop again (rare)
+        tile(0, std::false_type{});
+        for (int t = 1; t < NFULL; ++t) tile(t, std::true_type{});
+        bool bad = false;
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) bad = bad || !(l[qb] < 3.0e38f);
+        if (__syncthreads_or(wave_active && bad)) {
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) {
+                negm[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                l[qb] = 0.f;
+#pragma unroll
+                for (int db = 0; db < 4; ++db) O[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            dma(rk, ks0, dvo_k, 0);
+            dma(rv, vs0, dvo_v, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int t = 0; t < NFULL; ++t) tile(t, std::false_type{});
+        }
+    } else {
+        for (int t = 0; t < NFULL; ++t) tile(t, std::false_type{});
+    }
+    if (!wave_active) return;
+
+    // ---- key 576 (VALU): s = q . k over the lane's 16 of the 64 dims, summed over the query's 4 lanes; one online-softmax step;
+    // O += p * v on the lane's 16 columns (d = 16 db + 4 g4 + e).  p stays fp32 here.
+    const uint16_t* krow = qkv + (base + (VIT_TOKENS - 1)) * QKV_LD + 1024 + head * 64;
+    const uint16_t* vrow = krow + 1024;
+    u32x4 kq[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) kq[ks] = *(const u32x4*)(krow + ks * 32 + g4 * 8);
+    u32x2 vv[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) vv[db] = *(const u32x2*)(vrow + db * 16 + g4 * 4);
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        float sp = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const u32x4 qq = __builtin_bit_cast(u32x4, qf[qb][ks]);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) sp = T::dot2(qq[w], kq[ks][w], sp);
+        }
+        sp += __shfl_xor(sp, 16, 64);
+        const float sc = sp + __shfl_xor(sp, 32, 64);
+        const float m = -negm[qb][0];
+        const float m_new = fmaxf(m, sc);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        const float pk = __builtin_amdgcn_exp2f(sc - m_new);
+        l[qb] = l[qb] * alpha + (g4 == 0 ? pk : 0.f);        // the 4 lanes of a query are summed below: count the key once
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint16_t hb = (uint16_t)(vv[db][e >> 1] >> (16 * (e & 1)));
+                O[db][qb][e] = fmaf(pk, T::val(hb), O[db][qb][e] * alpha);
+            }
+        float lt = l[qb] + __shfl_xor(l[qb], 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        const float inv = 1.0f / lt;
+        const int qrow = q_first + 16 * qb + r16;
+        if (qrow < VIT_TOKENS) {
+            uint16_t* orow = out + (base + qrow) * VIT_HIDDEN + head * 64;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                u32x2 pk2;
+                pk2[0] = pack16x2<T>(O[db][qb][0] * inv, O[db][qb][1] * inv);
+                pk2[1] = pack16x2<T>(O[db][qb][2] * inv, O[db][qb][3] * inv);
+                *(u32x2*)(orow + db * 16 + g4 * 4) = pk2;
+            }
+        }
+    }
+}
+
 static int attention_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("PIGEON_ATTN_VARIANT");
         v = e ? atoi(e) : 11;
-        if (v < 1 || v > 15) v = 11;
+        if (v < 1 || v > 20) v = 11;
     }
     return v;
 }
@@ -791,6 +1156,10 @@ int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hip
         case 14: return att_launch2(dtype, attention5_kernel<T_F16, 3, true, true, 1>, attention5_kernel<T_BF16, 3, true, true, 1>, grid, qkv, out, s);
         case 15: return att_launch2(dtype, attention5_kernel<T_F16, 3, true, true, 2>, attention5_kernel<T_BF16, 3, true, true, 2>, grid, qkv, out, s);
         case 13: return att_launch2(dtype, attention5_kernel<T_F16, 3, true, false>, attention5_kernel<T_BF16, 3, true, false>, grid, qkv, out, s);
+        case 18: hipLaunchKernelGGL((attention8_kernel<T_F16, 2, 4, 3, true>), grid, dim3(256), 0, s, (const uint16_t*)qkv, (uint16_t*)out); return dtype == PG_DTYPE_F16 ? pg_check_launch("attention8") : PG_EINVAL;
+        case 19: hipLaunchKernelGGL((attention8_kernel<T_F16, 4, 2, 2, true>), grid, dim3(128), 0, s, (const uint16_t*)qkv, (uint16_t*)out); return dtype == PG_DTYPE_F16 ? pg_check_launch("attention8") : PG_EINVAL;
+        case 20: hipLaunchKernelGGL((attention8_kernel<T_F16, 2, 4, 3, false>), grid, dim3(256), 0, s, (const uint16_t*)qkv, (uint16_t*)out); return dtype == PG_DTYPE_F16 ? pg_check_launch("attention8") : PG_EINVAL;
+        case 16: return att_launch2(dtype, attention5_kernel<T_F16, 3, true, true, 0, true>, attention5_kernel<T_BF16, 3, true, true, 0, true>, grid, qkv, out, s);
         default: break;
     }
 #endif

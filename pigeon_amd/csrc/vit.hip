@@ -149,6 +149,7 @@ struct pg_vit {
     unsigned long long* sat_counter = nullptr;
     // profiling
     bool prof = false;
+    unsigned prof_mask = 0xFFFFFFFFu;                      // classes bracketed while prof is on (bit c = class c)
     struct Ev { hipEvent_t a, b; int cls; };
     std::vector<Ev> evs;
     int64_t prof_launches[PG_PROF_CLASSES] = {0};
@@ -397,10 +398,10 @@ extern "C" int pg_vit_workspace_bytes(const pg_vit* h, int n_images, size_t* byt
 struct ProfScope {
     pg_vit* h; hipStream_t s; int cls; hipEvent_t a = nullptr, b = nullptr;
     ProfScope(pg_vit* h_, hipStream_t s_, int c) : h(h_), s(s_), cls(c) {
-        if (h->prof) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
+        if (h->prof && ((h->prof_mask >> c) & 1u)) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
     }
     ~ProfScope() {
-        if (h->prof) { (void)hipEventRecord(b, s); h->evs.push_back({a, b, cls}); }
+        if (a) { (void)hipEventRecord(b, s); h->evs.push_back({a, b, cls}); }
     }
 };
 
@@ -582,6 +583,7 @@ extern "C" int pg_vit_saturation_read(pg_vit* h, int64_t* count, int reset) {
 extern "C" int pg_vit_profile_enable(pg_vit* h, int on) {
     if (!h) { pg_set_error("profile_enable: null handle"); return PG_EINVAL; }
     h->prof = on != 0;
+    h->prof_mask = (on == 1 || on == 0) ? 0xFFFFFFFFu : ((unsigned)on >> 1);     // on >= 2: bit (c + 1) selects class c
     return PG_OK;
 }
 static int prof_drain(pg_vit* h) {

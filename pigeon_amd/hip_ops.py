@@ -310,8 +310,14 @@ class VitEncoder:
     __call__ = forward
 
     # ---- per-kernel-class timing for bench.py ----
-    def profile_enable(self, on: bool = True):
-        check(load().pg_vit_profile_enable(self._h, 1 if on else 0), "pg_vit_profile_enable")
+    def profile_enable(self, on: bool = True, classes=None):
+        """classes: None = every kernel class, else an iterable of class names (_lib.PROF_CLASSES) to bracket with events."""
+        v = 1 if on else 0
+        if on and classes is not None:
+            v = 0
+            for c in classes:
+                v |= 1 << (_lib.PROF_CLASSES.index(c) + 1)
+        check(load().pg_vit_profile_enable(self._h, v), "pg_vit_profile_enable")
 
     def profile_reset(self):
         check(load().pg_vit_profile_reset(self._h), "pg_vit_profile_reset")

@@ -524,14 +524,14 @@ def test_evaluate_consumes_the_references_refiner_cache(env, golden_dir, tmp_pat
     from pigeon_amd.clip_embedder import HipCLIPVisionModel
     from pigeon_amd.evaluate import evaluate
     syn, orc = env["syn"], env["orc"]
-    C, ppc, bseed = [int(x) for x in _gold(golden_dir, "refiner_cache.npz")["meta"]]
+    C, ppc, bseed, maxm = [int(x) for x in _gold(golden_dir, "refiner_cache.npz")["meta"]]
     geo = _geocells_csv(tmp_path, C)
     W, b = syn.make_head_weights(C, seed=5)
     head = os.path.join(str(tmp_path), "head.model")
     torch.save({"cell_layer.weight": W * 8, "cell_layer.bias": b}, head)
     vit_sd = syn.make_vit_weights(seed=11, layers=1, affine_jitter=True)
     base = HipCLIPVisionModel(vit_sd, layers=1)
-    bank = syn.make_bank(C, ppc, seed=bseed, empty_frac=0.05)
+    bank = syn.make_bank(C, ppc, seed=bseed, empty_frac=0.05, max_members=maxm)
     ds = os.path.join(str(tmp_path), "hf")
     syn.write_bank_reference_files(bank, os.path.join(str(tmp_path), "unused_protos.csv"), ds)     # only the training rows are read
     px = syn.make_pixels(4 * 6, seed=21, panorama=True)

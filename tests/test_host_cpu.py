@@ -298,11 +298,11 @@ def test_load_refiner_cache_committed_reference_pickle(golden_dir, tmp_path):
     converts to exactly the bank it was built from."""
     from pigeon_amd.proto_refiner import bank_from_protos, load_refiner_cache
     meta = np.load(os.path.join(golden_dir, "refiner_cache.npz"))
-    C, ppc, bseed = [int(x) for x in meta["meta"]]
+    C, ppc, bseed, maxm = [int(x) for x in meta["meta"]]
     assert "models.proto_refiner" not in sys.modules
     protos = load_refiner_cache(os.path.join(golden_dir, "proto.refiner"))
     assert len(protos) == C and sum(p is None for p in protos) == int(meta["n_empty"])
-    bank = synthetic.make_bank(C, ppc, seed=bseed, empty_frac=0.05)
+    bank = synthetic.make_bank(C, ppc, seed=bseed, empty_frac=0.05, max_members=maxm)
     ds_dir = os.path.join(str(tmp_path), "hf_train")
     synthetic.write_bank_reference_files(bank, os.path.join(str(tmp_path), "protos.csv"), ds_dir)
     _arrays_equal(bank_from_protos(protos, ds_dir), bank)
