@@ -7,10 +7,12 @@
 // a head's Q/K/V rows are 128-byte contiguous segments), with Q pre-multiplied by log2(e)/8 so the kernel
 // can use v_exp_f32 (2^x) directly.  Output (n_img*577, 1024) in the same 16-bit type, column = head*64 + d.
 //
-// This file holds three generations (selected by PIGEON_ATTN_VARIANT, see pg_attention_launch at the bottom):
+// This file holds four generations (selected by PIGEON_ATTN_VARIANT, see pg_attention_launch at the bottom):
 //   v1 attention_kernel   register-staged K/V, the structure described below;
 //   v4 attention4_kernel  v1 with the softmax instruction diet and 3 waves per SIMD (+ ablation switches);
-//   v5 attention5_kernel  DEFAULT: K and V by direct-to-LDS DMA, V row-major + ds_read_b64_tr_b16, single-key tail.
+//   v5 attention5_kernel  round 2's product: K and V by direct-to-LDS DMA, V row-major + ds_read_b64_tr_b16, single-key tail;
+//   v8 attention8_kernel  DEFAULT (round 3): the same data movement with both GEMMs on v_mfma_f32_16x16x32 (section "v8" below).
+// The product library instantiates v8 only; the older generations compile into the tools build (-DPIGEON_ABLATIONS).
 //
 // Structure common to all (gfx950, wave64):
 //   * block = 4 waves = 128 query rows of one (image, head); 5 blocks cover the 577 queries.  The 5 blocks of
@@ -605,39 +607,9 @@ __device__ __forceinline__ void att6_softmax(f32x16 (&s)[2], f32x16 (&o)[2], f32
     l = l0 + l1;
 }
 
-// ---- v7 softmax: NO per-tile maximum.  The scores arrive relative to the reference maximum (att6_qk seeds the accumulator with
-// -m), and the only thing the per-tile maximum was still needed for in v6 is the decision "has the reference fallen so far
-// behind that P = 2^(s - m) leaves the 16-bit range?".  That question answers itself: an overflowing P converts to +inf,
-// v_dot2c carries it into the row sum, so ONE compare of the new row sum (plus the wave ballot) per tile replaces 16 v_max3,
-// a lane exchange and a compare -- 17 of the ~100 VALU instructions of a tile, on a kernel that runs at the package power cap,
-// where instruction count is time.  When it does happen (wave-uniform, rare after the first tiles: the
-// reference would have to be exceeded by a factor 2^16 for fp16) the tile is simply done again the careful way: QK^T recomputed
-// from the K tile still in LDS, then att6_softmax with its maximum / rescale.  Nothing has been accumulated from the bad P:
-// l is only replaced on success and the PV MFMAs come after the check.  P up to 65504 instead of 2^8 changes no precision
-// (fp16 keeps 11 bits at any magnitude, l and O accumulate in fp32); underflow of keys > 2^24 below the stale reference drops
-// weights < 2^-24 of a key that is itself below the true maximum.
-template <typename T>
-__device__ __forceinline__ float att7_softmax_nomax(const f32x16 (&s)[2], float l, typename T::v8 (&pf)[2][2]) {
-    float l0 = l, l1 = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            u32x4 pw;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                pw[w] = T::pack2(__builtin_amdgcn_exp2f(s[kb][8 * s2 + 2 * w]), __builtin_amdgcn_exp2f(s[kb][8 * s2 + 2 * w + 1]));
-                if (w & 1) l1 = T::dot2(pw[w], AttOnes<T>::v, l1);
-                else l0 = T::dot2(pw[w], AttOnes<T>::v, l0);
-            }
-            pf[kb][s2] = __builtin_bit_cast(typename T::v8, pw);
-        }
-    return l0 + l1;
-}
-
 // KTAIL false: ten 64-key tiles, the last one masked (A/B arm).  ABL (timing-only ablations, results are garbage):
 // 1 no K/V DMA inside the tile loop, 2 no per-tile vmcnt wait / barrier.
-template <typename T, int WAVES_PER_SIMD, bool KTAIL = true, bool LAZY = true, int ABL = 0, bool NOMAX = false>
+template <typename T, int WAVES_PER_SIMD, bool KTAIL = true, bool LAZY = true, int ABL = 0>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention5_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) char smem[4 * K_TILE_BYTES];              // K0 K1 V0 V1, 8 KB each
     char* ks0 = smem;
@@ -700,9 +672,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention5_kernel(const u
     att5_dma(rv, vs0, wave, dvo_v, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // one 64-key tile.  FAST (compile time, NOMAX kernels): the softmax without the per-tile maximum (att7_softmax_nomax).
-    auto tile = [&](int t, auto fast_tag) {
-        constexpr bool FAST = decltype(fast_tag)::value;
+    for (int t = 0; t < NFULL; ++t) {
         const int cur = t & 1;
         if (ABL != 1 && t + 1 < NFULL) {                      // both tiles of step t+1 land under this tile's math
             att5_dma(rk, ks0 + (cur ^ 1) * K_TILE_BYTES, wave, dvo_k, t + 1);
@@ -717,15 +687,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention5_kernel(const u
             if (LAZY) {
                 att6_qk<T>(sA, qf, negm, ks, kxoff, lq);
                 att5_load_v<T>(vf, vs, vbase);                // 16 transposing reads in flight under the softmax
-                if constexpr (FAST) {
-                    l = att7_softmax_nomax<T>(sA, l, pfA);
-                    // without the rescale branch of att6_softmax nothing stops hipcc from hoisting the wait for the V fragments
-                    // (and the first PV MFMAs) up between the first exps: the wave then sits on the LDS latency of 16 reads
-                    // issued a moment ago (first v7 build: 3-8 % SLOWER than v6 with 16 VALU instructions less per tile)
-                    __builtin_amdgcn_sched_barrier(0);
-                } else {
-                    att6_softmax<T>(sA, o, negm, l, pfA, t == 0);
-                }
+                att6_softmax<T>(sA, o, negm, l, pfA, t == 0);
                 att5_wait_v(vf);
             } else {
                 att3_qk<T>(sA, qf, ks, kxoff, lq);
@@ -740,31 +702,6 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention5_kernel(const u
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's DMAs of step t+1 have landed
             __syncthreads();
         }
-    };
-    if constexpr (NOMAX) {
-        // Tile 0 establishes the reference maximum the careful way; tiles 1.. never look at a maximum again.  If the reference
-        // ever falls behind by more than the 16-bit range, a P becomes +inf, the row sum l becomes +inf (or NaN) and STAYS so:
-        // one test of l after the last tile -- block-wide, because the K/V stream is shared -- finds it, and the block then runs
-        // the whole pass again with the v6 softmax (maximum + rescale every tile).  Rare by construction; costs nothing when it
-        // does not happen (no per-tile compare, no extra registers in the hot loop).
-        tile(0, std::false_type{});
-        for (int t = 1; t < NFULL; ++t) tile(t, std::true_type{});
-        if (__syncthreads_or(wave_active && !(l < 3.0e38f))) {
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) negm[r] = 0.f;
-            l = 0.f;
-            att5_dma(rk, ks0, wave, dvo_k, 0);
-            att5_dma(rv, vs0, wave, dvo_v, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            for (int t = 0; t < NFULL; ++t) tile(t, std::false_type{});
-        }
-    } else {
-        for (int t = 0; t < NFULL; ++t) tile(t, std::false_type{});
     }
     if (KTAIL && wave_active) {
         // ---- key 576: s = q . k (this lane holds 32 of the 64 dims, its lane^32 partner the rest), one online-softmax step,
@@ -817,7 +754,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention5_kernel(const u
 }
 
 // ================================================================================================================
-// v8 (variants 18 / 19): both GEMMs of the attention on v_mfma_f32_16x16x32 instead of 32x32x16.
+// v8 (variant 21 = product default; 19 = 64-queries-per-wave arm): both GEMMs of the attention on v_mfma_f32_16x16x32.
 //
 // Why: at the 1400 W package cap the 16x16x32 form moves half as many accumulator registers per flop and sustains 2.06-2.09
 // PFLOP/s where 32x32x16 sustains 1.72-1.74 (tools/mfma_issue.hip, profiles/r02/mfma_issue.txt) -- the persistent GEMMs gained
@@ -900,8 +837,40 @@ __device__ __forceinline__ void att8_softmax(f32x4 (&S)[4][NQB], f32x4 (&O)[4][N
     att8_exp_pack<T, NQB>(S, l, pf);
 }
 
-template <typename T, int NQB, int WAVES, int WPS, bool NOMAX>
-__global__ __launch_bounds__(64 * WAVES, WPS) void attention8_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
+// Everything that is not valid HOST code lives in __device__ functions, not in the kernel body or its lambdas: those are also
+// instantiated for the host, and one address-space cast / "v" asm constraint / buffer-resource parameter there makes hipcc drop the
+// host side of the kernel template WITHOUT a diagnostic (the library then fails to load with an undefined kernel symbol).
+__device__ __forceinline__ void att8_dma(__amdgpu_buffer_rsrc_t r, char* dst, int wave, const int* dvo, int ndma, int waves, int t) {
+#pragma unroll
+    for (int i = 0; i < ndma; ++i)                           // ndma / waves are compile-time constants at every (inlined) call site
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (att_lds_void*)(dst + (wave + waves * i) * 8 * K_ROWB), 16, dvo[i],
+                                                 t * (ATT_KT * QKV_LD * 2), 0, 0);
+}
+// the 16 transposing V reads of a tile, right behind the last QK^T MFMA (inline asm: see att5_load_v)
+__device__ __forceinline__ void att8_load_v(u32x4 (&vf)[4][2], const char* vs, const int (&vb)[4]) {
+    const uint32_t vs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)vs;
+    __builtin_amdgcn_sched_barrier(0);
+#define ATT8_TR(db, j)                                                                                        \
+    {                                                                                                         \
+        const u32x2 lo = att_tr_read<((j) * 32) * K_ROWB>(vs_lds + vb[db]);                                   \
+        const u32x2 hi = att_tr_read<((j) * 32 + 16) * K_ROWB>(vs_lds + vb[db]);                              \
+        vf[db][j] = u32x4{lo[0], lo[1], hi[0], hi[1]};                                                        \
+    }
+    ATT8_TR(0, 0) ATT8_TR(1, 0) ATT8_TR(2, 0) ATT8_TR(3, 0) ATT8_TR(0, 1) ATT8_TR(1, 1) ATT8_TR(2, 1) ATT8_TR(3, 1)
+#undef ATT8_TR
+    __builtin_amdgcn_sched_barrier(0);
+}
+// (a __device__ function, not inline in the kernel's lambda: a lambda body is also instantiated for the host, where the "v"
+// constraint does not exist -- hipcc then silently drops the HOST side of the whole kernel template and the library fails to load)
+__device__ __forceinline__ void att8_wait_v(u32x4 (&vf)[4][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(vf[0][0]), "+v"(vf[1][0]), "+v"(vf[2][0]), "+v"(vf[3][0]), "+v"(vf[0][1]), "+v"(vf[1][1]),
+                   "+v"(vf[2][1]), "+v"(vf[3][1])
+                 :: "memory");
+}
+
+template <typename T, int NQB, int WAVES, int WPS>
+__global__ __launch_bounds__(256, WPS) void attention8_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
     static_assert(NQB * WAVES * 16 == ATT_QB, "a block covers 128 queries");
     static_assert(VIT_TOKENS == 9 * ATT_KT + 1, "key tail assumes 577 tokens");
     __shared__ __attribute__((aligned(16))) char smem[4 * K_TILE_BYTES];              // K0 K1 V0 V1, 8 KB each
@@ -961,20 +930,17 @@ __global__ __launch_bounds__(64 * WAVES, WPS) void attention8_kernel(const uint1
         dvo_k[i] = row * (QKV_LD * 2) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
         dvo_v[i] = row * (QKV_LD * 2) + (((lane & 7) ^ (((row >> 1) & 3) << 1)) << 4);
     }
-    auto dma = [&](__amdgpu_buffer_rsrc_t r, char* dst, const int (&dvo)[NDMA], int t) {
-#pragma unroll
-        for (int i = 0; i < NDMA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (att_lds_void*)(dst + (wave + WAVES * i) * 8 * K_ROWB), 16, dvo[i],
-                                                     t * (ATT_KT * QKV_LD * 2), 0, 0);
-    };
     constexpr int NFULL = 9;
 
-    auto tile = [&](int t, auto fast_tag) {
-        constexpr bool FAST = decltype(fast_tag)::value;
+    att8_dma(rk, ks0, wave, dvo_k, NDMA, WAVES, 0);
+    att8_dma(rv, vs0, wave, dvo_v, NDMA, WAVES, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < NFULL; ++t) {
         const int cur = t & 1;
         if (t + 1 < NFULL) {                                  // both tiles of step t+1 land under this tile's math
-            dma(rk, ks0 + (cur ^ 1) * K_TILE_BYTES, dvo_k, t + 1);
-            dma(rv, vs0 + (cur ^ 1) * K_TILE_BYTES, dvo_v, t + 1);
+            att8_dma(rk, ks0 + (cur ^ 1) * K_TILE_BYTES, wave, dvo_k, NDMA, WAVES, t + 1);
+            att8_dma(rv, vs0 + (cur ^ 1) * K_TILE_BYTES, wave, dvo_v, NDMA, WAVES, t + 1);
         }
         const char* ks = ks0 + cur * K_TILE_BYTES;
         const char* vs = vs0 + cur * K_TILE_BYTES;
@@ -998,29 +964,9 @@ __global__ __launch_bounds__(64 * WAVES, WPS) void attention8_kernel(const uint1
             }
             // the 16 transposing V reads, right behind the last QK^T MFMA (inline asm: see att5_load_v)
             u32x4 vf[4][2];
-            {
-                const uint32_t vs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)vs;
-                __builtin_amdgcn_sched_barrier(0);
-#define ATT8_TR(db, j)                                                                                        \
-                {                                                                                             \
-                    const u32x2 lo = att_tr_read<((j) * 32) * K_ROWB>(vs_lds + vb[db]);                       \
-                    const u32x2 hi = att_tr_read<((j) * 32 + 16) * K_ROWB>(vs_lds + vb[db]);                  \
-                    vf[db][j] = u32x4{lo[0], lo[1], hi[0], hi[1]};                                            \
-                }
-                ATT8_TR(0, 0) ATT8_TR(1, 0) ATT8_TR(2, 0) ATT8_TR(3, 0) ATT8_TR(0, 1) ATT8_TR(1, 1) ATT8_TR(2, 1) ATT8_TR(3, 1)
-#undef ATT8_TR
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (FAST) {
-                att8_exp_pack<T, NQB>(S, l, pf);
-                __builtin_amdgcn_sched_barrier(0);            // keep the wait for the V fragments behind the exps (attention5_kernel)
-            } else {
-                att8_softmax<T, NQB>(S, O, negm, l, pf, t == 0);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(vf[0][0]), "+v"(vf[1][0]), "+v"(vf[2][0]), "+v"(vf[3][0]), "+v"(vf[0][1]), "+v"(vf[1][1]),
-                           "+v"(vf[2][1]), "+v"(vf[3][1])
-                         :: "memory");
+            att8_load_v(vf, vs, vb);
+            att8_softmax<T, NQB>(S, O, negm, l, pf, t == 0);
+            att8_wait_v(vf);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1031,37 +977,6 @@ __global__ __launch_bounds__(64 * WAVES, WPS) void attention8_kernel(const uint1
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMAs of step t+1 have landed
         __syncthreads();
-    };
-
-    dma(rk, ks0, dvo_k, 0);
-    dma(rv, vs0, dvo_v, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if constexpr (NOMAX) {
-        // see attention5_kernel: tile 0 fixes the reference maximum, tiles 1.. run without one, a P that leaves the 16-bit range
-        // turns the row sum into +inf / NaN for good, and ONE block-wide test after the last tile sends the block through the
-        // careful loop again (rare)
-        tile(0, std::false_type{});
-        for (int t = 1; t < NFULL; ++t) tile(t, std::true_type{});
-        bool bad = false;
-#pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) bad = bad || !(l[qb] < 3.0e38f);
-        if (__syncthreads_or(wave_active && bad)) {
-#pragma unroll
-            for (int qb = 0; qb < NQB; ++qb) {
-                negm[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                l[qb] = 0.f;
-#pragma unroll
-                for (int db = 0; db < 4; ++db) O[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            dma(rk, ks0, dvo_k, 0);
-            dma(rv, vs0, dvo_v, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            for (int t = 0; t < NFULL; ++t) tile(t, std::false_type{});
-        }
-    } else {
-        for (int t = 0; t < NFULL; ++t) tile(t, std::false_type{});
     }
     if (!wave_active) return;
 
@@ -1119,13 +1034,15 @@ static int attention_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("PIGEON_ATTN_VARIANT");
-        v = e ? atoi(e) : 11;
-        if (v < 1 || v > 20) v = 11;
+        v = e ? atoi(e) : 21;
+        if (v < 1 || v > 21) v = 21;
     }
     return v;
 }
 
-// Variants (env PIGEON_ATTN_VARIANT): 11 (default) v6 = K and V by DMA, transposing LDS reads, single-key tail, lazy softmax;
+// Variants (env PIGEON_ATTN_VARIANT): 21 (default, the only one in the product library) v8 = v6's structure on v_mfma_f32_16x16x32
+// (attention8_kernel, 32 queries per wave); 19 = v8 with 64 queries per wave (A/B arm); 11 v6 (round 2's product) = K and V by DMA,
+// transposing LDS reads, single-key tail, lazy softmax on 32x32x16 MFMAs;
 // 13 the same with the v5 softmax (running maximum updated every tile, packed fp32 ops); 12 = 13 with a masked tenth key
 // tile instead of the tail (A/B arms); 14 / 15 timing-only ablations of 11 (no DMA in the loop / no per-tile barrier); 4 / 10 v4 register-staged / K by DMA;
 // 5 v4 forced to 4 waves per SIMD (spills); 6..9 timing-only ablations of v4; 1 the first kernel.
@@ -1133,6 +1050,13 @@ template <typename KF, typename KB>
 static int att_launch2(int dtype, KF kf, KB kb, dim3 grid, const void* qkv, void* out, hipStream_t s) {
     if (dtype == PG_DTYPE_F16) hipLaunchKernelGGL(kf, grid, dim3(256), 0, s, (const uint16_t*)qkv, (uint16_t*)out);
     else hipLaunchKernelGGL(kb, grid, dim3(256), 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+    return pg_check_launch("attention");
+}
+
+template <typename KF, typename KB>
+static int att_launch3(int dtype, KF kf, KB kb, dim3 grid, int threads, const void* qkv, void* out, hipStream_t s) {
+    if (dtype == PG_DTYPE_F16) hipLaunchKernelGGL(kf, grid, dim3(threads), 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+    else hipLaunchKernelGGL(kb, grid, dim3(threads), 0, s, (const uint16_t*)qkv, (uint16_t*)out);
     return pg_check_launch("attention");
 }
 
@@ -1156,16 +1080,14 @@ int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hip
         case 14: return att_launch2(dtype, attention5_kernel<T_F16, 3, true, true, 1>, attention5_kernel<T_BF16, 3, true, true, 1>, grid, qkv, out, s);
         case 15: return att_launch2(dtype, attention5_kernel<T_F16, 3, true, true, 2>, attention5_kernel<T_BF16, 3, true, true, 2>, grid, qkv, out, s);
         case 13: return att_launch2(dtype, attention5_kernel<T_F16, 3, true, false>, attention5_kernel<T_BF16, 3, true, false>, grid, qkv, out, s);
-        case 18: hipLaunchKernelGGL((attention8_kernel<T_F16, 2, 4, 3, true>), grid, dim3(256), 0, s, (const uint16_t*)qkv, (uint16_t*)out); return dtype == PG_DTYPE_F16 ? pg_check_launch("attention8") : PG_EINVAL;
-        case 19: hipLaunchKernelGGL((attention8_kernel<T_F16, 4, 2, 2, true>), grid, dim3(128), 0, s, (const uint16_t*)qkv, (uint16_t*)out); return dtype == PG_DTYPE_F16 ? pg_check_launch("attention8") : PG_EINVAL;
-        case 20: hipLaunchKernelGGL((attention8_kernel<T_F16, 2, 4, 3, false>), grid, dim3(256), 0, s, (const uint16_t*)qkv, (uint16_t*)out); return dtype == PG_DTYPE_F16 ? pg_check_launch("attention8") : PG_EINVAL;
-        case 16: return att_launch2(dtype, attention5_kernel<T_F16, 3, true, true, 0, true>, attention5_kernel<T_BF16, 3, true, true, 0, true>, grid, qkv, out, s);
+        case 19: return att_launch3(dtype, attention8_kernel<T_F16, 4, 2, 2>, attention8_kernel<T_BF16, 4, 2, 2>, grid, 128, qkv, out, s);
+        case 11: return att_launch2(dtype, attention5_kernel<T_F16, 3>, attention5_kernel<T_BF16, 3>, grid, qkv, out, s);
         default: break;
     }
 #endif
-    if (variant != 11) {
-        pg_set_error("attention: PIGEON_ATTN_VARIANT=%d is not part of this build (product: 11; others need -DPIGEON_ABLATIONS)", variant);
+    if (variant != 21) {
+        pg_set_error("attention: PIGEON_ATTN_VARIANT=%d is not part of this build (product: 21; others need -DPIGEON_ABLATIONS)", variant);
         return PG_EINVAL;
     }
-    return att_launch2(dtype, attention5_kernel<T_F16, 3>, attention5_kernel<T_BF16, 3>, grid, qkv, out, s);
+    return att_launch3(dtype, attention8_kernel<T_F16, 2, 4, 3>, attention8_kernel<T_BF16, 2, 4, 3>, grid, 256, qkv, out, s);
 }

@@ -46,3 +46,22 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "/root/reference" in txt:
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_every_device_kernel_has_its_host_side(hip_lib):
+    """A kernel template whose body (or a lambda in it) contains something that is not valid HOST code -- an address-space cast,
+    a "v" asm constraint, a buffer-resource parameter of a template -- loses its host side WITHOUT a compiler diagnostic; the
+    library then links (shared objects may have undefined symbols) and only fails at dlopen, on the GPU box (round 3, the first
+    16x16x32 attention kernel).  Loading the library in the fixture already proves the product build; this also loads the tools
+    build when it exists, and checks both with `nm -u` for undefined kernel stubs."""
+    import ctypes
+    import subprocess
+    libs = [os.path.join(ROOT, "pigeon_amd", "libpigeon_hip.so")]
+    dev = os.path.join(ROOT, "pigeon_amd", "libpigeon_hip_dev.so")
+    if os.path.exists(dev) and os.path.getmtime(dev) >= os.path.getmtime(libs[0]) - 3600:
+        libs.append(dev)
+    for lib in libs:
+        und = subprocess.run(["nm", "-u", "-C", lib], capture_output=True, text=True, check=True).stdout
+        bad = [l.strip() for l in und.splitlines() if "_kernel" in l or "__device_stub__" in l]
+        assert not bad, f"{lib}: kernels without a host side: {bad[:4]}"
+        ctypes.CDLL(lib)

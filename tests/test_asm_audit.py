@@ -9,14 +9,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-HOT = ("gemm_pp6_kernel", "gemm_pp_kernel", "gemm_w4_kernel", "gemm_tail_kernel", "gemm_bf16_kernel", "attention5_kernel")
+HOT = ("gemm_pp6_kernel", "gemm_pp_kernel", "gemm_tail_kernel", "gemm_bf16_kernel", "attention8_kernel")
 
 
 def test_hot_kernels_have_no_waterfall_loops_and_no_spills(hip_lib):
     import asm_audit
     res = asm_audit.audit(os.path.join(ROOT, "pigeon_amd", "libpigeon_hip.so"))
     hot = {k: v for k, v in res.items() if any(h in k for h in HOT)}
-    assert len(hot) >= 40, f"only {len(hot)} hot kernels found in the library: bundle parsing broken?"
+    assert len(hot) >= 30, f"only {len(hot)} hot kernels found in the library: bundle parsing broken?"
     for name, v in hot.items():
         assert v["waterfall"] == 0, f"{name}: {v['waterfall']} waterfall loop(s) -- a descriptor or soffset lives in VGPRs"
         assert v["scratch"] <= 16, f"{name}: {v['scratch']} bytes of scratch per lane (spills)"
