@@ -18,6 +18,19 @@ def collect(sub, counter):
 
 
 fetch, write = collect("pmc_fetch", "FETCH_SIZE"), collect("pmc_write", "WRITE_SIZE")
+
+
+def kernel_avg_ms():
+    """Kernel_Name -> average duration (ms) from the --kernel-trace --stats pass of the same command (kernel_stats.csv)."""
+    out = {}
+    f = os.path.join(d, "kernel_stats.csv")
+    if os.path.exists(f):
+        for r in csv.DictReader(open(f)):
+            out[r["Name"]] = float(r["AverageNs"]) / 1e6
+    return out
+
+
+avg_ms = kernel_avg_ms()
 # kernel-name patterns per class: the LayerNorm-folded chain (default) uses epilogues 6 / 7 / 5, the separate-LayerNorm chain 0 / 1 / 2
 CLASSES = {"gemm_qkv": (("gemm_pp6_kernel<T_F16, 6>", "gemm_pp6_kernel<T_F16, 0>", "gemm_pp_kernel<T_F16, 6,", "gemm_pp_kernel<T_F16, 0,"), 2 * 1024 + 2 * 3072),
            "gemm_fc1": (("gemm_pp6_kernel<T_F16, 7>", "gemm_pp6_kernel<T_F16, 1>", "gemm_pp_kernel<T_F16, 7,", "gemm_pp_kernel<T_F16, 1,"), 2 * 1024 + 2 * 4096),
@@ -39,6 +52,11 @@ for cls, (pats, bytes_per_row) in CLASSES.items():
         continue
     e = {"rows": rows, "fetch_size_kib_raw": f[0], "write_size_kib": w[0],
          "hbm_bytes_per_launch_corrected": (2 * f[0] + w[0]) * 1024}
+    for pat in pats:                                   # rocprofv3 average launch duration of the same kernel class
+        ms = [v for k, v in avg_ms.items() if pat in k]
+        if ms:
+            e["rocprof_avg_ms"] = ms[0]
+            break
     if bytes_per_row:
         wbytes = {"gemm_qkv": 3072 * 1024 * 2, "gemm_fc1": 4096 * 1024 * 2}.get(cls, 0)
         e["algorithmic_bytes"] = rows * bytes_per_row + wbytes

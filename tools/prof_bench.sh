@@ -2,7 +2,7 @@
 # rocprofv3 kernel-trace summary (+ HBM traffic counters for the GEMM kernels) of the benchmark command.
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$REPO/gpurun_out/prof_bench_$TAG
 mkdir -p $OUT
 CMD="python $REPO/bench.py --steps 2 --warmup 1 --cpu-images 0 --no-extras"
