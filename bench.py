@@ -643,6 +643,7 @@ def worker(args):
         # the committed rocprofv3 --kernel-trace --stats average of the same kernel (another box of the pool: +-4 %)
         result["roofline"]["frac_rocprof"] = GEMM_FLOPS[dom] * chunk_rows / (traffic_detail["rocprof_avg_ms"] * 1e-3) / PEAK_MFMA
     result["kernels"] = kernels
+    result["fp16_range_alarm_rows"] = enc.range_alarm_read()       # always-on: residual rows that came near the fp16 limit (0 = none)
     if world > 1:
         result["rccl"] = {"nranks": comm.rccl_ranks(), "version": _lib.load().pg_comm_rccl_version(),
                           "collective": "pg_allgather_many (C ABI, csrc/comm.hip): 5 buffers before refinement + 2 after, one grouped launch each"}

@@ -120,6 +120,12 @@ int pg_tune_gemm_tail_rows(int rows);
 int pg_tune_gemm_tail_shape(int min_k, int min_n);
 int pg_vit_saturation_check(pg_vit* h, int on);
 int pg_vit_saturation_read(pg_vit* h, int64_t* count, int reset);
+/* Always-on range alarm of the fp16 operand path (no scan, no cost worth naming): the kernel that turns the residual GEMMs' row
+ * statistics into (rstd, mean rstd) also counts the rows whose sum of squares reaches 65504^2 -- a NECESSARY condition for an
+ * element of that row's 16-bit copy (the next GEMM's operand) to have been clamped at the fp16 limit.  0 = no residual row ever
+ * came near the limit since the last reset; > 0 = run pg_vit_saturation_check for the exact element count, or switch the
+ * handle to bf16 operands.  Always 0 with bf16 operands or the separate-LayerNorm chain.  Synchronises the device. */
+int pg_vit_range_alarm_read(pg_vit* h, int64_t* rows, int reset);
 
 /* ------------------------------------------------------------------------------------------------
  * SuperGuessr geocell head.

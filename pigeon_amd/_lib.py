@@ -54,6 +54,7 @@ SIGNATURES = {
     "pg_tune_gemm_tail_shape": (_I, [_I, _I]),
     "pg_vit_saturation_check": (_I, [_P, _I]),
     "pg_vit_saturation_read": (_I, [_P, C.POINTER(_I64), _I]),
+    "pg_vit_range_alarm_read": (_I, [_P, C.POINTER(_I64), _I]),
     "pg_comm_unique_id": (_I, [_P]),
     "pg_comm_init_rank": (_I, [C.POINTER(_P), _I, _P, _I]),
     "pg_comm_count": (_I, [_P, C.POINTER(_I)]),

@@ -52,7 +52,8 @@ int pg_im2col_launch(const void* pixels, int pix_dtype, void* out, int out_dtype
 int pg_token_mean_launch(const float* x, float* out, int n_images, hipStream_t s);
 int pg_cast_f32_launch(const float* x, void* y, int out_dtype, int64_t n, hipStream_t s);
 int pg_rowstat_cast_launch(const float* x, void* x16, int out_dtype, float* rowstat, int64_t rows, float eps, hipStream_t s);
-int pg_rowstat_finalize_launch(const float* statpart, int slots, float* rowstat, int64_t rows, float eps, hipStream_t s);
+int pg_rowstat_finalize_launch(const float* statpart, int slots, float* rowstat, int64_t rows, float eps, hipStream_t s,
+                               unsigned long long* alarm = nullptr, float alarm_sumsq = 0.f);
 int pg_count_sat16_launch(const void* buf, int64_t rows, int cols, int64_t ld, int dtype, unsigned long long* counter, hipStream_t s);
 // attention.hip
 int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hipStream_t s);

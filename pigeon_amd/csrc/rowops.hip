@@ -185,8 +185,12 @@ int pg_rowstat_cast_launch(const float* x, void* x16, int out_dtype, float* rows
 
 // rowstat_finalize: (sum, sum of squares) partials per 64-column slice, written slot-major [slot][row][2] by the
 // EPI_RESID_STAT epilogue, summed in slice order -> (rstd, mean*rstd).  One thread per row (coalesced 8-byte reads).
+// Range alarm (always on with fp16 operands): a row whose sum of squares reaches 65504^2 MAY hold an element that the 16-bit copy
+// of the residual stream clamped (|x| >= 65504 implies it; the converse does not hold) -- one compare per row here, an atomic only
+// when it fires.  The exact, per-element count is the debug scan pg_vit_saturation_check.
 __global__ __launch_bounds__(256) void rowstat_finalize_kernel(const float* __restrict__ part, int slots, float* __restrict__ rowstat,
-                                                               int64_t rows, float eps) {
+                                                               int64_t rows, float eps, unsigned long long* __restrict__ alarm,
+                                                               float alarm_sumsq) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= rows) return;
     float s1 = 0.f, s2 = 0.f;
@@ -199,11 +203,14 @@ __global__ __launch_bounds__(256) void rowstat_finalize_kernel(const float* __re
     const float rstd = 1.0f / sqrtf(var + eps);
     rowstat[2 * row] = rstd;
     rowstat[2 * row + 1] = mean * rstd;
+    if (alarm && !(s2 < alarm_sumsq)) atomicAdd(alarm, 1ull);         // (NaN rows count too)
 }
 
-int pg_rowstat_finalize_launch(const float* statpart, int slots, float* rowstat, int64_t rows, float eps, hipStream_t s) {
+int pg_rowstat_finalize_launch(const float* statpart, int slots, float* rowstat, int64_t rows, float eps, hipStream_t s,
+                               unsigned long long* alarm, float alarm_sumsq) {
     if (rows <= 0) return PG_OK;
-    hipLaunchKernelGGL(rowstat_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, statpart, slots, rowstat, rows, eps);
+    hipLaunchKernelGGL(rowstat_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, statpart, slots, rowstat, rows, eps,
+                       alarm, alarm_sumsq);
     return pg_check_launch("rowstat_finalize");
 }
 

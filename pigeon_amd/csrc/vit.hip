@@ -147,6 +147,9 @@ struct pg_vit {
     // fp16 saturation scan (debug): device counter of 16-bit activations sitting on +-65504
     bool sat_check = false;
     unsigned long long* sat_counter = nullptr;
+    // always-on fp16 range alarm (rowstat_finalize_kernel): rows of the residual stream whose sum of squares reaches 65504^2
+    unsigned long long* range_alarm = nullptr;
+    float range_alarm_sumsq = 0.f;
     // profiling
     bool prof = false;
     unsigned prof_mask = 0xFFFFFFFFu;                      // classes bracketed while prof is on (bit c = class c)
@@ -200,6 +203,13 @@ extern "C" int pg_vit_create(pg_vit** out, int device, const pg_vit_cfg* cfg) {
     { const char* e = getenv("PIGEON_LN_FOLD"); h->ln_fold = !(e && e[0] == '0'); }
     if (pg_default_gemm_variant() < 30) h->ln_fold = false;   // the folded epilogues exist only in the persistent GEMM
     h->layers.resize(cfg->layers);
+    if (h->ln_fold && h->cfg.mma_dtype == PG_DTYPE_F16) {   // the always-on range alarm of the fp16 residual copies
+        PG_HIP(hipSetDevice(device));
+        PG_HIP(hipMalloc((void**)&h->range_alarm, sizeof(unsigned long long)));
+        h->allocs.push_back(h->range_alarm);
+        PG_HIP(hipMemset(h->range_alarm, 0, sizeof(unsigned long long)));
+        h->range_alarm_sumsq = 65504.0f * 65504.0f;
+    }
     { const char* e = getenv("PIGEON_VIT_STREAMS"); h->streams = e ? atoi(e) : PG_DEFAULT_VIT_STREAMS; }
     if (h->streams < 1 || h->streams > 4) h->streams = 1;
     if (h->streams > 1) {
@@ -452,7 +462,7 @@ static int vit_forward_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n
               RC(pg_gemm_launch(dt, Xn, VIT_HIDDEN, L.wo, VIT_HIDDEN, L.bo, X, VIT_HIDDEN, (int)M, VIT_HIDDEN, VIT_HIDDEN, EPI_RESID_STAT,
                                 1.f, 0, nullptr, 0, s, &ex)); }
             SAT(Xn2, M, VIT_HIDDEN, VIT_HIDDEN);
-            { ProfScope p(h, s, 6); RC(pg_rowstat_finalize_launch(statpart, slots, rsB, M, eps, s)); }
+            { ProfScope p(h, s, 6); RC(pg_rowstat_finalize_launch(statpart, slots, rsB, M, eps, s, h->range_alarm, h->range_alarm_sumsq)); }
             { ProfScope p(h, s, 2);
               ex = PgGemmExtra(); ex.colsum = L.s1; ex.rowstat = rsB;
               RC(pg_gemm_launch(dt, Xn2, VIT_HIDDEN, L.w1, VIT_HIDDEN, L.b1, big, VIT_MLP, (int)M, VIT_MLP, VIT_HIDDEN, EPI_GELU_LN, 1.f, 0,
@@ -467,7 +477,7 @@ static int vit_forward_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n
                                     nullptr, 0, s, &ex));
               } }
             if (!last) SAT(Xn, M, VIT_HIDDEN, VIT_HIDDEN);
-            if (!last) { ProfScope p(h, s, 6); RC(pg_rowstat_finalize_launch(statpart, slots, rsA, M, eps, s)); }
+            if (!last) { ProfScope p(h, s, 6); RC(pg_rowstat_finalize_launch(statpart, slots, rsA, M, eps, s, h->range_alarm, h->range_alarm_sumsq)); }
         }
     } else
     for (int l = 0; l < h->cfg.layers; ++l) {
@@ -554,6 +564,18 @@ extern "C" int pg_vit_destroy(pg_vit* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     delete h;
+    return PG_OK;
+}
+
+extern "C" int pg_vit_range_alarm_read(pg_vit* h, int64_t* rows, int reset) {
+    if (!h || !rows) { pg_set_error("range_alarm_read: null argument"); return PG_EINVAL; }
+    *rows = 0;
+    if (!h->range_alarm) return PG_OK;                       // bf16 operands, or the separate-LayerNorm chain: no alarm
+    PG_HIP(hipDeviceSynchronize());
+    unsigned long long v = 0;
+    PG_HIP(hipMemcpy(&v, h->range_alarm, sizeof(v), hipMemcpyDeviceToHost));
+    *rows = (int64_t)v;
+    if (reset) PG_HIP(hipMemset(h->range_alarm, 0, sizeof(v)));
     return PG_OK;
 }
 

@@ -339,6 +339,13 @@ class VitEncoder:
         check(load().pg_vit_saturation_read(self._h, C.byref(n), 1 if reset else 0), "pg_vit_saturation_read")
         return int(n.value)
 
+    def range_alarm_read(self, reset: bool = True) -> int:
+        """Rows of the residual stream whose sum of squares reached 65504^2 since the last reset (always-on, fp16 operands):
+        0 means no 16-bit copy of a residual row can have been clamped.  Synchronises the device."""
+        n = C.c_int64()
+        check(load().pg_vit_range_alarm_read(self._h, C.byref(n), 1 if reset else 0), "pg_vit_range_alarm_read")
+        return int(n.value)
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             load().pg_vit_destroy(self._h)

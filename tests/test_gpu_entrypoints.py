@@ -139,6 +139,7 @@ def test_vit24_trained_regime_both_ln_chains(env, golden_dir, monkeypatch, capsy
         enc.saturation_check(True)
         emb = enc.forward(px)
         sats[fold] = enc.saturation_read()
+        assert enc.range_alarm_read() == 0
         errs[fold] = orc.rel_err(emb.cpu(), ref)
         # the rows carry a DC offset of ~6 on every channel, which inflates ||ref||: also measure against the part that varies
         cerrs[fold] = float((emb.cpu().double() - ref.double()).norm() / (ref.double() - ref.double().mean()).norm())
@@ -186,6 +187,33 @@ def test_saturation_counter_counts_clamped_conversions(env):
     enc.saturation_check(False)
     enc.forward(big)
     assert enc.saturation_read() == 0
+    enc.close()
+
+
+def test_range_alarm_is_always_on_and_fires_only_near_the_fp16_limit(env):
+    """fp16's +-65504 range was guarded only by a debug scan that is off by default.  The row-statistics kernel
+    of the LayerNorm-fold chain now also counts residual rows whose sum of squares reaches 65504^2 (a necessary condition for a
+    clamped element in the 16-bit copy) -- always on, fp16 operands."""
+    syn, ops = env["syn"], env["ops"]
+    px = syn.make_pixels(1, seed=5).to(DEV)
+    enc = ops.VitEncoder(syn.make_vit_weights(seed=11, layers=2), device=0)
+    enc.forward(px)
+    assert enc.range_alarm_read() == 0                          # ordinary weights: nowhere near
+    enc.close()
+    sd = syn.make_vit_weights(seed=11, layers=2)
+    sd["encoder.layers.0.self_attn.out_proj.bias"] = sd["encoder.layers.0.self_attn.out_proj.bias"].clone()
+    sd["encoder.layers.0.self_attn.out_proj.bias"][7] = 1.0e5   # channel 7 of every residual row beyond the fp16 range from layer 0 on
+    enc = ops.VitEncoder(sd, device=0)
+    enc.saturation_check(True)
+    enc.forward(px)
+    rows = enc.range_alarm_read()
+    assert rows >= 577, rows                                    # every token row of the image, at least once
+    assert enc.saturation_read() >= 577                         # and the exact scan agrees that elements were clamped
+    assert enc.range_alarm_read() == 0                          # reset by the read
+    enc.close()
+    enc = ops.VitEncoder(sd, device=0, mma_dtype="bf16")        # bf16 operands have the range: no alarm
+    enc.forward(px)
+    assert enc.range_alarm_read() == 0
     enc.close()
 
 
