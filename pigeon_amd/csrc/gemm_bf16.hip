@@ -436,6 +436,23 @@ static int launch_a3w2(const GemmArgs& g0, int epi, hipStream_t s) {
 #undef PG_LAUNCH
 }
 
+// EPI_RESID_STAT on the 384 x 256 kernel (round 3): bit 0 = long-K GEMMs (fc2, K >= 2048), bit 1 = short-K ones (out-projection).
+// Results are bit-identical either way; this only selects the tile shape.  Env PIGEON_GEMM_RESID6 (A/B).  Measured on the 512-image
+// step (profiles/r03/pp6_resid_stat_ab.txt): fc2 2.224 -> 2.199 ms (-1.1 %; W is re-streamed through every XCD's L2 12 instead of 18
+// times, the 1.5x larger epilogue with its slab-ahead residual fetch gives most of it back), out-projection 0.90 -> 0.976 ms (its
+// epilogue is 43 % of a tile): the default takes fc2 only, +0.5 % end to end.
+#ifndef PG_DEFAULT_GEMM_RESID6
+#define PG_DEFAULT_GEMM_RESID6 1
+#endif
+static bool resid6_enabled(int K) {
+    static int mask = -1;
+    if (mask < 0) { const char* e = getenv("PIGEON_GEMM_RESID6"); mask = e ? atoi(e) : PG_DEFAULT_GEMM_RESID6; if (mask < 0) mask = 0; }
+    return (mask & (K >= 2048 ? 1 : 2)) != 0;
+}
+static bool use_pp6(int variant, int epi, int N, int K) {
+    return variant == 56 && pg_gemm_pp6_supported(epi, N, K) && (epi != EPI_RESID_STAT || resid6_enabled(K));
+}
+
 template <typename T>
 static int gemm_dispatch(GemmArgs& g, int epi, int variant, hipStream_t s) {
     switch (variant) {
@@ -488,7 +505,7 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
         // 8 us (+4 us with the GELU) + 2.44 us per K tile.
         const float f = pg_gemm_stagger_fraction();
         if (f > 0.f && M >= 256 * 64) {
-            const bool six = variant == 56 && pg_gemm_pp6_supported(epi, N, K);
+            const bool six = use_pp6(variant, epi, N, K);
             const float period_us = six ? ((epi == EPI_GELU || epi == EPI_GELU_LN ? 12.f : 8.f) + 2.44f * (K / 64))
                                         : ((epi == EPI_RESID || epi == EPI_RESID_STAT ? 25.f : 10.f) + 1.63f * (K / 64));
             g.xcd_stagger_ticks = (int)(f * period_us * 100.f);              // 100 ticks per us
@@ -506,7 +523,7 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
         // Tail split (gemm_tail.hip): if the tiles do not fill the persistent kernel's last round and the rows beyond the last
         // whole round are few, the persistent kernel gets the rows that make whole rounds and the small-tile kernel the rest.
         // Both produce the same bits for a row, so the cut changes timing only.
-        const bool six = variant == 56 && pg_gemm_pp6_supported(epi, N, K);
+        const bool six = use_pp6(variant, epi, N, K);
         const bool pp = !six && (variant == 56 || (variant >= 30 && variant < 50)) && N % 256 == 0 && K % 128 == 0;
         const int tail_max = pg_gemm_tail_rows();
         if ((six || pp) && tail_max > 0 && (K >= pg_gemm_tail_min_k() || N >= pg_gemm_tail_min_n()) && pg_gemm_tail_supported(epi, N, K)) {
@@ -538,7 +555,7 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
 #endif
     }
     if (variant == 56) {                                     // 384 x 256 tiles where they exist, the product kernel elsewhere
-        if (pg_gemm_pp6_supported(epi, N, K)) return pg_gemm_pp6_launch(dtype, g, epi, s);
+        if (use_pp6(variant, epi, N, K)) return pg_gemm_pp6_launch(dtype, g, epi, s);
         variant = 36;
     }
     if (variant >= 30 && variant < 50) {

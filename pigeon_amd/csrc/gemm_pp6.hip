@@ -14,8 +14,8 @@
 // mainloop (K/64 even).  A wave issues 6 + 4 DMAs per K tile; the lane's offset inside a 64-row DMA group does not depend
 // on the group (the swizzle term only sees (row>>1)&7), so ONE VGPR offset per operand is kept and the group / K advance
 // is added per DMA -- there are no registers to spare: 192 accumulators + 32 fragment registers + bias.
-// Only the 16-bit-output epilogues (EPI_QKV, EPI_GELU and their LayerNorm-fold forms) exist here: QKV and fc1 are where the weight bytes are (N = 3072 /
-// 4096, K = 1024).  Same MFMA order over K as every other GEMM kernel of the library: results are bit-identical.
+// The 16-bit-output epilogues (EPI_QKV, EPI_GELU and their LayerNorm-fold forms: QKV and fc1 are where the weight bytes are, N = 3072 /
+// 4096, K = 1024) and, since round 3, the fp32 residual epilogue with row statistics (EPI_RESID_STAT: out-projection and fc2).  Same MFMA order over K as every other GEMM kernel of the library: results are bit-identical.
 #include "gemm_epi.h"
 
 namespace {
@@ -174,12 +174,14 @@ __device__ __forceinline__ void ktile6(Acc6& acc, char* smem, uint32_t baseA, ui
 
 struct Bias6 { f32x4 lo, hi; };
 
+// HOFF: column distance between the lane's two f32x4 (4: eight consecutive columns; 32: the split halves of EPI_RESID_STAT)
+template <int HOFF = 4>
 __device__ __forceinline__ void load_bias6(Bias6& b, const GemmArgs& g, int col) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     b.lo = z; b.hi = z;
     if (g.bias) {
         b.lo = *(const f32x4*)(g.bias + col);
-        b.hi = *(const f32x4*)(g.bias + col + 4);
+        b.hi = *(const f32x4*)(g.bias + col + HOFF);
     }
 }
 __device__ __forceinline__ void pin_bias6(Bias6& b) { asm volatile("" : "+v"(b.lo), "+v"(b.hi)); }
@@ -260,6 +262,104 @@ __device__ __forceinline__ void epilogue6(Acc6& acc, const GemmArgs& g, char* sm
     }
 }
 
+// ---- EPI_RESID_STAT on 384 x 256 tiles (round 3: out-projection and fc2) ------------------------------------------------------
+// X += acc + b (fp32, in place), the 16-bit copy of the new rows and the per-64-column (sum, sum of squares) partials -- the
+// arithmetic is gemm_epi.h's (epi_resid4 / epi_copy16x4 / epi_stat8 / row8_sum), the geometry gemm_pp.hip's split halves (a lane
+// holds columns 4k.. and 32 + 4k.. of its row, k = lane & 7): results are bit-identical to the 256 x 256 kernel and the tail kernel.
+// Registers are the problem here (192 accumulators): the residual rows of a slab are 32 registers per lane.  Slab 0's rows are
+// fetched right after the last MFMA phase, into the dead fragment registers; slab i + 1's rows are fetched AFTER slab i's
+// accumulators have been parked in LDS, into the registers that frees, and land while slab i is processed (one slab ahead, as
+// in gemm_pp.hip, but with nothing spare).
+struct XRows6 { u32x4 v[4][2]; };
+template <int IT0 = 0, int IT1 = 4>
+__device__ __forceinline__ void fetch_xrows6(XRows6& x, __amdgpu_buffer_rsrc_t ro, int voff, int slab_off, int rstep) {
+#pragma unroll
+    for (int it = IT0; it < IT1; ++it)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)       // (readfirstlane: keeps the row offset an SGPR soffset -- no waterfall loop; loads need no
+            x.v[it][h] =                  //  bounds check on it: rows past M are read and dropped, the STORES carry it in the VGPR offset)
+                __builtin_amdgcn_raw_buffer_load_b128(ro, voff + 128 * h, __builtin_amdgcn_readfirstlane(slab_off + it * rstep), 0);
+}
+constexpr int P6_X0_EARLY = 2;                              // store iterations of slab 0 whose residual rows are fetched before the epilogue
+struct ResidCtx6 {
+    __amdgpu_buffer_rsrc_t ro, rx16, rstat;
+    int voff;
+};
+__device__ __forceinline__ ResidCtx6 make_resid6(const GemmArgs& g, int row0, int col0, int lane) {
+    ResidCtx6 r;
+    int rv = g.M - row0; rv = rv < 0 ? 0 : (rv > P6_TM * 32 ? P6_TM * 32 : rv);
+    rv = __builtin_amdgcn_readfirstlane(rv);                 // descriptors stay in SGPRs (rowstat_rsrc6)
+    const uint32_t nel = rv > 0 ? (uint32_t)((int64_t)(rv - 1) * g.ldc + 64) : 0u;
+    r.ro = make_rsrc((const char*)g.out + ((int64_t)row0 * g.ldc + col0) * 4, nel * 4u);
+    r.rx16 = make_rsrc((const char*)g.ex.x16 + ((int64_t)row0 * g.ldc + col0) * 2, nel * 2u);
+    r.rstat = make_rsrc((const char*)(g.ex.statpart + ((int64_t)(col0 / 64) * g.ex.stat_rows + row0) * 2), (uint32_t)rv * 8u);
+    r.voff = ((lane >> 3) * (int)g.ldc + (lane & 7) * 4) * 4;
+    return r;
+}
+template <typename T, typename PREFETCH_DMA, typename PREFETCH_BIAS>
+__device__ __forceinline__ void epilogue6_resid(Acc6& acc, const GemmArgs& g, char* smem, int wave, int lane, int row0, int col0,
+                                                const Bias6& bias, const XRows6& x0, const ResidCtx6& rc,
+                                                PREFETCH_DMA&& prefetch_dma, PREFETCH_BIAS&& prefetch_bias, int dbg_iter = 0) {
+    constexpr int ROWPF = P6_SLAB_ROWF;
+    const int l15 = lane & 15, lq = lane >> 4;
+    float* slab = (float*)(smem + P6_SLAB_OFF + wave * P6_SLAB_BYTES);
+    const int rr = lane >> 3, cc = (lane & 7) * 4;
+    int rstep = 8 * (int)g.ldc * 4;                          // bytes between two store iterations
+    int sstep = 32 * (int)g.ldc * 4;                         // bytes between two slabs
+    asm volatile("" : "+s"(rstep), "+s"(sstep));             // not hoisted into SGPRs across the K loop
+    prefetch_dma();
+    XRows6 xr[2];
+#pragma unroll
+    for (int it = 0; it < P6_X0_EARLY; ++it) { xr[0].v[it][0] = x0.v[it][0]; xr[0].v[it][1] = x0.v[it][1]; }
+    auto process = [&](int i, int it) {
+        const int r = it * 8 + rr;
+        const f32x4 lo = *(const f32x4*)(slab + r * ROWPF + cc);
+        const f32x4 hi = *(const f32x4*)(slab + r * ROWPF + cc + 32);
+        // row offset in the VGPR offset, not the SGPR soffset (bounds check of the M tail; hazard of >64-bit stores: gemm_pp.hip)
+        const int ooff = rc.voff + (i * sstep + it * rstep);
+        const f32x4 x = epi_resid4(__builtin_bit_cast(f32x4, xr[i & 1].v[it][0]), lo, bias.lo);
+        const f32x4 y = epi_resid4(__builtin_bit_cast(f32x4, xr[i & 1].v[it][1]), hi, bias.hi);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rc.ro, ooff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rc.ro, ooff + 128, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(epi_copy16x4<T>(x), rc.rx16, ooff >> 1, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(epi_copy16x4<T>(y), rc.rx16, (ooff >> 1) + 64, 0, 0);
+        float s1, s2;
+        epi_stat8(x, y, s1, s2);
+        s1 = row8_sum(s1);
+        s2 = row8_sum(s2);
+        if ((lane & 7) == 0) { slab[r * ROWPF + 64] = s1; slab[r * ROWPF + 65] = s2; }
+    };
+#pragma unroll
+    for (int i = 0; i < P6_TM; ++i) {
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(f32x4*)(slab + (ib * 16 + l15) * ROWPF + j * 16 + 4 * lq) = acc[2 * i + ib][j];
+        // Slab i's accumulators are parked: 32 registers are free.  The residual rows arrive in HALVES (16 registers each):
+        // the first two store iterations of slab i + 1 now, its last two once the first two of slab i are done with theirs --
+        // 48 residual registers live at the peak instead of 64 (next to 160 accumulators that is the difference between no
+        // spill and a spilled piece, which costs a vmcnt(0) in the middle of the epilogue).  Slab 0: only its first two
+        // iterations could be fetched before the epilogue, its last two come with this first batch.
+        if (i == 0) fetch_xrows6<P6_X0_EARLY, 4>(xr[0], rc.ro, rc.voff, 0, rstep);
+        if (i + 1 < P6_TM) fetch_xrows6<0, 2>(xr[(i + 1) & 1], rc.ro, rc.voff, (i + 1) * sstep, rstep);
+        wave_lds_fence();
+        process(i, 0);
+        process(i, 1);
+        if (i + 1 < P6_TM) fetch_xrows6<2, 4>(xr[(i + 1) & 1], rc.ro, rc.voff, (i + 1) * sstep, rstep);
+        process(i, 2);
+        process(i, 3);
+        wave_lds_fence();                                    // slab reads retired, the row partials parked
+        // one coalesced 256-byte store of the slab's 32 row partials, through a descriptor that ends at the tile's last valid row
+        // (the slab offset rides in the instruction's immediate, which the bounds check covers): written as flat stores, hipcc keeps
+        // six (32 i + lane) indices and their byte offsets live across the whole K loop and spills them (first build: 88 bytes)
+        if (lane < 32)
+            __builtin_amdgcn_raw_buffer_store_b64(*(const u32x2*)(slab + lane * ROWPF + 64), rc.rstat, lane * 8 + i * 256, 0, 0);
+        wave_lds_fence();
+        PG_TS(g, dbg_iter, wave, 3 + i);
+        if (i == 0) prefetch_bias();
+    }
+}
+
 template <typename T, int EPI>
 __global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -279,7 +379,9 @@ __global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
     const uint32_t smem0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const uint32_t baseA = smem0 + (wm * (P6_TM * 32) + l15) * ROWB + xo0;
     const uint32_t baseB = smem0 + P6_W_OFF + (wn * 64 + l15) * ROWB + xo0;
-    const int ecc = (lane & 7) * 8;
+    constexpr bool RSTAT = (EPI == EPI_RESID_STAT);
+    constexpr int BHOFF = RSTAT ? 32 : 4;
+    const int ecc = RSTAT ? (lane & 7) * 4 : (lane & 7) * 8;
 
     const int nt = g.K / BK;                                 // even, >= 4 (checked on the host)
     const int nblk = gridDim.x;
@@ -289,7 +391,7 @@ __global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
     Tile6 c = make_tile6(g, L);
     issue_dma6<0, P6_NDMA>(c, smem, wave, voffA, voffW, 0);  // K tile 0 of the first output tile -> stage 0
     Bias6 bias;
-    load_bias6(bias, g, c.n0 + wn * 64 + ecc);
+    load_bias6<BHOFF>(bias, g, c.n0 + wn * 64 + ecc);
     pin_bias6(bias);
     // at the top of the next tile vmcnt(NST) must mean "the prefetched K tile 0 has landed": the DMAs are the oldest
     // operations of an epilogue, at least 5 x 4 stores (+ the bias / row-statistics loads) are younger than all of them
@@ -328,6 +430,12 @@ __global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
             rrs = rowstat_rsrc6(g, row0);
             load_rowstat6(rs0, rrs, lane >> 3, 0);
         }
+        ResidCtx6 rc;
+        XRows6 x0;
+        if constexpr (RSTAT) {                               // residual rows of slab 0 into the (dead) fragment registers
+            rc = make_resid6(g, row0, col0, lane);
+            fetch_xrows6<0, P6_X0_EARLY>(x0, rc.ro, rc.voff, 0, 8 * (int)g.ldc * 4);
+        }
         if (!follower) raw_barrier();                        // re-align: every wave has left the mainloop
         // inline-asm MFMAs: hipcc pads no "matrix-pipe write -> VALU / LDS read" hazard for the accumulators (see gemm_pp.hip)
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
@@ -341,8 +449,9 @@ __global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
             c = make_tile6(g, more ? L : L - nblk);
             issue_dma6<0, P6_NDMA>(c, smem, wave, voffA, voffW, 0);
         };
-        auto prefetch_bias = [&]() { load_bias6(bias_next, g, c.n0 + wn * 64 + ecc); };
-        epilogue6<T, EPI>(acc, g, smem, wave, lane, row0, col0, bias, cs, rs0, rrs, prefetch_dma, prefetch_bias, dbg_iter);
+        auto prefetch_bias = [&]() { load_bias6<BHOFF>(bias_next, g, c.n0 + wn * 64 + ecc); };
+        if constexpr (RSTAT) epilogue6_resid<T>(acc, g, smem, wave, lane, row0, col0, bias, x0, rc, prefetch_dma, prefetch_bias, dbg_iter);
+        else epilogue6<T, EPI>(acc, g, smem, wave, lane, row0, col0, bias, cs, rs0, rrs, prefetch_dma, prefetch_bias, dbg_iter);
         PG_TS(g, dbg_iter, wave, 9);
         ++dbg_iter;
         if (!more) break;
@@ -379,7 +488,8 @@ int cus6() {
 
 // true if this (epilogue, shape) has a 384 x 256 kernel
 bool pg_gemm_pp6_supported(int epi, int N, int K) {
-    return (epi == EPI_QKV || epi == EPI_GELU || epi == EPI_QKV_LN || epi == EPI_GELU_LN) && N % P6_BN == 0 && K % (2 * BK) == 0 && K >= 4 * BK;
+    return (epi == EPI_QKV || epi == EPI_GELU || epi == EPI_QKV_LN || epi == EPI_GELU_LN || epi == EPI_RESID_STAT) && N % P6_BN == 0 &&
+           K % (2 * BK) == 0 && K >= 4 * BK;
 }
 
 int pg_gemm_pp6_launch(int dtype, GemmArgs g, int epi, hipStream_t s) {
@@ -396,11 +506,13 @@ int pg_gemm_pp6_launch(int dtype, GemmArgs g, int epi, hipStream_t s) {
     if (pg_gemm_block_cap() > 0 && pg_gemm_block_cap() < cap) cap = pg_gemm_block_cap();   // tuning: share the chip between streams
     const int nblk = g.ntiles < cap ? g.ntiles : cap;
     if ((epi == EPI_QKV_LN || epi == EPI_GELU_LN) && (!g.ex.colsum || !g.ex.rowstat)) { pg_set_error("gemm_pp6: LN epilogue needs colsum / rowstat"); return PG_EINVAL; }
+    if (epi == EPI_RESID_STAT && (!g.ex.x16 || !g.ex.statpart || g.ex.ldx != g.ldc || !g.bias)) { pg_set_error("gemm_pp6: EPI_RESID_STAT needs bias, x16 / statpart and ldx == ldc"); return PG_EINVAL; }
 #define P6_DISPATCH(TT)                                                          \
     switch (epi) {                                                               \
         case EPI_QKV: return launch_pp6<TT, EPI_QKV>(g, nblk, s);                \
         case EPI_GELU: return launch_pp6<TT, EPI_GELU>(g, nblk, s);              \
         case EPI_QKV_LN: return launch_pp6<TT, EPI_QKV_LN>(g, nblk, s);          \
+        case EPI_RESID_STAT: return launch_pp6<TT, EPI_RESID_STAT>(g, nblk, s);  \
         default: return launch_pp6<TT, EPI_GELU_LN>(g, nblk, s);                 \
     }
     if (dtype == PG_DTYPE_F16) { P6_DISPATCH(T_F16) }

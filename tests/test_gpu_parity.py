@@ -196,6 +196,39 @@ def test_gemm_tail_split_changes_nothing(env):
         ops.tune_gemm_tail_shape(2048, 4096)
 
 
+def test_gemm_resid_stat_on_384_row_tiles_bit_identical(env):
+    """Round 3: fc2 (K >= 2048) runs its fp32-residual + 16-bit-copy + row-statistics epilogue on the 384 x 256 kernel
+    (gemm_pp6.hip epilogue6_resid).  Same MFMA chain, same epilogue arithmetic (gemm_epi.h), same split-halves geometry: the new
+    residual rows, their 16-bit copy and the (sum, sum of squares) partials must equal the 256 x 256 kernel's bit for bit --
+    several persistent rounds, a ragged M tail, guard rows untouched, with the tail split on and off."""
+    ops, L = env["ops"], env["lib"]
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 3 * 256 * 96 + 211, 1024, 2048                  # 193 row panels of 384 x 4 column tiles = 772 tiles: 3 rounds + a tail
+    A = torch.randn((M, K), generator=g).to(torch.float16).to(DEV)
+    W = (torch.randn((N, K), generator=g) * 0.03).to(torch.float16).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    X0 = torch.cat([torch.randn((M, N), generator=g), torch.full((5, N), 7.0)]).to(DEV)     # 5 guard rows past M
+    res = {}
+    try:
+        for tail in (0, 768):
+            ops.tune_gemm_tail_rows(tail)
+            for v in (36, 56):
+                X = X0.clone()
+                x16, part = ops.gemm16_resid_stat(A, W, bias, X[:M], variant=v)
+                torch.cuda.synchronize()
+                assert bool((X[M:] == 7.0).all()), (tail, v)
+                res[(tail, v)] = (X[:M].clone(), x16.clone(), part.clone())
+    finally:
+        ops.tune_gemm_tail_rows(768)
+    ref = res[(0, 36)]
+    for key, got in res.items():
+        for name, a, b in zip(("X", "x16", "statpart"), ref, got):
+            assert torch.equal(a, b), (key, name)
+    # and the values themselves: X = X0 + A W^T + b on the rounded operands
+    want = X0[:2048] + A[:2048].float() @ W.float().T + bias
+    assert torch.allclose(ref[0][:2048], want, rtol=2e-3, atol=2e-3)
+
+
 def test_gemm_w4_one_wave_per_simd_kernel(env):
     """gemm_w4.hip (variant 64, experimental): v_mfma_f32_16x16x32 sums the k products of an instruction in another
     association than the 32x32x16 kernels, so it is held to fp32 rounding against variant 36 -- every epilogue incl. the
