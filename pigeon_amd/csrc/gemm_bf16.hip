@@ -438,9 +438,8 @@ static int launch_a3w2(const GemmArgs& g0, int epi, hipStream_t s) {
 
 // EPI_RESID_STAT on the 384 x 256 kernel (round 3): bit 0 = long-K GEMMs (fc2, K >= 2048), bit 1 = short-K ones (out-projection).
 // Results are bit-identical either way; this only selects the tile shape.  Env PIGEON_GEMM_RESID6 (A/B).  Measured on the 512-image
-// step (profiles/r03/pp6_resid_stat_ab.txt): fc2 2.224 -> 2.199 ms (-1.1 %; W is re-streamed through every XCD's L2 12 instead of 18
-// times, the 1.5x larger epilogue with its slab-ahead residual fetch gives most of it back), out-projection 0.90 -> 0.976 ms (its
-// epilogue is 43 % of a tile): the default takes fc2 only, +0.5 % end to end.
+// step (profiles/r03/pp6_resid_stat_ab.txt): fc2 2.224 -> 2.152 ms (-3.2 %; W is re-streamed through every XCD's L2 12 instead of 18
+// times), out-projection 0.90 -> 0.976 ms (its epilogue is 43 % of a tile, first build): the default takes fc2 only, +0.9 % end to end.
 #ifndef PG_DEFAULT_GEMM_RESID6
 #define PG_DEFAULT_GEMM_RESID6 1
 #endif

@@ -43,6 +43,8 @@
 // the row-statistics partials use the same 64-column slices and summation order.
 #include "gemm_epi.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int W4_BM = 256, W4_BN = 256;
@@ -205,26 +207,32 @@ __device__ __forceinline__ void dma_one(__amdgpu_buffer_rsrc_t ra, __amdgpu_buff
 // k-step 0 of a K tile: 64 MFMAs on `fc`; the 16 fragment reads of k-step 1 (into `fn`) one after every second MFMA of the
 // first half -- the wait at the end comes 32 MFMAs after the last read -- and the wave's 16 DMAs of the NEXT K tile of the
 // stream, one after every fourth MFMA, into the other stage (freed by the barrier that ended the previous K tile)
-template <int Q, bool ZERO, typename T>
+// SCHED (round 3 experiment, env PIGEON_W4_SCHED): 0 = as described above (one DMA per four MFMAs over the whole k-step: the last
+// one is issued 36 MFMAs before the wave waits for it); 1 = all sixteen DMAs in the first 32 MFMAs, two per quad next to the two
+// fragment reads (one non-MFMA instruction per MFMA, as in hipBLASLt's loop), the second half of the k-step pure MFMAs: the last
+// DMA then has 64 MFMAs (~1000 matrix-pipe cycles) to land.
+template <int Q, bool ZERO, int SCHED, typename T>
 __device__ __forceinline__ void kstep0_quad(Acc4& acc, const Frag4<T>& fc, Frag4<T>& fn, uint32_t aA, uint32_t aB,
                                             __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rw, char* stage, int wave, int voffA,
                                             int voffW, int sa, int sw, int koff) {
     if constexpr (Q < 16) {
         mma_one<4 * Q, ZERO>(acc, fc);
-        dma_one<Q>(ra, rw, stage, wave, voffA, voffW, sa, sw, koff);
+        if constexpr (SCHED == 0) dma_one<Q>(ra, rw, stage, wave, voffA, voffW, sa, sw, koff);
+        else if constexpr (Q < 8) dma_one<2 * Q>(ra, rw, stage, wave, voffA, voffW, sa, sw, koff);
         mma_one<4 * Q + 1, ZERO>(acc, fc);
         if constexpr (Q < 8) read_frag<2 * Q>(fn, aA, aB);
         mma_one<4 * Q + 2, ZERO>(acc, fc);
+        if constexpr (SCHED == 1 && Q < 8) dma_one<2 * Q + 1>(ra, rw, stage, wave, voffA, voffW, sa, sw, koff);
         mma_one<4 * Q + 3, ZERO>(acc, fc);
         if constexpr (Q < 8) read_frag<2 * Q + 1>(fn, aA, aB);
-        kstep0_quad<Q + 1, ZERO>(acc, fc, fn, aA, aB, ra, rw, stage, wave, voffA, voffW, sa, sw, koff);
+        kstep0_quad<Q + 1, ZERO, SCHED>(acc, fc, fn, aA, aB, ra, rw, stage, wave, voffA, voffW, sa, sw, koff);
     }
 }
-template <bool ZERO, typename T>
+template <bool ZERO, int SCHED, typename T>
 __device__ __forceinline__ void kstep4_dma(Acc4& acc, const Frag4<T>& fc, Frag4<T>& fn, uint32_t aA, uint32_t aB,
                                            __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rw, char* stage, int wave, int voffA,
                                            int voffW, int sa, int sw, int koff) {
-    kstep0_quad<0, ZERO>(acc, fc, fn, aA, aB, ra, rw, stage, wave, voffA, voffW, sa, sw, koff);
+    kstep0_quad<0, ZERO, SCHED>(acc, fc, fn, aA, aB, ra, rw, stage, wave, voffA, voffW, sa, sw, koff);
     asm_wait_lgkm0();
 }
 
@@ -256,23 +264,23 @@ __device__ __forceinline__ void w4_drain() { asm volatile("s_nop 15\n\ts_nop 15"
 // exit.  Its k-step 0 issues the DMAs of K tile u + 1 (same output tile) into the other stage.  FIRST: u == 0 of an output
 // tile, the first k-step accumulates from 0.  Branch-free: a branch around the asm would make hipcc merge 256 accumulator
 // registers at the join and spill them.
-template <typename T, bool FIRST>
+template <typename T, bool FIRST, int SCHED>
 __device__ __forceinline__ void ktile4(Acc4& acc, Frag4<T> (&f)[2], char* smem, int u, const Tile4& c, int wave,
                                        int voffA, int voffW, int sa, int sw, uint32_t baseA, uint32_t baseB) {
     const uint32_t so = (uint32_t)(u & 1) * W4_STAGE, sn = W4_STAGE - so;
     // k-step 1 reads chunk (4 + (lane >> 4)) ^ swz = chunk0 ^ 4: address ^ 64 (disjoint bits)
-    kstep4_dma<FIRST>(acc, f[0], f[1], (baseA + so) ^ 64u, (baseB + so) ^ 64u, c.ra, c.rw, smem + sn, wave, voffA, voffW, sa, sw,
+    kstep4_dma<FIRST, SCHED>(acc, f[0], f[1], (baseA + so) ^ 64u, (baseB + so) ^ 64u, c.ra, c.rw, smem + sn, wave, voffA, voffW, sa, sw,
                       (u + 1) * ROWB);
     kstep4_close<T>(acc, f[1], f[0], baseA + sn, baseB + sn);
 }
 
 // the last K tile of an output tile (u == nt - 1, stage 1; nt is even): its k-step 0 prefetches K tile 0 of the NEXT output
 // tile into stage 0 -- it lands under the rest of this K tile and the epilogue -- and nothing is read past its k-step 1
-template <typename T>
+template <typename T, int SCHED>
 __device__ __forceinline__ void ktile4_last(Acc4& acc, Frag4<T> (&f)[2], char* smem, const Tile4& cn, int wave,
                                             int voffA, int voffW, int sa, int sw, uint32_t baseA, uint32_t baseB) {
     const uint32_t so = W4_STAGE;
-    kstep4_dma<false>(acc, f[0], f[1], (baseA + so) ^ 64u, (baseB + so) ^ 64u, cn.ra, cn.rw, smem, wave, voffA, voffW, sa, sw, 0);
+    kstep4_dma<false, SCHED>(acc, f[0], f[1], (baseA + so) ^ 64u, (baseB + so) ^ 64u, cn.ra, cn.rw, smem, wave, voffA, voffW, sa, sw, 0);
     mma_run<0, 64, false>(acc, f[1]);
 }
 
@@ -434,7 +442,7 @@ __device__ __forceinline__ void epilogue4(Acc4& acc, const GemmArgs& g, char* sm
     }
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, int SCHED>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -478,9 +486,9 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmArgs g) {
         Frag4<T> f[2];
         read_frags<0, 16>(f[0], baseA, baseB);
         asm_wait_lgkm0();
-        ktile4<T, true>(acc, f, smem, 0, c, wave, voffA, voffW, sa, sw, baseA, baseB);            // first k-step: C = 0
-        for (int u = 1; u + 1 < nt; ++u) ktile4<T, false>(acc, f, smem, u, c, wave, voffA, voffW, sa, sw, baseA, baseB);
-        ktile4_last<T>(acc, f, smem, cn, wave, voffA, voffW, sa, sw, baseA, baseB);
+        ktile4<T, true, SCHED>(acc, f, smem, 0, c, wave, voffA, voffW, sa, sw, baseA, baseB);            // first k-step: C = 0
+        for (int u = 1; u + 1 < nt; ++u) ktile4<T, false, SCHED>(acc, f, smem, u, c, wave, voffA, voffW, sa, sw, baseA, baseB);
+        ktile4_last<T, SCHED>(acc, f, smem, cn, wave, voffA, voffW, sa, sw, baseA, baseB);
         w4_drain();
         // the next tile's bias (/ colsum): lands under the epilogue
         Bias4 bias_next;
@@ -496,10 +504,15 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmArgs g) {
     }
 }
 
-template <typename T, int EPI>
-int launch_w4(const GemmArgs& g, int nblk, hipStream_t s) {
+static int w4_sched() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PIGEON_W4_SCHED"); v = e ? atoi(e) : 0; if (v < 0 || v > 1) v = 0; }
+    return v;
+}
+template <typename T, int EPI, int SCHED>
+int launch_w4s(const GemmArgs& g, int nblk, hipStream_t s) {
     static bool attr_set = false;
-    auto kfn = gemm_w4_kernel<T, EPI>;
+    auto kfn = gemm_w4_kernel<T, EPI, SCHED>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
         if (e != hipSuccess) { pg_set_error("gemm_w4: set LDS attr: %s", hipGetErrorString(e)); return PG_EHIP; }
@@ -507,6 +520,12 @@ int launch_w4(const GemmArgs& g, int nblk, hipStream_t s) {
     }
     hipLaunchKernelGGL(kfn, dim3(nblk), dim3(256), W4_LDS, s, g);
     return pg_check_launch("gemm_w4");
+}
+template <typename T, int EPI>
+int launch_w4(const GemmArgs& g, int nblk, hipStream_t s) {
+    // the schedule experiment is built for the two residual epilogues only (out-projection / fc2: where this kernel could pay)
+    if constexpr (EPI == EPI_RESID || EPI == EPI_RESID_STAT) { if (w4_sched() == 1) return launch_w4s<T, EPI, 1>(g, nblk, s); }
+    return launch_w4s<T, EPI, 0>(g, nblk, s);
 }
 
 int cus4() {
