@@ -513,6 +513,7 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
     if (g.ex.stat_rows <= 0) g.ex.stat_rows = M;
 #ifdef PIGEON_ABLATIONS
     if (g_dbg_ts && epi != EPI_PATCH) { g.aux = (const float*)g_dbg_ts; g.stagger = -7; }
+    else if (epi == EPI_RESID_STAT) { static const bool abl = getenv("PIGEON_EPI_ABL") != nullptr; if (abl) g.stagger = -11; }
 #endif
     if (variant == 70) {                                     // the whole problem through the small-tile tail kernel (tests, tools)
         if (!pg_gemm_tail_supported(epi, N, K)) { pg_set_error("gemm: variant 70 (gemm_tail) does not support epi=%d N=%d K=%d", epi, N, K); return PG_EINVAL; }

@@ -461,9 +461,25 @@ __device__ __forceinline__ void pp_epilogue(AccPP& acc, const GemmArgs& g, char*
                     __builtin_amdgcn_raw_buffer_store_b128(pk, ro, ooff, 0, PP_STORE_AUX);
                 } else if constexpr (RESID) {
                     const f32x4 x = epi_resid4(__builtin_bit_cast(f32x4, XEARLY == 1 ? xq[i][it] : xr[i & 1][it][0]), lo, bias.lo);
+#ifdef PIGEON_ABLATIONS
+                    // timing-only ablation (env PIGEON_EPI_ABL=1, WRONG RESULTS): the fp32 rows written as 8 instead of 16 bytes per
+                    // lane -- the write traffic a residual stream stored as an fp16 value + fp16 correction pair would have
+                    // (8 instead of 10 bytes per element in all)
+                    const bool half_store = STAT && g.stagger == -11;
+                    if (half_store) {
+                        u32x2 hx2; hx2[0] = __builtin_bit_cast(u32x4, x)[0]; hx2[1] = __builtin_bit_cast(u32x4, x)[1];
+                        __builtin_amdgcn_raw_buffer_store_b64(hx2, ro, ooff, 0, 0);
+                    } else
+#endif
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), ro, ooff, 0, PP_STORE_AUX);
                     if constexpr (STAT) {
                         const f32x4 y = epi_resid4(__builtin_bit_cast(f32x4, xr[i & 1][it][1]), hi, bias.hi);
+#ifdef PIGEON_ABLATIONS
+                        if (half_store) {
+                            u32x2 hy2; hy2[0] = __builtin_bit_cast(u32x4, y)[0]; hy2[1] = __builtin_bit_cast(u32x4, y)[1];
+                            __builtin_amdgcn_raw_buffer_store_b64(hy2, ro, ooff + HOFF * 4, 0, 0);
+                        } else
+#endif
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, ooff + HOFF * 4, 0, 0);
                         __builtin_amdgcn_raw_buffer_store_b64(epi_copy16x4<T>(x), rx16, ooff >> 1, 0, 0);
                         __builtin_amdgcn_raw_buffer_store_b64(epi_copy16x4<T>(y), rx16, (ooff >> 1) + HOFF * 2, 0, 0);
