@@ -769,14 +769,18 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void attention5_kernel(const u
 //                 as A uses the same;  A = V^T block (16 d x 32 keys): two ds_read_b64_tr_b16 per fragment (keys 32 j + 4 g4 ..
 //                 and 32 j + 16 + 4 g4 .., column 16 db + r16);  D = O^T block: lane holds d 16 db + 4 g4 + e of query r16.
 //   A lane therefore holds NQB queries (one per 16-query block), 16 keys of each per tile; the 64 keys of a query are spread
-//   over the 4 lanes r16 + 16 g4.  The row sum is per-lane partial (combined once at the end); the reference maximum (first
+//   over the 4 lanes r16 + 16 g4.  The row sum comes out of the matrix pipe: a fifth 16-row "d" block whose V^T rows are (1, 0, ..., 0)
+//   -- two more MFMAs per tile and query block instead of 16 v_dot2c per tile, which share the matrix pipe and cost more than the
+//   MFMAs do (-2 %, profiles/r03/attention_v7_v8_ab.txt); with LSUM = false it is a per-lane partial (combined once at the end); the reference maximum (first
 //   tile / careful path) needs two lane exchanges (xor 16, xor 32).
 // LDS: K tile as before (row = key, 16-byte chunk c at c ^ ((key >> 1) & 7)).  V tile row-major with the 32-byte column block
 //   db stored at db ^ ((key >> 1) & 3): one transposing read pass (lanes 0-31) then covers 8 key rows x 32 B = all 64 banks once.
 // NQB x WAVES = 2 x 4 (32 queries per wave, 3 waves per SIMD, as v5) or 4 x 2 (64 queries per wave, 2 waves per SIMD: each K / V
 //   fragment read from LDS feeds twice the MFMAs).  Block = 128 queries either way, 5 blocks per (image, head) on one XCD.
 // ================================================================================================================
-template <typename T, int NQB>
+// LSUM: true = the row sums come out of the matrix pipe (an extra "ones" row block in the PV product, attention8_kernel) and this
+// function only exponentiates and packs; false = v_dot2c on the packed P (16 per tile and wave; v_dot2c shares the matrix pipe).
+template <typename T, int NQB, bool LSUM = false>
 __device__ __forceinline__ void att8_exp_pack(const f32x4 (&S)[4][NQB], float (&l)[NQB], typename T::v8 (&pf)[NQB][2]) {
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
@@ -790,19 +794,21 @@ __device__ __forceinline__ void att8_exp_pack(const f32x4 (&S)[4][NQB], float (&
                 for (int w = 0; w < 2; ++w) {
                     const f32x4& sv = S[2 * j + h][qb];
                     pw[2 * h + w] = T::pack2(__builtin_amdgcn_exp2f(sv[2 * w]), __builtin_amdgcn_exp2f(sv[2 * w + 1]));
-                    if (w) l1 = T::dot2(pw[2 * h + w], AttOnes<T>::v, l1);
-                    else l0 = T::dot2(pw[2 * h + w], AttOnes<T>::v, l0);
+                    if constexpr (!LSUM) {
+                        if (w) l1 = T::dot2(pw[2 * h + w], AttOnes<T>::v, l1);
+                        else l0 = T::dot2(pw[2 * h + w], AttOnes<T>::v, l0);
+                    }
                 }
             pf[qb][j] = __builtin_bit_cast(typename T::v8, pw);
         }
-        l[qb] = l0 + l1;
+        if constexpr (!LSUM) l[qb] = l0 + l1;
     }
 }
 
 // careful softmax step: per-query maximum of the tile (relative to the reference, the scores arrive as s - m), lazy rescale
-template <typename T, int NQB>
+template <typename T, int NQB, bool LSUM = false>
 __device__ __forceinline__ void att8_softmax(f32x4 (&S)[4][NQB], f32x4 (&O)[4][NQB], f32x4 (&negm)[NQB], float (&l)[NQB],
-                                             typename T::v8 (&pf)[NQB][2], bool first) {
+                                             typename T::v8 (&pf)[NQB][2], bool first, f32x4 (&L)[NQB]) {
     float tmax[NQB];
     bool over = false;
 #pragma unroll
@@ -831,10 +837,11 @@ __device__ __forceinline__ void att8_softmax(f32x4 (&S)[4][NQB], f32x4 (&O)[4][N
             for (int kb = 0; kb < 4; ++kb) S[kb][qb] -= delta;
 #pragma unroll
             for (int db = 0; db < 4; ++db) O[db][qb] *= alpha;
-            l[qb] *= alpha;
+            if constexpr (LSUM) L[qb] *= alpha;
+            else l[qb] *= alpha;
         }
     }
-    att8_exp_pack<T, NQB>(S, l, pf);
+    att8_exp_pack<T, NQB, LSUM>(S, l, pf);
 }
 
 // Everything that is not valid HOST code lives in __device__ functions, not in the kernel body or its lambdas: those are also
@@ -869,7 +876,7 @@ __device__ __forceinline__ void att8_wait_v(u32x4 (&vf)[4][2]) {
                  :: "memory");
 }
 
-template <typename T, int NQB, int WAVES, int WPS>
+template <typename T, int NQB, int WAVES, int WPS, bool LSUM = false>
 __global__ __launch_bounds__(256, WPS) void attention8_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
     static_assert(NQB * WAVES * 16 == ATT_QB, "a block covers 128 queries");
     static_assert(VIT_TOKENS == 9 * ATT_KT + 1, "key tail assumes 577 tokens");
@@ -898,11 +905,15 @@ __global__ __launch_bounds__(256, WPS) void attention8_kernel(const uint16_t* __
             qf[qb][ks] = *(const typename T::v8*)(qkv + (base + qr) * QKV_LD + head * 64 + ks * 32 + g4 * 8);
     }
     f32x4 O[4][NQB], negm[NQB];
+    f32x4 L[NQB];                                            // LSUM: row sums as a fifth "d" block whose V^T rows are (1, 0, 0, ...): l = L[qb][0] in lanes g4 == 0
     float l[NQB];
+    // A fragment of that block: row m = 0 is all ones (lanes r16 == 0 hold eight 1.0), rows 1..15 zero
+    const u32x4 ones_rows = r16 == 0 ? u32x4{AttOnes<T>::v, AttOnes<T>::v, AttOnes<T>::v, AttOnes<T>::v} : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
         negm[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
         l[qb] = 0.f;
+        L[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int db = 0; db < 4; ++db) O[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -965,7 +976,7 @@ __global__ __launch_bounds__(256, WPS) void attention8_kernel(const uint16_t* __
             // the 16 transposing V reads, right behind the last QK^T MFMA (inline asm: see att5_load_v)
             u32x4 vf[4][2];
             att8_load_v(vf, vs, vb);
-            att8_softmax<T, NQB>(S, O, negm, l, pf, t == 0);
+            att8_softmax<T, NQB, LSUM>(S, O, negm, l, pf, t == 0, L);
             att8_wait_v(vf);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -974,6 +985,13 @@ __global__ __launch_bounds__(256, WPS) void attention8_kernel(const uint16_t* __
 #pragma unroll
                     for (int qb = 0; qb < NQB; ++qb)
                         O[db][qb] = T::mfma16(__builtin_bit_cast(typename T::v8, vf[db][j]), pf[qb][j], O[db][qb]);
+            if constexpr (LSUM) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int qb = 0; qb < NQB; ++qb)
+                        L[qb] = T::mfma16(__builtin_bit_cast(typename T::v8, ones_rows), pf[qb][j], L[qb]);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMAs of step t+1 have landed
         __syncthreads();
@@ -1001,6 +1019,7 @@ __global__ __launch_bounds__(256, WPS) void attention8_kernel(const uint16_t* __
         }
         sp += __shfl_xor(sp, 16, 64);
         const float sc = sp + __shfl_xor(sp, 32, 64);
+        if constexpr (LSUM) l[qb] = L[qb][0];                // lanes g4 == 0: the row sum; the others: 0
         const float m = -negm[qb][0];
         const float m_new = fmaxf(m, sc);
         const float alpha = __builtin_amdgcn_exp2f(m - m_new);
@@ -1041,7 +1060,8 @@ static int attention_variant() {
 }
 
 // Variants (env PIGEON_ATTN_VARIANT): 21 (default, the only one in the product library) v8 = v6's structure on v_mfma_f32_16x16x32
-// (attention8_kernel, 32 queries per wave); 19 = v8 with 64 queries per wave (A/B arm); 11 v6 (round 2's product) = K and V by DMA,
+// (attention8_kernel, 32 queries per wave, row sums out of the matrix pipe); 20 = the same with v_dot2c row sums, 19 = 64 queries
+// per wave (A/B arms); 11 v6 (round 2's product) = K and V by DMA,
 // transposing LDS reads, single-key tail, lazy softmax on 32x32x16 MFMAs;
 // 13 the same with the v5 softmax (running maximum updated every tile, packed fp32 ops); 12 = 13 with a masked tenth key
 // tile instead of the tail (A/B arms); 14 / 15 timing-only ablations of 11 (no DMA in the loop / no per-tile barrier); 4 / 10 v4 register-staged / K by DMA;
@@ -1081,6 +1101,7 @@ int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hip
         case 15: return att_launch2(dtype, attention5_kernel<T_F16, 3, true, true, 2>, attention5_kernel<T_BF16, 3, true, true, 2>, grid, qkv, out, s);
         case 13: return att_launch2(dtype, attention5_kernel<T_F16, 3, true, false>, attention5_kernel<T_BF16, 3, true, false>, grid, qkv, out, s);
         case 19: return att_launch3(dtype, attention8_kernel<T_F16, 4, 2, 2>, attention8_kernel<T_BF16, 4, 2, 2>, grid, 128, qkv, out, s);
+        case 20: return att_launch3(dtype, attention8_kernel<T_F16, 2, 4, 3, false>, attention8_kernel<T_BF16, 2, 4, 3, false>, grid, 256, qkv, out, s);
         case 11: return att_launch2(dtype, attention5_kernel<T_F16, 3>, attention5_kernel<T_BF16, 3>, grid, qkv, out, s);
         default: break;
     }
@@ -1089,5 +1110,5 @@ int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hip
         pg_set_error("attention: PIGEON_ATTN_VARIANT=%d is not part of this build (product: 21; others need -DPIGEON_ABLATIONS)", variant);
         return PG_EINVAL;
     }
-    return att_launch3(dtype, attention8_kernel<T_F16, 2, 4, 3>, attention8_kernel<T_BF16, 2, 4, 3>, grid, 256, qkv, out, s);
+    return att_launch3(dtype, attention8_kernel<T_F16, 2, 4, 3, true>, attention8_kernel<T_BF16, 2, 4, 3, true>, grid, 256, qkv, out, s);
 }
