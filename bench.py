@@ -230,42 +230,50 @@ def cpu_reference_module(args, vit_sd, px_images, threads, port_emb):
             "embedding_rel_err_vs_port": orc.rel_err(port_emb[:n], emb)}
 
 
+def flip_analysis(ref_logits, hip_logits, hip_cell, where):
+    """Pure part of the parity leg (CPU-testable): per panorama the reference's top-1 / top-2 logit margin, the HIP - reference
+    deltas of those two logits and the flip flag.  A flip is EXPLAINED only if the reference margin is below twice the largest
+    logit error measured anywhere in the sample (the margin itself moves by at most |d_top1| + |d_top2|)."""
+    import torch
+    ref_logits, hip_logits = ref_logits.double(), hip_logits.double()
+    top2 = torch.topk(ref_logits, 2, dim=-1)
+    margin = top2.values[:, 0] - top2.values[:, 1]
+    delta = hip_logits - ref_logits
+    err_max = float(delta.abs().max())
+    flips = hip_cell != top2.indices[:, 0]
+    rows = []
+    for i in range(ref_logits.shape[0]):
+        c1, c2 = int(top2.indices[i, 0]), int(top2.indices[i, 1])
+        rows.append({"panorama": where[i], "oracle_cell": c1, "hip_cell": int(hip_cell[i]), "flip": bool(flips[i]),
+                     "oracle_margin": round(float(margin[i]), 5), "d_top1": round(float(delta[i, c1]), 5),
+                     "d_top2": round(float(delta[i, c2]), 5)})
+    unexplained = [r for r in rows if r["flip"] and r["oracle_margin"] >= 2 * err_max]
+    return {"logit_abs_err_max": err_max, "logit_sigma": float(ref_logits.std()),
+            "oracle_margin_min": float(margin.min()), "oracle_margin_median": float(margin.median()),
+            "flips": int(flips.sum()), "flips_unexplained": len(unexplained),
+            "flip_rule": "a flip is explained only if the oracle's top-1/top-2 logit margin is below 2 x logit_abs_err_max "
+                         "(the margin moves by at most |d_top1| + |d_top2|)",
+            "geocell_argmax_equal": bool(not flips.any()),
+            "flipped": [r for r in rows if r["flip"]],
+            "smallest_margins": sorted(rows, key=lambda r: r["oracle_margin"])[:4]}, flips
+
+
 def parity_report(args, dev, model, o, refined, hip):
     """The oracle's answer from the PIXELS against this run's outputs for the same panoramas."""
     import torch
     from oracle import pigeon_oracle as orc
     from pigeon_amd import hip_ops
     n = o["embedding"].shape[0]
-    ref_logits = o["logits"].double()
     # the product head kernel on this run's embeddings: the logits the step's argmax was taken from
     ho = hip_ops.head_forward(hip["embedding"].to(dev).contiguous(), model.cell_layer.weight.data, model.cell_layer.bias.data,
                               model.lla_geocells.data, args.topk)
-    hip_logits = ho["logits"].cpu().double()
     assert torch.equal(ho["preds_geocell"].cpu(), hip["preds_geocell"].cpu()), "head is not batch-position independent"
-    top2 = torch.topk(ref_logits, 2, dim=-1)
-    margin = (top2.values[:, 0] - top2.values[:, 1])
-    delta = hip_logits - ref_logits
-    err_max = float(delta.abs().max())
-    hip_cell = hip["preds_geocell"].cpu()
-    flips = (hip_cell != o["preds_geocell"])
-    rows = []
-    for i in range(n):
-        c1, c2 = int(top2.indices[i, 0]), int(top2.indices[i, 1])
-        rows.append({"panorama": hip["where"][i], "oracle_cell": c1, "hip_cell": int(hip_cell[i]), "flip": bool(flips[i]),
-                     "oracle_margin": round(float(margin[i]), 5), "d_top1": round(float(delta[i, c1]), 5),
-                     "d_top2": round(float(delta[i, c2]), 5)})
-    unexplained = [r for r in rows if r["flip"] and r["oracle_margin"] >= 2 * err_max]
+    fa, flips = flip_analysis(o["logits"], ho["logits"].cpu(), hip["preds_geocell"].cpu(), hip["where"])
+    assert torch.equal(torch.topk(o["logits"], 1, dim=-1).indices[:, 0], o["preds_geocell"])
     rep = {"n_panoramas": n, "from": "pixels (oracle ViT fp32 on the host) vs this run's step outputs",
            "embedding_rel_err": orc.rel_err(hip["embedding"].cpu(), o["embedding"]),
-           "embedding_rel_err_worst_image": orc.max_rel_err_rows(hip["embedding"].cpu().reshape(-1, 1024), o["embedding"].reshape(-1, 1024)),
-           "logit_abs_err_max": err_max, "logit_sigma": float(ref_logits.std()),
-           "oracle_margin_min": float(margin.min()), "oracle_margin_median": float(margin.median()),
-           "flips": int(flips.sum()), "flips_unexplained": len(unexplained),
-           "flip_rule": "a flip is explained only if the oracle's top-1/top-2 logit margin is below 2 x logit_abs_err_max "
-                        "(the margin moves by at most |d_top1| + |d_top2|)",
-           "geocell_argmax_equal": bool(not flips.any()),
-           "flipped": [r for r in rows if r["flip"]],
-           "smallest_margins": sorted(rows, key=lambda r: r["oracle_margin"])[:4]}
+           "embedding_rel_err_worst_image": orc.max_rel_err_rows(hip["embedding"].cpu().reshape(-1, 1024), o["embedding"].reshape(-1, 1024))}
+    rep.update(fa)
     if refined is not None and "refined_geocell" in hip:
         r_llh, r_cell, _ = refined
         keep = ~flips

@@ -76,3 +76,27 @@ def test_bench_self_launch_propagates_a_rank_failure():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--panoramas", "6", "--cells", "3",
                         "--topk", "5"], capture_output=True, text=True, timeout=300, env=_env())   # topk > cells: torch.topk raises
     assert p.returncode != 0
+
+
+def test_flip_analysis_rule():
+    """The rule bench.py's parity leg applies (pure function, no GPU): a top-1 flip is explained only below 2 x the measured
+    logit error."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    ref = torch.zeros((3, 6))
+    ref[0, 2], ref[0, 4] = 5.0, 4.99          # panorama 0: near-tie, margin 0.01
+    ref[1, 1], ref[1, 3] = 5.0, 3.0           # panorama 1: clear winner
+    ref[2, 0], ref[2, 5] = 5.0, 4.0           # panorama 2: margin 1.0
+    hip = ref.clone()
+    hip[0, 4] += 0.02                          # flips the near-tie: |delta| = 0.02 -> bound 0.04 > margin 0.01: explained
+    hip[1, 1] -= 0.015
+    r, flips = bench.flip_analysis(ref, hip, torch.tensor([4, 1, 0]), ["a", "b", "c"])
+    assert r["flips"] == 1 and r["flips_unexplained"] == 0 and flips.tolist() == [True, False, False]
+    assert abs(r["logit_abs_err_max"] - 0.02) < 1e-6 and r["flipped"][0]["panorama"] == "a" and abs(r["flipped"][0]["d_top2"] - 0.02) < 1e-6
+    assert r["geocell_argmax_equal"] is False and r["smallest_margins"][0]["panorama"] == "a"
+    # the same error but a flip where the reference margin is 1.0: NOT explained (a bug, not a near-tie)
+    r2, _ = bench.flip_analysis(ref, hip, torch.tensor([4, 1, 5]), ["a", "b", "c"])
+    assert r2["flips"] == 2 and r2["flips_unexplained"] == 1
+    r3, _ = bench.flip_analysis(ref, ref, torch.tensor([2, 1, 0]), ["a", "b", "c"])
+    assert r3["flips"] == 0 and r3["geocell_argmax_equal"] is True and r3["logit_abs_err_max"] == 0.0
