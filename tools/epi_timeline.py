@@ -48,6 +48,17 @@ for name in which:
     print(f"== {name}: N={N} K={K} {kind}; us relative to the tile start of wave 0; tiles 4..7 of blocks 0 and 100")
     print("  start of block 100's tile minus block 0's (us), tiles 0..9: " + " ".join(f"{(t[1, i, 0, 0] - t[0, i, 0, 0]):6.1f}" for i in range(10)))
     print("  tile period of block 0 (us), tiles 0..9: " + " ".join(f"{(t[0, i + 1, 0, 0] - t[0, i, 0, 0]):6.1f}" for i in range(10)))
+    # one line for sweeps (PIGEON_GEMM_BLOCKS=n caps the persistent grid: fewer CUs share HBM / the fabric -- does a tile's epilogue
+    # get shorter?): block 0, mean over tiles 4..11
+    its = range(4, 12)
+    ml = sum(float(t[0, i, 0, 1] - t[0, i, 0, 0]) for i in its) / 8
+    ea = sum(float(t[0, i, 0, 9] - t[0, i, 0, 1]) for i in its) / 8
+    eb = sum(float(t[0, i, 4, 9] - t[0, i, 4, 1]) for i in its) / 8
+    per = sum(float(t[0, i + 1, 0, 0] - t[0, i, 0, 0]) for i in its) / 8
+    print(f"SUMMARY {name} blocks={os.environ.get('PIGEON_GEMM_BLOCKS', 'all')}: mainloop {ml:6.1f} us  epilogue waves 0-3 {ea:5.1f}  waves 4-7 {eb:5.1f}  tile period {per:6.1f}")
+    if os.environ.get("EPI_TIMELINE_SUMMARY_ONLY"):
+        del A, W
+        continue
     for blk in (0, 1):
         for it in (4, 5, 6, 7):
             t0 = t[blk, it, 0, 0]
