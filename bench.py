@@ -465,11 +465,21 @@ def _dry_stubs(args):
 
 # ------------------------------------------------------------------------------------------------------ worker
 def worker(args):
+    from pigeon_amd import distributed
+    comm = distributed.init_from_env()               # control plane (gloo); the data-path collective is RCCL through the C ABI
+    try:
+        _worker(args, comm)
+    finally:
+        # every rank, on every way out: RCCL communicator and the gloo group are torn down explicitly (a gloo group alive at
+        # interpreter exit aborts the process -- a finished rank would then fail its launcher)
+        comm.close()
+
+
+def _worker(args, comm):
     import torch
     from pigeon_amd import distributed
     from pigeon_amd.evaluate import PanoramaPipeline
 
-    comm = distributed.init_from_env()               # control plane (gloo); the data-path collective is RCCL through the C ABI
     rank, world = comm.rank, comm.world_size
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: either leave WORLD_SIZE unset (bench.py then starts "
@@ -595,6 +605,12 @@ def worker(args):
     if not complete:
         raise SystemExit(f"rank {rank}: gathered batch is incomplete: {gathered}")
 
+    # All collectives are behind us.  Every rank tears its RCCL communicator and the control-plane group down HERE, together,
+    # right after a barrier (ncclCommDestroy wants all ranks of a node; a gloo group alive at interpreter exit aborts the
+    # process); rank 0 then goes on alone with the roofline / CPU-baseline / parity legs.
+    rccl_ranks = comm.rccl_ranks()
+    comm.barrier()
+    comm.close()
     if rank != 0:
         return
     images_per_step = args.panoramas * 4 * world
@@ -653,7 +669,7 @@ def worker(args):
     result["kernels"] = kernels
     result["fp16_range_alarm_rows"] = enc.range_alarm_read()       # always-on: residual rows that came near the fp16 limit (0 = none)
     if world > 1:
-        result["rccl"] = {"nranks": comm.rccl_ranks(), "version": _lib.load().pg_comm_rccl_version(),
+        result["rccl"] = {"nranks": rccl_ranks, "version": _lib.load().pg_comm_rccl_version(),
                           "collective": "pg_allgather_many (C ABI, csrc/comm.hip): 5 buffers before refinement + 2 after, one grouped launch each"}
     if refiner is not None and pipe.refine_events:
         ms = [a.elapsed_time(b_) for a, b_ in pipe.refine_events]

@@ -27,7 +27,6 @@ from __future__ import annotations
 from collections import namedtuple
 from typing import Dict, Optional
 
-import numpy as np
 import torch
 import torch.nn.functional as F
 

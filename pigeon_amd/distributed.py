@@ -38,6 +38,7 @@ class Communicator:
             self.rank, self.world_size = 0, 1
         self._rccl = None          # pg_comm handle (ctypes void*)
         self._rccl_device = None
+        self._owns_group = False   # set by init_from_env: close() then also tears the control-plane group down
 
     @property
     def is_main_process(self) -> bool:
@@ -77,10 +78,17 @@ class Communicator:
         return int(n.value)
 
     def close(self):
+        """Release the RCCL communicator and, if init_from_env created it, the control-plane process group.  Call it on EVERY
+        rank before the process exits: a gloo group that is still alive when the interpreter unwinds takes the process down
+        with `terminate called without an active exception` (its worker threads are still joinable) -- a rank that computed
+        everything correctly then exits non-zero and fails its launcher."""
         if self._rccl is not None:
             from . import _lib
             _lib.load().pg_comm_destroy(self._rccl)
             self._rccl = None
+        if self._owns_group and dist.is_available() and dist.is_initialized():
+            self._owns_group = False
+            dist.destroy_process_group()
 
     def gather(self, t: torch.Tensor) -> torch.Tensor:
         """accelerate.Accelerator.gather: (n, ...) on every rank -> (world*n, ...) rank-major, on every rank."""
@@ -139,6 +147,9 @@ def init_from_env(backend: Optional[str] = None) -> Communicator:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend or "gloo")
+        comm = Communicator()
+        comm._owns_group = True
+        return comm
     return Communicator()
 
 

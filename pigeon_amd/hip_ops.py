@@ -5,7 +5,6 @@ from __future__ import annotations
 import ctypes as C
 from typing import Dict, Optional
 
-import numpy as np
 import torch
 
 from . import _lib

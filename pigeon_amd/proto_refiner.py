@@ -9,7 +9,7 @@ models/README.md:11) and raises.
 from __future__ import annotations
 
 import json
-from typing import List, Optional
+from typing import List
 
 import numpy as np
 import torch

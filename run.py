@@ -86,8 +86,16 @@ def main():
     if args.function in ('pretrain', 'finetune'):
         raise NotImplementedError(f'Mode {args.function} is training and not part of the MI355X inference hot path.')
 
-    from pigeon_amd import distributed, synthetic
+    from pigeon_amd import distributed
     comm = distributed.init_from_env()
+    try:
+        return _dispatch(args, comm)
+    finally:
+        comm.close()           # every rank: RCCL communicator + control-plane group, before the interpreter unwinds
+
+
+def _dispatch(args, comm):
+    from pigeon_amd import synthetic
     dev = f'cuda:{int(os.environ.get("LOCAL_RANK", "0"))}'
     torch.cuda.set_device(dev)
 

@@ -125,7 +125,9 @@ def _worker(rank, world, port, outdir):
         raise AssertionError("mixed-device gather_many must raise")
     except ValueError:
         pass
-    torch.distributed.destroy_process_group()
+    comm.close()                                  # tears down the gloo group init_from_env created (idempotent)
+    comm.close()
+    assert not torch.distributed.is_initialized()
 
 
 def test_two_rank_gather_and_embed_loop(tmp_path):

@@ -159,7 +159,7 @@ def test_load_refiner_cache_reads_the_references_pickle(tmp_path):
     reads `torch.load(...).protos` back.  Written here by the reference's OWN class exactly that way; read back without the
     reference package importable (the loader must not need `models.proto_refiner`), converted to the CSR bank."""
     import types
-    from pigeon_amd.proto_refiner import ProtoRefiner, bank_from_protos, load_refiner_cache
+    from pigeon_amd.proto_refiner import bank_from_protos, load_refiner_cache
     C = 24
     bank = synthetic.make_bank(C, 5, seed=3, empty_frac=0.1)
     proto_csv = os.path.join(str(tmp_path), "protos.csv")
