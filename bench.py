@@ -467,12 +467,15 @@ def _dry_stubs(args):
 def worker(args):
     from pigeon_amd import distributed
     comm = distributed.init_from_env()               # control plane (gloo); the data-path collective is RCCL through the C ABI
+    # every rank, on every way out: the gloo group is torn down explicitly (alive at interpreter exit it aborts the process --
+    # a finished rank would then fail its launcher); the RCCL communicator only on the regular way out (_worker does it after
+    # its last barrier), a failing rank abandons it
     try:
         _worker(args, comm)
-    finally:
-        # every rank, on every way out: RCCL communicator and the gloo group are torn down explicitly (a gloo group alive at
-        # interpreter exit aborts the process -- a finished rank would then fail its launcher)
-        comm.close()
+    except BaseException:
+        comm.close(rccl=False)
+        raise
+    comm.close()
 
 
 def _worker(args, comm):

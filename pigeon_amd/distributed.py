@@ -77,14 +77,17 @@ class Communicator:
         _lib.check(_lib.load().pg_comm_count(self._rccl, C.byref(n)), "pg_comm_count")
         return int(n.value)
 
-    def close(self):
+    def close(self, rccl: bool = True):
         """Release the RCCL communicator and, if init_from_env created it, the control-plane process group.  Call it on EVERY
         rank before the process exits: a gloo group that is still alive when the interpreter unwinds takes the process down
         with `terminate called without an active exception` (its worker threads are still joinable) -- a rank that computed
-        everything correctly then exits non-zero and fails its launcher."""
+        everything correctly then exits non-zero and fails its launcher.
+        rccl=False (a rank on its way out with an exception): the RCCL communicator is abandoned, not destroyed --
+        ncclCommDestroy expects the other ranks of the node, which may be sitting in a collective this rank will never join."""
         if self._rccl is not None:
-            from . import _lib
-            _lib.load().pg_comm_destroy(self._rccl)
+            if rccl:
+                from . import _lib
+                _lib.load().pg_comm_destroy(self._rccl)
             self._rccl = None
         if self._owns_group and dist.is_available() and dist.is_initialized():
             self._owns_group = False

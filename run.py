@@ -89,9 +89,13 @@ def main():
     from pigeon_amd import distributed
     comm = distributed.init_from_env()
     try:
-        return _dispatch(args, comm)
-    finally:
-        comm.close()           # every rank: RCCL communicator + control-plane group, before the interpreter unwinds
+        res = _dispatch(args, comm)
+    except BaseException:
+        comm.close(rccl=False)  # a failing rank abandons its RCCL communicator (the others may sit in a collective)
+        raise
+    comm.barrier()
+    comm.close()               # every rank: RCCL communicator + control-plane group, before the interpreter unwinds
+    return res
 
 
 def _dispatch(args, comm):
