@@ -466,7 +466,8 @@ def _dry_stubs(args):
 # ------------------------------------------------------------------------------------------------------ worker
 def worker(args):
     from pigeon_amd import distributed
-    comm = distributed.init_from_env()               # control plane (gloo); the data-path collective is RCCL through the C ABI
+    # control plane (gloo); the data-path collective is RCCL through the C ABI.  --dry-run never touches a GPU, also on a GPU box
+    comm = distributed.init_from_env(set_device=not args.dry_run)
     # every rank, on every way out: the gloo group is torn down explicitly (alive at interpreter exit it aborts the process --
     # a finished rank would then fail its launcher); the RCCL communicator only on the regular way out (_worker does it after
     # its last barrier), a failing rank abandons it

@@ -140,12 +140,16 @@ class Communicator:
     wait_for_everyone = barrier
 
 
-def init_from_env(backend: Optional[str] = None) -> Communicator:
+def init_from_env(backend: Optional[str] = None, set_device: bool = True) -> Communicator:
     """Initialise the control-plane process group from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun's env);
-    no-op for a single process.  Default backend "gloo": the data path does not use it (see Communicator)."""
+    no-op for a single process.  Default backend "gloo": the data path does not use it (see Communicator).
+    set_device=False: do not bind this process to cuda:LOCAL_RANK (host-only runs: the CPU tests, `bench.py --dry-run`)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if torch.cuda.is_available():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    if set_device and torch.cuda.is_available():
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if local >= torch.cuda.device_count():
+            raise RuntimeError(f"LOCAL_RANK {local} but this node has {torch.cuda.device_count()} GPU(s): one process per GPU")
+        torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

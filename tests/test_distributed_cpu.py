@@ -26,7 +26,7 @@ def _worker(rank, world, port, outdir):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank))
     from pigeon_amd import distributed
     from pigeon_amd.embed import compute_embeddings
-    comm = distributed.init_from_env("gloo")
+    comm = distributed.init_from_env("gloo", set_device=False)     # host-only, also when the box has a GPU
     assert (comm.rank, comm.world_size) == (rank, world)
     # --- gather: rank-major concat, identical on every rank
     t = torch.arange(6, dtype=torch.float32).view(3, 2) + 100 * rank
