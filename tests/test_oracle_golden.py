@@ -121,17 +121,21 @@ def test_geo_oracle_matches_reference_functions(golden_dir):
     from oracle import geo_oracle
     g = _load(golden_dir, "geo.npz")
     x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
-    assert np.array_equal(geo_oracle.haversine_matrix(x, y.t()).numpy(), g["matrix_f64"])
+    # fp64: equal to the reference's output up to the last ulps of sin / cos / asin -- torch's CPU kernels pick their vector
+    # width by the CPU (bit-identical on the authoring box, 1e-13-level differences on an AVX-512 one); 1e-6 km = 1 mm
+    np.testing.assert_allclose(geo_oracle.haversine_matrix(x, y.t()).numpy(), g["matrix_f64"], rtol=1e-11, atol=1e-6)
     # fp32 points: torch's CPU cos is vectorised (Sleef) on full vectors and scalar on chunk tails, so the last ulp of
     # cos(lat) depends on the thread partition; one fp32 ulp of cos(lat) moves near-antipodal distances by up to 0.2 km
     np.testing.assert_allclose(geo_oracle.haversine_matrix(x.float(), y.t()).numpy(), g["matrix_f32x"], rtol=3e-5, atol=0.5)
     n = x.shape[0]
     np.testing.assert_allclose(geo_oracle.haversine(x, y[:n].float()).numpy(), g["pairs_f32y"], rtol=3e-5, atol=0.5)
-    assert np.array_equal(geo_oracle.haversine(x, y[:n]).numpy(), g["pairs_f64y"])
-    assert np.array_equal(geo_oracle.smooth_labels(torch.from_numpy(g["smooth_in"]), float(g["smooth_constant"])).numpy(), g["smooth_out"])
+    np.testing.assert_allclose(geo_oracle.haversine(x, y[:n]).numpy(), g["pairs_f64y"], rtol=1e-11, atol=1e-6)
+    sm = geo_oracle.smooth_labels(torch.from_numpy(g["smooth_in"]), float(g["smooth_constant"])).numpy()
+    assert sm.dtype == g["smooth_out"].dtype
+    np.testing.assert_allclose(sm, g["smooth_out"], rtol=1e-6 if sm.dtype == np.float32 else 1e-12, atol=0)   # exp: last ulps by CPU
     m = geo_oracle.geoguessr_metrics(g["metric_preds"], g["metric_labels"], g["metric_cell_preds"], g["metric_cell_labels"], g["metric_top5"])
     for k, v in zip([str(s) for s in g["metric_names"]], g["metric_values"]):
-        assert float(m[k]) == float(v), k
+        assert abs(float(m[k]) - float(v)) <= 1e-9 * max(1.0, abs(float(v))), k      # means of fp64 haversines: last ulps by CPU
 
 
 def test_vit24_trained_regime_matches_reference(golden_dir):
@@ -182,7 +186,8 @@ def test_pipeline24_wide_head_and_refine_match_reference(golden_dir, tmp_path):
     assert np.array_equal(o["topk"].indices.numpy(), g["topk_indices"])
     top8 = torch.topk(o["logits"], 8, dim=-1)
     assert np.array_equal(top8.indices.numpy(), g["top8_cells"])
-    np.testing.assert_allclose(top8.values.numpy(), g["top8_logits"], rtol=0, atol=2e-5)      # fp32 GEMV order on another thread count
+    # fp32 GEMV over K = 1024 at |logit| ~ 17: the summation order depends on thread count and vector width (5e-5 seen on AVX-512)
+    np.testing.assert_allclose(top8.values.numpy(), g["top8_logits"], rtol=0, atol=2e-4)
     margin = g["logit_margin"]
     assert len(set(g["preds_geocell"].tolist())) >= 100 and margin.min() > 0 and (margin < 0.03).sum() >= 2   # honest near-ties inside
     bank = synthetic.make_bank(C, ppc, seed=bseed, empty_frac=0.01, max_members=maxm, center=g["center"], radius=float(g["radius"]))
