@@ -80,7 +80,9 @@ int pg_vit_finalize(pg_vit* h);
 /* Bytes of DEVICE workspace pg_vit_forward needs for n_images (caller allocates, e.g. a torch uint8 tensor). */
 int pg_vit_workspace_bytes(const pg_vit* h, int n_images, size_t* bytes);
 /* pixels: DEVICE (n_images,3,336,336) contiguous NCHW, fp32 (PG_DTYPE_F32), fp16 (what pg_prep_forward writes) or bf16.
- * emb_out: DEVICE (n_images,1024) fp32 -- mean over the 577 tokens of last_hidden_state. */
+ * emb_out: DEVICE (n_images,1024) fp32 -- mean over the 577 tokens of last_hidden_state.
+ * n_images = 0 is a no-op (PG_OK; the buffers of an empty batch may be NULL), n_images < 0 is PG_EINVAL -- the same holds for
+ * pg_prep_forward, pg_head_forward (B) and pg_refine_forward (B). */
 int pg_vit_forward(pg_vit* h, const void* pixels, int pix_dtype, int n_images, float* emb_out,
                    void* workspace, size_t workspace_bytes, void* stream);
 /* Same, additionally copying the final residual stream (n_images,577,1024) fp32 to `hidden_out` (DEVICE,

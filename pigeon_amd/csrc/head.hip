@@ -149,7 +149,8 @@ extern "C" int pg_head_forward(const float* emb, int B, int P, const float* W, c
                                const double* centroids, int C, int k, float* logits, float* topk_val,
                                int64_t* topk_idx, int64_t* argmax, double* pred_llh, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (B <= 0) return PG_OK;
+    if (B < 0) { pg_set_error("head: B = %d", B); return PG_EINVAL; }
+    if (B == 0) return PG_OK;                              // an empty batch is a no-op: its (empty) buffers may be NULL
     if (!emb || !W || !bias || !centroids || !logits || !topk_val || !topk_idx || !argmax || !pred_llh) {
         pg_set_error("head: null pointer argument"); return PG_EINVAL;
     }

@@ -218,8 +218,10 @@ __global__ __launch_bounds__(384) void prep_v_kernel(const uint8_t* __restrict__
 
 extern "C" int pg_prep_forward(pg_prep* h, const void* images_u8, int n_images, void* out, int out_dtype, void* workspace,
                                size_t workspace_bytes, void* stream) {
-    if (!h || !images_u8 || !out || !workspace) { pg_set_error("prep_forward: null argument"); return PG_EINVAL; }
-    if (n_images <= 0) return PG_OK;
+    if (!h) { pg_set_error("prep_forward: null handle"); return PG_EINVAL; }
+    if (n_images < 0) { pg_set_error("prep_forward: n_images = %d", n_images); return PG_EINVAL; }
+    if (n_images == 0) return PG_OK;                       // an empty batch is a no-op: its (empty) buffers may be NULL
+    if (!images_u8 || !out || !workspace) { pg_set_error("prep_forward: null argument"); return PG_EINVAL; }
     if (out_dtype != PG_DTYPE_F32 && out_dtype != PG_DTYPE_F16) { pg_set_error("prep_forward: out dtype must be F32 or F16"); return PG_EINVAL; }
     size_t need = 0;
     pg_prep_workspace_bytes(h, n_images, &need);

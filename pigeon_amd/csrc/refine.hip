@@ -232,7 +232,8 @@ extern "C" int pg_refine_forward(const pg_bank* bank, const float* q, int B, int
                                  double max_refine_km, float* scratch, float* out_llh, int64_t* out_cell,
                                  int32_t* out_choice, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (B <= 0) return PG_OK;
+    if (B < 0) { pg_set_error("refine: B = %d", B); return PG_EINVAL; }
+    if (B == 0) return PG_OK;                              // an empty batch is a no-op: its (empty) buffers may be NULL
     if (!bank || !q || !init_llh || !cand || !scratch || !out_llh || !out_cell || !out_choice) {
         pg_set_error("refine: null pointer argument"); return PG_EINVAL;
     }

@@ -507,9 +507,11 @@ static int vit_forward_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n
 
 extern "C" int pg_vit_forward_hidden(pg_vit* h, const void* pixels, int pix_dtype, int n_images, float* emb_out,
                                      float* hidden_out, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!h || !pixels || !emb_out || !workspace) { pg_set_error("vit_forward: null argument"); return PG_EINVAL; }
+    if (!h) { pg_set_error("vit_forward: null handle"); return PG_EINVAL; }
     if (!h->finalized) { pg_set_error("vit_forward: handle not finalized"); return PG_ESTATE; }
-    if (n_images <= 0) return PG_OK;
+    if (n_images < 0) { pg_set_error("vit_forward: n_images = %d", n_images); return PG_EINVAL; }
+    if (n_images == 0) return PG_OK;                       // an empty batch is a no-op: its (empty) buffers may be NULL
+    if (!pixels || !emb_out || !workspace) { pg_set_error("vit_forward: null argument"); return PG_EINVAL; }
     if (pix_dtype != PG_DTYPE_F32 && pix_dtype != PG_DTYPE_BF16 && pix_dtype != PG_DTYPE_F16) { pg_set_error("vit_forward: bad pixel dtype"); return PG_EINVAL; }
     size_t needb = 0;
     pg_vit_workspace_bytes(h, n_images, &needb);

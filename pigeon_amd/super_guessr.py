@@ -154,7 +154,7 @@ class SuperGuessr(nn.Module):
                     pixel_values = pixel_values.squeeze(1)                      # :392-393
                 embedding = self._encoder().embed(pixel_values.to(dev))         # :395-398 (ViT + token mean)
                 if self.panorama:
-                    embedding = embedding.reshape((num_samples, 4, -1))         # :404-405
+                    embedding = embedding.reshape((num_samples, 4, embedding.shape[-1]))   # :404-405 (explicit width: B = 0 stays legal)
             else:
                 embedding = embedding.to(dev, torch.float32).contiguous()
 

@@ -479,6 +479,45 @@ def test_refiner_3d_embedding_no_probs_and_assert(env, golden_dir):
         ref(emb.to(DEV), initial_preds=torch.zeros(48, 2, dtype=torch.float64), candidate_cells=torch.zeros((48, 3), dtype=torch.long))
 
 
+def test_empty_and_single_sample_batches(env, vit2, golden_dir, tmp_path):
+    """Edge of the batch dimension through the class surface: B = 0 (a rank whose shard is empty must still be able to step) returns
+    correctly-shaped empty tensors from the encoder, the head and the refiner without touching the GPU kernels' grids; B = 1 (the
+    serving case, one panorama) equals row 0 of the same inputs run as a batch.  (The reference returns empties for B = 0 as well,
+    except that its panorama reshape `(B, 4, -1)` is ambiguous for an empty tensor, super_guessr.py:404-405; here the width is explicit.)"""
+    from pigeon_amd.proto_refiner import ProtoRefiner
+    from pigeon_amd.super_guessr import SuperGuessr
+    sd, base = vit2
+    C = 120
+    model = SuperGuessr(base, panorama=True, freeze_base=True, num_candidates=5, geocell_path=_geocells_csv(tmp_path, C)).to(DEV).eval()
+    g = _gold(golden_dir, "refine.npz")
+    ref = ProtoRefiner(topk=5, bank=_bank(env, g)).eval()
+    with torch.no_grad():
+        # B = 0
+        e0 = base.embed(torch.zeros((0, 3, 336, 336), device=DEV)) if hasattr(base, "embed") else None
+        if e0 is not None:
+            assert tuple(e0.shape) == (0, 1024)
+        o0 = model(pixel_values=torch.zeros((0, 12, 336, 336), device=DEV), labels=torch.zeros((0, 2), dtype=torch.float64, device=DEV),
+                   labels_clf=torch.zeros((0,), dtype=torch.long, device=DEV))
+        assert tuple(o0.embedding.shape) == (0, 4, 1024) and tuple(o0.preds_LLH.shape) == (0, 2) and o0.preds_LLH.dtype == torch.float64
+        assert tuple(o0.preds_geocell.shape) == (0,) and tuple(o0.top5_geocells.indices.shape) == (0, 5)
+        _, l0, c0 = ref(torch.zeros((0, 1024), device=DEV), initial_preds=torch.zeros((0, 2), dtype=torch.float64, device=DEV),
+                        candidate_cells=torch.zeros((0, 5), dtype=torch.long, device=DEV),
+                        candidate_probs=torch.zeros((0, 5), device=DEV), quiet=True)
+        assert tuple(l0.shape) == (0, 2) and l0.dtype == torch.float32 and tuple(c0.shape) == (0,) and c0.dtype == torch.long
+        # B = 1 against the same sample inside a batch of 3
+        px = env["syn"].make_pixels(12, seed=77).view(3, 12, 336, 336).to(DEV)
+        lab = dict(labels=torch.zeros((3, 2), dtype=torch.float64, device=DEV), labels_clf=torch.zeros((3,), dtype=torch.long, device=DEV))
+        o3 = model(pixel_values=px, **lab)
+        o1 = model(pixel_values=px[:1], labels=lab["labels"][:1], labels_clf=lab["labels_clf"][:1])
+        assert torch.equal(o1.embedding, o3.embedding[:1]) and torch.equal(o1.preds_geocell, o3.preds_geocell[:1])
+        assert torch.equal(o1.top5_geocells.indices, o3.top5_geocells.indices[:1]) and torch.equal(o1.preds_LLH, o3.preds_LLH[:1])
+        emb = torch.from_numpy(g["embedding"]).to(DEV)
+        args = lambda sl: dict(initial_preds=torch.from_numpy(g["initial_preds"]).to(DEV)[sl], candidate_cells=torch.from_numpy(g["candidate_cells"]).to(DEV)[sl],
+                               candidate_probs=torch.from_numpy(g["candidate_probs"]).to(DEV)[sl], quiet=True)
+        _, l1, c1 = ref(emb[:1], **args(slice(0, 1)))
+        assert np.array_equal(c1.cpu().numpy(), g["default_cell"][:1]) and np.array_equal(l1.cpu().numpy(), g["default_LLH"][:1])
+
+
 def test_refiner_built_from_reference_files(env, golden_dir, tmp_path):
     """ProtoRefiner(proto_path=CSV, dataset_path=HF dataset dir): the reference's own on-disk inputs."""
     from pigeon_amd.proto_refiner import ProtoRefiner
