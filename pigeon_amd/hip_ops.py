@@ -42,6 +42,15 @@ def _dev(t: torch.Tensor, dtype=None) -> torch.Tensor:
     return t
 
 
+def _shape(t: torch.Tensor, name: str, *dims):
+    """The C ABI takes pointers plus a few sizes; every other extent is implied.  Refuse a tensor whose shape is not the implied
+    one (None = any extent) instead of letting a kernel read past its end."""
+    if t.dim() != len(dims) or any(d is not None and int(s) != int(d) for s, d in zip(t.shape, dims)):
+        want = "(" + ",".join("*" if d is None else str(int(d)) for d in dims) + ")"
+        raise _lib.PigeonHipError(f"{name} must have shape {want}, got {tuple(t.shape)}")
+    return t
+
+
 # ----------------------------------------------------------------------------------------- building blocks
 def gemm16(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epi: int,
            qscale: float = 1.0, qcols: int = 0, aux: Optional[torch.Tensor] = None, variant: int = 0,
@@ -361,9 +370,15 @@ class VitEncoder:
 def head_forward(emb: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, centroids: torch.Tensor, k: int):
     """emb (B,P,1024) or (B,1024) fp32; returns dict(logits, topk_values, topk_indices, preds_geocell, preds_LLH)."""
     _dev(emb, torch.float32); _dev(W, torch.float32); _dev(bias, torch.float32); _dev(centroids, torch.float64)
+    if emb.dim() not in (2, 3):
+        raise _lib.PigeonHipError(f"emb must be (B,{HIDDEN}) or (B,P,{HIDDEN}), got {tuple(emb.shape)}")
     B = emb.shape[0]
     P = emb.shape[1] if emb.dim() == 3 else 1
+    _shape(emb, "emb", *((B, P, HIDDEN) if emb.dim() == 3 else (B, HIDDEN)))
     Cn = W.shape[0]
+    _shape(W, "W", Cn, HIDDEN); _shape(bias, "bias", Cn); _shape(centroids, "centroids", Cn, 2)
+    if not 1 <= int(k) <= Cn:
+        raise _lib.PigeonHipError(f"head: k = {k} candidates of {Cn} geocells")
     dev = emb.device
     logits = torch.empty((B, Cn), dtype=torch.float32, device=dev)
     tv = torch.empty((B, k), dtype=torch.float32, device=dev)
@@ -392,6 +407,11 @@ class DeviceBank:
         self.num_cells = self.t["cell_off"].numel() - 1
         self.num_protos = self.t["proto_emb"].shape[0]
         self.num_train = self.t["train_emb"].shape[0]
+        t = self.t                                            # the CSR arrays must fit each other: the kernels index by them
+        _shape(t["proto_emb"], "proto_emb", self.num_protos, HIDDEN); _shape(t["proto_lnglat"], "proto_lnglat", self.num_protos, 2)
+        _shape(t["proto_count"], "proto_count", self.num_protos); _shape(t["member_off"], "member_off", self.num_protos + 1)
+        _shape(t["cell_off"], "cell_off", self.num_cells + 1); _shape(t["member_idx"], "member_idx", None)
+        _shape(t["train_emb"], "train_emb", self.num_train, HIDDEN); _shape(t["train_lnglat"], "train_lnglat", self.num_train, 2)
         self.struct = Bank(*[C.c_void_p(self.t[n].data_ptr()) for n, _ in self.FIELDS],
                            self.num_cells, self.num_protos, self.num_train)
 
@@ -404,9 +424,17 @@ def refine_forward(bank: DeviceBank, q: torch.Tensor, init_llh: torch.Tensor, ca
     _dev(q, torch.float32); _dev(init_llh, torch.float64); _dev(cand, torch.int64)
     if cand_prob is not None:
         _dev(cand_prob, torch.float32)
+    if q.dim() not in (2, 3) or cand.dim() != 2:
+        raise _lib.PigeonHipError(f"refine: q must be (B,{HIDDEN}) or (B,P,{HIDDEN}) and cand (B,k), got {tuple(q.shape)} / {tuple(cand.shape)}")
     B = q.shape[0]
     P = q.shape[1] if q.dim() == 3 else 1
     k = cand.shape[1]
+    _shape(q, "q", *((B, P, HIDDEN) if q.dim() == 3 else (B, HIDDEN)))
+    _shape(init_llh, "init_llh", B, 2); _shape(cand, "cand", B, k)
+    if cand_prob is not None:
+        _shape(cand_prob, "cand_prob", B, k)
+    if not 1 <= int(topk) <= k:
+        raise _lib.PigeonHipError(f"refine: topk = {topk} of k = {k} candidates")
     dev = q.device
     scratch = torch.empty((B, topk, 4), dtype=torch.float32, device=dev)
     out_llh = torch.empty((B, 2), dtype=torch.float32, device=dev)

@@ -518,6 +518,48 @@ def test_empty_and_single_sample_batches(env, vit2, golden_dir, tmp_path):
         assert np.array_equal(c1.cpu().numpy(), g["default_cell"][:1]) and np.array_equal(l1.cpu().numpy(), g["default_LLH"][:1])
 
 
+def test_input_forms_do_not_change_results(env, vit2, golden_dir, tmp_path):
+    """What callers really hand over: strided views (top-k slices, a channel-last pixel tensor viewed as NCHW), host tensors, int32
+    candidate cells, fp32 initial predictions that are exactly representable, fp16 pixels -- the host side canonicalises
+    (device, dtype, contiguity) before a pointer crosses the C ABI, so the results equal those of the canonical tensors; shapes the
+    kernels do not implement are refused by name, not read out of bounds."""
+    from pigeon_amd.proto_refiner import ProtoRefiner
+    sd, base = vit2
+    L = env["lib"]
+    g = _gold(golden_dir, "refine.npz")
+    ref = ProtoRefiner(topk=5, bank=_bank(env, g)).eval()
+    emb, init = torch.from_numpy(g["embedding"]), torch.from_numpy(g["initial_preds"])
+    cand, probs = torch.from_numpy(g["candidate_cells"]), torch.from_numpy(g["candidate_probs"])
+    want_cell, want_llh = g["default_cell"], g["default_LLH"]
+    B, k = cand.shape
+    wide_c = torch.cat([cand, torch.zeros((B, 3), dtype=cand.dtype)], dim=1)[:, :k]        # a (B,k) slice of a (B,k+3) top-k: strided
+    wide_p = torch.cat([probs, torch.zeros((B, 3))], dim=1)[:, :k]
+    emb_t = emb.t().contiguous().t()                                                        # column-major embedding
+    assert not wide_c.is_contiguous() and not emb_t.is_contiguous()
+    for kw in (dict(e=emb_t.to(DEV), i=init.to(DEV), c=wide_c.to(DEV), p=wide_p.to(DEV)),   # strided device tensors
+               dict(e=emb, i=init, c=cand, p=probs),                                        # everything on the host (reference: .to('cuda') inside)
+               dict(e=emb.to(DEV).double(), i=init.to(DEV), c=cand.to(DEV).int(), p=probs.to(DEV).double())):   # other dtypes
+        _, llh, cell = ref(kw["e"], initial_preds=kw["i"], candidate_cells=kw["c"], candidate_probs=kw["p"], quiet=True)
+        assert llh.is_cuda and np.array_equal(cell.cpu().numpy(), want_cell) and np.array_equal(llh.cpu().numpy(), want_llh)
+    # encoder: NHWC storage viewed as NCHW, a host tensor, fp16 pixels (exactly representable values) -- same embedding
+    px = (torch.randint(-8, 9, (3, 3, 336, 336), generator=torch.Generator().manual_seed(5)).float() / 4).to(DEV)
+    want = base.embed(px)
+    nhwc_view = px.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    assert not nhwc_view.is_contiguous()
+    for form in (nhwc_view, px.cpu(), px.half(), px.double()):
+        assert torch.equal(base.embed(form), want)
+    for bad in (torch.zeros((2, 3, 224, 224), device=DEV), torch.zeros((3, 336, 336), device=DEV), torch.zeros((2, 1, 336, 336), device=DEV)):
+        with pytest.raises(L.PigeonHipError):
+            base.embed(bad)
+    # head: k > C and a wrong embedding width are refused
+    ops = env["ops"]
+    W, b, cen = torch.zeros((6, 1024), device=DEV), torch.zeros(6, device=DEV), torch.zeros((6, 2), dtype=torch.float64, device=DEV)
+    with pytest.raises(L.PigeonHipError):
+        ops.head_forward(torch.zeros((2, 1, 1024), device=DEV), W, b, cen, 7)
+    with pytest.raises(L.PigeonHipError):
+        ops.head_forward(torch.zeros((2, 1, 768), device=DEV), W, b, cen, 3)
+
+
 def test_refiner_built_from_reference_files(env, golden_dir, tmp_path):
     """ProtoRefiner(proto_path=CSV, dataset_path=HF dataset dir): the reference's own on-disk inputs."""
     from pigeon_amd.proto_refiner import ProtoRefiner
