@@ -163,10 +163,19 @@ def cast_f32(x: torch.Tensor, out_dtype: torch.dtype = torch.float16) -> torch.T
 def proto_build(train_emb: torch.Tensor, member_off: torch.Tensor, member_idx: torch.Tensor) -> torch.Tensor:
     """(Ntr,1024) or (Ntr,4,1024) fp32 training embeddings + CSR member lists -> (P,1024) fp32 prototype means."""
     _dev(train_emb, torch.float32); _dev(member_off, torch.int64); _dev(member_idx, torch.int64)
+    if train_emb.dim() not in (2, 3) or train_emb.shape[-1] != HIDDEN:
+        raise _lib.PigeonHipError(f"proto_build: embeddings must be (Ntr,{HIDDEN}) or (Ntr,panels,{HIDDEN}), got {tuple(train_emb.shape)}")
     panels = 1 if train_emb.dim() == 2 else int(train_emb.shape[1])
-    if train_emb.shape[-1] != HIDDEN:
-        raise _lib.PigeonHipError("proto_build: embeddings must have 1024 columns")
+    if member_off.dim() != 1 or member_off.numel() < 1 or member_idx.dim() != 1:
+        raise _lib.PigeonHipError("proto_build: member_off (P+1,) and member_idx (n,) expected")
     P = member_off.numel() - 1
+    # one-off bank construction: a host round trip for the CSR invariants is cheap, a member index past the training bank is a
+    # read out of bounds in the kernel
+    off = member_off.cpu()
+    if int(off[0]) != 0 or int(off[-1]) != member_idx.numel() or bool((off[1:] < off[:-1]).any()):
+        raise _lib.PigeonHipError("proto_build: member_off must rise from 0 to len(member_idx)")
+    if member_idx.numel() and (int(member_idx.min()) < 0 or int(member_idx.max()) >= train_emb.shape[0]):
+        raise _lib.PigeonHipError(f"proto_build: member index outside the {train_emb.shape[0]} training rows")
     out = torch.empty((P, HIDDEN), dtype=torch.float32, device=train_emb.device)
     check(load().pg_proto_build(_p(train_emb), panels, train_emb.shape[0], _p(member_off), _p(member_idx), P, _p(out),
                                 _stream()), "pg_proto_build")
@@ -178,6 +187,7 @@ def haversine_matrix(x: torch.Tensor, y_rows: torch.Tensor) -> torch.Tensor:
     _dev(x); _dev(y_rows, torch.float64)
     if x.dtype not in (torch.float32, torch.float64):
         raise _lib.PigeonHipError("haversine_matrix: x must be fp32 or fp64")
+    _shape(x, "x", None, 2); _shape(y_rows, "y_rows", None, 2)
     N, M = x.shape[0], y_rows.shape[0]
     out = torch.empty((N, M), dtype=torch.float64, device=x.device)
     check(load().pg_haversine_matrix(_p(x), _lib.PG_DTYPE_F64 if x.dtype == torch.float64 else _lib.PG_DTYPE_F32, _p(y_rows),
@@ -198,6 +208,7 @@ def haversine_pairs(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
 
 def smooth_labels(distances: torch.Tensor, constant: float) -> torch.Tensor:
     _dev(distances, torch.float64)
+    _shape(distances, "distances", None, None)
     N, M = distances.shape
     out = torch.empty_like(distances)
     check(load().pg_smooth_labels(_p(distances), N, M, float(constant), _p(out), _stream()), "pg_smooth_labels")

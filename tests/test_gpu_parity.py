@@ -558,6 +558,14 @@ def test_input_forms_do_not_change_results(env, vit2, golden_dir, tmp_path):
         ops.head_forward(torch.zeros((2, 1, 1024), device=DEV), W, b, cen, 7)
     with pytest.raises(L.PigeonHipError):
         ops.head_forward(torch.zeros((2, 1, 768), device=DEV), W, b, cen, 3)
+    # around the path: a member index past the training bank, CSR offsets that do not end at the list, a (N,3) point list
+    tr = torch.zeros((4, 1024), device=DEV)
+    with pytest.raises(L.PigeonHipError):
+        ops.proto_build(tr, torch.tensor([0, 2], device=DEV), torch.tensor([1, 4], device=DEV))
+    with pytest.raises(L.PigeonHipError):
+        ops.proto_build(tr, torch.tensor([0, 3], device=DEV), torch.tensor([1, 2], device=DEV))
+    with pytest.raises(L.PigeonHipError):
+        ops.haversine_matrix(torch.zeros((3, 3), dtype=torch.float64, device=DEV), torch.zeros((2, 2), dtype=torch.float64, device=DEV))
 
 
 def test_refiner_built_from_reference_files(env, golden_dir, tmp_path):
