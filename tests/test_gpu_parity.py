@@ -445,6 +445,34 @@ def test_head_ties_pick_lowest_index(env):
     assert o["topk_indices"][0, 3:].tolist() == [0, 1, 2, 3]
 
 
+@pytest.mark.parametrize("B,P,C,k", [(7, 4, 38399, 50), (1, 1, 17, 17), (130, 4, 1031, 5)])
+def test_head_sizes_outside_the_fixtures(env, B, P, C, k):
+    """Geocell counts that are a multiple of nothing, k = C, one row, more rows than a block: the head's outputs are consistent
+    with each other (top-k = the k largest of its own softmax in descending order, ties aside; argmax = top-1; prediction =
+    that cell's centroid) and its logits equal an fp64 restatement of mean-over-panels + Linear (super_guessr.py:437-447)."""
+    ops = env["ops"]
+    g = torch.Generator().manual_seed(C)
+    emb = torch.randn((B, P, 1024), generator=g)
+    W = torch.randn((C, 1024), generator=g) * 0.05
+    b = torch.randn(C, generator=g)
+    cen = torch.stack([torch.rand(C, generator=g, dtype=torch.float64) * 360 - 180, torch.rand(C, generator=g, dtype=torch.float64) * 180 - 90], 1)
+    o = ops.head_forward(emb.to(DEV), W.to(DEV), b.to(DEV), cen.to(DEV), k)
+    logits = o["logits"].cpu()
+    want = (emb.double().mean(1) @ W.double().t() + b.double())
+    assert float((logits.double() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+    probs = torch.softmax(logits, dim=-1)
+    tv, ti = o["topk_values"].cpu(), o["topk_indices"].cpu()
+    assert torch.equal(o["preds_geocell"].cpu(), ti[:, 0]) and torch.equal(o["preds_LLH"].cpu(), cen[ti[:, 0]])
+    assert bool((tv[:, :-1] >= tv[:, 1:]).all()) and all(len(set(r.tolist())) == k for r in ti)
+    np.testing.assert_allclose(tv.numpy(), torch.gather(probs, 1, ti).numpy(), rtol=2e-6, atol=1e-12)
+    kth = torch.topk(probs, k, dim=-1).values[:, -1]
+    assert bool((tv[:, -1] >= kth * (1 - 1e-6)).all())                       # nothing larger was left out
+    if C > 30000:                                                             # the documented limit (include/pigeon_hip.h) is refused by name
+        with pytest.raises(env["lib"].PigeonHipError, match="38400"):
+            ops.head_forward(emb.to(DEV), torch.zeros((40003, 1024), device=DEV), torch.zeros(40003, device=DEV),
+                             torch.zeros((40003, 2), dtype=torch.float64, device=DEV), k)
+
+
 # ------------------------------------------------------------------------------------------------ refiner
 def _bank(env, g):
     C, ppc, bseed = [int(x) for x in g["meta"][:3]]
@@ -614,6 +642,57 @@ def test_refiner_full_size_bank_vs_oracle(env):
     _, o_llh, o_cell = orc.proto_refiner_forward(hb, q[:24], ini[:24], cand[:24], cp[:24], 5, 1.6, 1000.0)
     assert torch.equal(cell[:24].cpu(), o_cell)
     assert np.allclose(llh[:24].cpu().numpy(), o_llh.numpy(), rtol=1e-6, atol=0)
+
+
+def test_refiner_ragged_bank_vs_oracle(env):
+    """Cell sizes the fixtures do not have: empty cells next to a 4 099-prototype cell (more than one block's worth of rows, not a
+    multiple of anything), a single-prototype cell, a 300-member cluster (the within-cluster farthest-member search over many rows),
+    the same cell twice in one candidate list, zero candidate probabilities, topk < k -- bit-for-bit against the oracle."""
+    ops, orc = env["ops"], env["orc"]
+    rng = np.random.default_rng(12)
+    sizes = np.array([0, 1, 4099, 2, 0, 257, 33], dtype=np.int64)
+    cell_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    P = int(cell_off[-1])
+    count = np.where(rng.random(P) < 0.5, rng.integers(2, 9, P), 1).astype(np.int32)
+    count[1] = 300                                   # a big cluster inside the big cell
+    count[0] = 1                                     # the single-prototype cell is a singleton cluster
+    member_off = np.concatenate([[0], np.cumsum(count.astype(np.int64))]).astype(np.int64)
+    Ntr = int(member_off[-1])
+    member_idx = rng.permutation(Ntr).astype(np.int64)
+    train_emb = rng.standard_normal((Ntr, 1024)).astype(np.float32)
+    train_lnglat = np.stack([rng.uniform(-180, 180, Ntr), rng.uniform(-90, 90, Ntr)], 1).astype(np.float32)
+    proto_emb = np.stack([train_emb[member_idx[member_off[p]:member_off[p + 1]]].mean(0) for p in range(P)]).astype(np.float32)
+    proto_lnglat = np.stack([rng.uniform(-180, 180, P), rng.uniform(-90, 90, P)], 1).astype(np.float32)
+
+    class HB:
+        pass
+    hb = HB()
+    hb.proto_emb, hb.cell_off, hb.proto_lnglat, hb.proto_count = proto_emb, cell_off, proto_lnglat, count
+    hb.member_off, hb.member_idx, hb.train_emb, hb.train_lnglat = member_off, member_idx, train_emb, train_lnglat
+    dbank = ops.DeviceBank({k: getattr(hb, k) for k in ("proto_emb", "cell_off", "proto_lnglat", "proto_count", "member_off",
+                                                        "member_idx", "train_emb", "train_lnglat")}, device=DEV)
+    B, k = 40, 6
+    g = torch.Generator().manual_seed(9)
+    # queries near prototypes of the big cell / the big cluster so that those really win, plus far-away ones
+    q = torch.randn((B, 1024), generator=g)
+    q[:8] = torch.from_numpy(proto_emb[1:9]) + 0.01 * torch.randn((8, 1024), generator=g)
+    q[8:12] = torch.from_numpy(proto_emb[1]) + 0.2 * torch.randn((4, 1024), generator=g)
+    cand = torch.randint(0, len(sizes), (B, k), generator=g)
+    cand[:12, 0] = 2                                 # the big cell first
+    cand[12:16] = torch.tensor([2, 2, 5, 5, 1, 0])   # duplicates and an empty cell
+    cand[16:18] = torch.tensor([0, 4, 0, 4, 0, 4])   # nothing but empty cells
+    cp = torch.softmax(torch.randn((B, k), generator=g), dim=-1)
+    cp[18:22, 1:4] = 0.0                             # zero probabilities
+    ini = torch.stack([torch.rand(B, generator=g, dtype=torch.float64) * 360 - 180, torch.rand(B, generator=g, dtype=torch.float64) * 180 - 90], 1)
+    for topk, T, mr in ((6, 1.6, 1000.0), (4, 0.6, 100000.0), (1, 1.0, 50.0)):
+        llh, cell, choice = ops.refine_forward(dbank, q.to(DEV), ini.to(DEV), cand.to(DEV), cp.to(DEV), topk, T, mr)
+        _, o_llh, o_cell = orc.proto_refiner_forward(hb, q, ini, cand, cp, topk, T, mr)
+        assert torch.equal(cell.cpu(), o_cell), (topk, T, mr)
+        assert np.array_equal(llh.cpu().numpy(), o_llh.numpy()), (topk, T, mr)
+    # the big cluster was really searched: a query at the big cluster's prototype ends on one of its 300 members (or was vetoed)
+    members = set(map(tuple, train_lnglat[member_idx[member_off[1]:member_off[2]]].tolist()))
+    llh, cell, choice = ops.refine_forward(dbank, q.to(DEV), ini.to(DEV), cand.to(DEV), cp.to(DEV), 6, 1.6, 1e9)
+    assert sum(tuple(r) in members for r in llh[8:12].cpu().numpy().tolist()) >= 1
 
 
 # ------------------------------------------------------------------------------------------------ end to end
