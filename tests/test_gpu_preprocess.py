@@ -37,6 +37,20 @@ def test_prep_matches_oracle_bit_exact(env, h, w):
         assert torch.equal(got16[i], torch.from_numpy(ref).to(torch.float16))
 
 
+@pytest.mark.parametrize("h,w", [(1, 1), (2, 900), (900, 2), (3000, 4000), (50, 51), (17, 4000), (1, 336)])
+def test_prep_extreme_geometries(env, h, w):
+    """One pixel, aspect ratios of 450:1 (the resized image would be 151 200 pixels long -- only the centre crop is ever computed),
+    an 8.9x downscale (36-tap bicubic support), a 6.7x upscale: bit-exact against the oracle, which equals Pillow + transformers
+    4.23.1 on exactly these geometries (checked on the CPU when this test was written)."""
+    ops, orc = env["ops"], env["orc"]
+    img = np.random.default_rng(h * 7 + w).integers(0, 256, (1, h, w, 3), dtype=np.uint8)
+    prep = ops.Preprocessor(h, w)
+    assert (prep.resized_h, prep.resized_w) == orc.resize_output_size(h, w)
+    got = prep(torch.from_numpy(img).to(DEV), torch.float32).cpu().numpy()[0]
+    ref = orc.clip_preprocess(img[0])
+    assert np.array_equal(got, ref), f"{np.abs(got - ref).max()}"
+
+
 def test_prep_matches_pillow_golden(env, golden_dir):
     ops = env["ops"]
     gold = np.load(os.path.join(golden_dir, "preprocess.npz"))
