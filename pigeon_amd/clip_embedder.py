@@ -135,7 +135,27 @@ def clip_preprocess(images) -> Tensor:
     return torch.from_numpy(np.ascontiguousarray(np.stack(out)))
 
 
-_PREPROCESSORS: Dict = {}
+# pg_prep handles by (in_h, in_w, device): each owns the resize coefficient tables of one input geometry.  Street-view panels come
+# in a handful of sizes, photo collections (YFCC) in thousands: least-recently-used handles beyond the cap are destroyed.
+_PREPROCESSORS: "OrderedDict" = None
+_PREPROCESSORS_MAX = 64
+
+
+def _preprocessor(in_h: int, in_w: int, device_index: int) -> "hip_ops.Preprocessor":
+    global _PREPROCESSORS
+    from collections import OrderedDict
+    if _PREPROCESSORS is None:
+        _PREPROCESSORS = OrderedDict()
+    key = (int(in_h), int(in_w), int(device_index))
+    p = _PREPROCESSORS.pop(key, None)
+    if p is None:
+        p = hip_ops.Preprocessor(key[0], key[1], device=key[2])
+    _PREPROCESSORS[key] = p                                        # most recently used last
+    while len(_PREPROCESSORS) > _PREPROCESSORS_MAX:
+        _, old = _PREPROCESSORS.popitem(last=False)
+        torch.cuda.synchronize(key[2])                             # its tables may still be read by a queued kernel
+        old.close()
+    return p
 
 
 def gpu_preprocess(images, device="cuda", out_dtype: torch.dtype = torch.float32) -> Tensor:
@@ -145,6 +165,8 @@ def gpu_preprocess(images, device="cuda", out_dtype: torch.dtype = torch.float32
     dev = torch.device(device)
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
+    if hasattr(images, "convert"):                                 # one PIL image, as `processor(images=img)` accepts it
+        images = [images]
     if torch.is_tensor(images) or isinstance(images, np.ndarray):
         t = torch.as_tensor(images)
         if t.dim() == 3:
@@ -161,11 +183,8 @@ def gpu_preprocess(images, device="cuda", out_dtype: torch.dtype = torch.float32
     for idx, t in groups:
         if t.dtype != torch.uint8 or t.shape[-1] != 3:
             raise ValueError(f"gpu_preprocess expects uint8 RGB (N,H,W,3), got {t.dtype} {tuple(t.shape)}")
-        key = (int(t.shape[1]), int(t.shape[2]), dev.index)
-        if key not in _PREPROCESSORS:
-            _PREPROCESSORS[key] = hip_ops.Preprocessor(key[0], key[1], device=dev.index)
         with torch.cuda.device(dev):
-            px = _PREPROCESSORS[key](t.to(dev, non_blocking=True).contiguous(), out_dtype)
+            px = _preprocessor(t.shape[1], t.shape[2], dev.index)(t.to(dev, non_blocking=True).contiguous(), out_dtype)
         if idx is None:
             out = px
         else:

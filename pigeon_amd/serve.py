@@ -86,6 +86,8 @@ def make_app(model, refiner=None, preprocess: Optional[Callable] = None, game_lo
             views = panorama_from_request(body)
         except (BadRequest, json.JSONDecodeError) as e:
             return JSONResponse({"error": str(e)}, status_code=400)
+        # called inline on the event loop, on purpose: the handles behind `model` are one per (device, stream) and not
+        # thread-safe, so requests are answered one at a time -- a `def` handler would run in Starlette's pool
         res = predict_panorama(views, model, refiner, preprocess)
         return JSONResponse({"gameID": body.get("gameID"), "roundID": body.get("roundID"), "results": res})
 

@@ -81,6 +81,28 @@ def test_clip_embedding_accepts_raw_images(env):
     assert torch.equal(e_u8, e_raw[[0, 2]])
 
 
+def test_gpu_preprocess_single_image_modes_and_handle_cache(env, monkeypatch):
+    """One PIL image (not a list), grayscale / RGBA / palette images (converted to RGB as the reference's processor does), and
+    more input geometries than the handle cache keeps (least recently used handles are destroyed): bit-identical to the host path."""
+    Image = pytest.importorskip("PIL.Image")
+    from pigeon_amd import clip_embedder as ce
+    rng = np.random.default_rng(6)
+    rgb = Image.fromarray(rng.integers(0, 256, (300, 400, 3), dtype=np.uint8))
+    one = ce.gpu_preprocess(rgb).cpu()
+    assert one.shape == (1, 3, 336, 336) and torch.equal(one, ce.clip_preprocess(rgb))
+    modes = [rgb.convert("L"), rgb.convert("RGBA"), rgb.convert("P"), Image.fromarray(rng.integers(0, 256, (350, 350), dtype=np.uint8))]
+    assert torch.equal(ce.gpu_preprocess(modes).cpu(), ce.clip_preprocess(modes))
+    monkeypatch.setattr(ce, "_PREPROCESSORS_MAX", 2)
+    sizes = [(340, 500), (500, 340), (336, 336), (400, 400), (340, 500), (700, 350)]
+    ims = [Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)) for h, w in sizes]
+    for _ in range(2):                                             # second pass: evicted geometries are rebuilt
+        for im in ims:
+            assert torch.equal(ce.gpu_preprocess([im]).cpu(), ce.clip_preprocess([im]))
+    assert len(ce._PREPROCESSORS) <= 2
+    assert torch.equal(ce.gpu_preprocess(ims).cpu(), ce.clip_preprocess(ims))       # one call, five geometries, cap 2
+    assert ce.gpu_preprocess([]).shape == (0, 3, 336, 336)
+
+
 # ------------------------------------------------------------------------------------------------ SURVEY 8f rows 3-4
 def test_proto_build_matches_torch_mean(env):
     """pg_proto_build == torch's `embeddings.mean(dim=1).mean(dim=0)` (reference proto_refiner.py:370-378), bit for bit,
