@@ -17,7 +17,8 @@ lib = C.CDLL(os.environ["PIGEON_HIP_LIB"])
 dev, dt = "cuda", torch.float16
 M = 512 * 577
 g = torch.Generator(device=dev).manual_seed(1)
-FORMS = {"out": (1024, 1024, "resid_stat"), "fc2": (1024, 4096, "resid_stat"), "qkv": (3072, 1024, "qkv_ln"), "fc1": (4096, 1024, "gelu_ln")}
+FORMS = {"out": (1024, 1024, "resid_stat"), "fc2": (1024, 4096, "resid_stat"), "qkv": (3072, 1024, "qkv_ln"), "fc1": (4096, 1024, "gelu_ln"),
+         "fc1q": (4096, 1024, "qkv_ln")}       # fc1's shape with the QKV epilogue (no QuickGELU): what the transcendentals + 3 packed ops cost
 which = sys.argv[1:] or list(FORMS)
 NSLAB = {"resid_stat": 4, "qkv_ln": 6, "gelu_ln": 6}
 for name in which:
