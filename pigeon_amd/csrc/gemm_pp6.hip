@@ -204,7 +204,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rowstat_rsrc6(const GemmArgs& 
     return make_rsrc((const char*)g.ex.rowstat + (int64_t)row0 * 8, (uint32_t)rvs * 8u);
 }
 
-// Epilogue of the 16-bit outputs: per wave six 32-row x 64-column fp32 slabs transposed through LDS (gemm_pp.hip
+// Round 2's epilogue of the 16-bit outputs (tools build: PIGEON_GEMM_PARK16=0; the product form is epilogue6_park16 below, same
+// bits, -1 % per launch): per wave six 32-row x 64-column fp32 slabs transposed through LDS (gemm_pp.hip
 // pp_epilogue, WIDE geometry: 8 lanes per row, 8 rows per store instruction, 4 instructions per slab).
 // LN: colsum (cs) and the row statistics of slab 0 (rs0) were fetched right after the last MFMA phase.
 template <typename T, int EPI, typename PREFETCH_DMA, typename PREFETCH_BIAS>
@@ -259,6 +260,78 @@ __device__ __forceinline__ void epilogue6(Acc6& acc, const GemmArgs& g, char* sm
         wave_lds_fence();                                    // slab reads retired before the next slab overwrites it
         PG_TS(g, dbg_iter, wave, 3 + i);
         if (i == 0) prefetch_bias();                         // next tile's bias (/ nothing else): 32 registers are free now
+    }
+}
+
+// ---- 16-bit outputs: finish in the accumulator layout, transpose the 16-bit values (product epilogue since the end of round 3) --
+// epilogue6 parks fp32 accumulators and finishes them after the read-back: 768 KB of LDS traffic per tile.  Here the arithmetic
+// (the same gemm_epi.h epi16_finish on the same values: outputs are bit-identical) runs on the accumulators where they are -- a
+// lane owns row rb * 16 + (lane & 15) and the 4 consecutive columns 16 j + 4 (lane >> 4) .. of each 16 x 16 block -- and only the
+// packed 16-bit results go through the slab: 384 KB per tile, and the read-back feeds the stores directly.  The stores keep the
+// slab form's geometry (8 rows x 128 bytes per instruction: full lines; tools/store_bw.hip: partial lines cost per request).
+// Needs the row statistics of the lane's two rows per slab and the column constants of all four column blocks: blocks 0, 1 come
+// as the tile's Bias6 (HOFF = 16), blocks 2, 3 and the colsum vectors are fetched right after the last MFMA phase.
+constexpr int P6_P16_ROWB = 128 + 16;                      // bytes per 64-column 16-bit slab row (pad: the 16 rows of a b64 write hit 16 bank pairs)
+static_assert(32 * P6_P16_ROWB <= P6_SLAB_BYTES, "16-bit slab must fit into the wave's slab");
+struct RowStatP { u32x2 v[2]; };
+__device__ __forceinline__ void load_rowstat_p(RowStatP& rs, __amdgpu_buffer_rsrc_t rrs, int l15, int slab) {
+    rs.v[0] = __builtin_amdgcn_raw_buffer_load_b64(rrs, (slab * 32 + l15) * 8, 0, 0);
+    rs.v[1] = __builtin_amdgcn_raw_buffer_load_b64(rrs, (slab * 32 + 16 + l15) * 8, 0, 0);
+}
+template <typename T, int EPI, typename PREFETCH_DMA, typename PREFETCH_BIAS>
+__device__ __forceinline__ void epilogue6_park16(Acc6& acc, const GemmArgs& g, char* smem, int wave, int lane, int row0, int col0,
+                                                 const Bias6& b01, const Bias6& b23, const Bias6& s01, const Bias6& s23,
+                                                 const RowStatP& rs0, __amdgpu_buffer_rsrc_t rrs,
+                                                 PREFETCH_DMA&& prefetch_dma, PREFETCH_BIAS&& prefetch_bias, int dbg_iter = 0) {
+    constexpr bool LN = ln6<EPI>();
+    const int l15 = lane & 15, lq = lane >> 4;
+    char* slab = smem + P6_SLAB_OFF + wave * P6_SLAB_BYTES;
+    const int rr = lane >> 3, c8 = lane & 7;
+    const bool q_strip = col0 < g.qcols;                     // wave-uniform: qcols is a multiple of 64
+    const float qsc = (qkv6<EPI>() && q_strip) ? g.qscale : 1.f;
+    int rv = g.M - row0; rv = rv < 0 ? 0 : (rv > P6_TM * 32 ? P6_TM * 32 : rv);
+    rv = __builtin_amdgcn_readfirstlane(rv);
+    const uint32_t nbytes = rv > 0 ? (uint32_t)(((int64_t)(rv - 1) * g.ldc + 64) * 2) : 0u;
+    __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)g.out + ((int64_t)row0 * g.ldc + col0) * 2, nbytes);
+    const int voff = (rr * (int)g.ldc + c8 * 8) * 2;
+    int rstep = 8 * (int)g.ldc * 2;
+    int sstep = 32 * (int)g.ldc * 2;
+    asm volatile("" : "+s"(rstep), "+s"(sstep));
+    prefetch_dma();
+    RowStatP rs[2];
+    rs[0] = rs0;
+    char* wr = slab + l15 * P6_P16_ROWB + 8 * lq;            // this lane's 8 bytes of column block 0 in row block 0 of the slab
+#pragma unroll
+    for (int i = 0; i < P6_TM; ++i) {
+        if constexpr (LN) { if (i + 1 < P6_TM) load_rowstat_p(rs[(i + 1) & 1], rrs, l15, i + 1); }
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            float rstd = 0.f, mrs = 0.f;
+            if constexpr (LN) {                              // each half through a move of its own (see epilogue6)
+                asm("v_mov_b32 %0, %1" : "=v"(rstd) : "v"(rs[i & 1].v[ib][0]));
+                asm("v_mov_b32 %0, %1" : "=v"(mrs) : "v"(rs[i & 1].v[ib][1]));
+            }
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                const Bias6& bb = jp ? b23 : b01;
+                const Bias6& ss = jp ? s23 : s01;
+                const u32x4 pk = epi16_finish<T, EPI>(acc[2 * i + ib][2 * jp], acc[2 * i + ib][2 * jp + 1], bb.lo, bb.hi, ss.lo, ss.hi,
+                                                      rstd, mrs, q_strip, qsc);
+                u32x2 h0, h1;
+                h0[0] = pk[0]; h0[1] = pk[1]; h1[0] = pk[2]; h1[1] = pk[3];
+                *(u32x2*)(wr + ib * 16 * P6_P16_ROWB + (2 * jp) * 32) = h0;
+                *(u32x2*)(wr + ib * 16 * P6_P16_ROWB + (2 * jp + 1) * 32) = h1;
+            }
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const u32x4 v = *(const u32x4*)(slab + (it * 8 + rr) * P6_P16_ROWB + c8 * 16);
+            __builtin_amdgcn_raw_buffer_store_b128(v, ro, voff + (i * sstep + it * rstep), 0, 0);
+        }
+        wave_lds_fence();                                    // slab reads retired before the next slab overwrites it
+        PG_TS(g, dbg_iter, wave, 3 + i);
+        if (i == 0) prefetch_bias();
     }
 }
 
@@ -360,7 +433,7 @@ __device__ __forceinline__ void epilogue6_resid(Acc6& acc, const GemmArgs& g, ch
     }
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, bool PARK>
 __global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -380,8 +453,9 @@ __global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
     const uint32_t baseA = smem0 + (wm * (P6_TM * 32) + l15) * ROWB + xo0;
     const uint32_t baseB = smem0 + P6_W_OFF + (wn * 64 + l15) * ROWB + xo0;
     constexpr bool RSTAT = (EPI == EPI_RESID_STAT);
-    constexpr int BHOFF = RSTAT ? 32 : 4;
-    const int ecc = RSTAT ? (lane & 7) * 4 : (lane & 7) * 8;
+    constexpr bool PARK16 = PARK && !RSTAT;                  // 16-bit outputs finished in the accumulator layout (epilogue6_park16)
+    constexpr int BHOFF = RSTAT ? 32 : (PARK16 ? 16 : 4);
+    const int ecc = RSTAT ? (lane & 7) * 4 : (PARK16 ? (lane >> 4) * 4 : (lane & 7) * 8);
 
     const int nt = g.K / BK;                                 // even, >= 4 (checked on the host)
     const int nblk = gridDim.x;
@@ -423,12 +497,21 @@ __global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
         const int row0 = c.m0 + wm * (P6_TM * 32), col0 = c.n0 + wn * 64;
         Bias6 cs;
         RowStat6 rs0;
+        Bias6 b23, cs23;
+        RowStatP rsp;
         __amdgpu_buffer_rsrc_t rrs = c.ra;                   // placeholder for the plain epilogues (never dereferenced)
+        if constexpr (PARK16) load_bias6<16>(b23, g, col0 + 32 + ecc);
         if constexpr (ln6<EPI>()) {
             cs.lo = *(const f32x4*)(g.ex.colsum + col0 + ecc);
-            cs.hi = *(const f32x4*)(g.ex.colsum + col0 + ecc + 4);
+            cs.hi = *(const f32x4*)(g.ex.colsum + col0 + ecc + BHOFF);
             rrs = rowstat_rsrc6(g, row0);
-            load_rowstat6(rs0, rrs, lane >> 3, 0);
+            if constexpr (PARK16) {
+                cs23.lo = *(const f32x4*)(g.ex.colsum + col0 + 32 + ecc);
+                cs23.hi = *(const f32x4*)(g.ex.colsum + col0 + 48 + ecc);
+                load_rowstat_p(rsp, rrs, l15, 0);
+            } else {
+                load_rowstat6(rs0, rrs, lane >> 3, 0);
+            }
         }
         ResidCtx6 rc;
         XRows6 x0;
@@ -451,6 +534,7 @@ __global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
         };
         auto prefetch_bias = [&]() { load_bias6<BHOFF>(bias_next, g, c.n0 + wn * 64 + ecc); };
         if constexpr (RSTAT) epilogue6_resid<T>(acc, g, smem, wave, lane, row0, col0, bias, x0, rc, prefetch_dma, prefetch_bias, dbg_iter);
+        else if constexpr (PARK16) epilogue6_park16<T, EPI>(acc, g, smem, wave, lane, row0, col0, bias, b23, cs, cs23, rsp, rrs, prefetch_dma, prefetch_bias, dbg_iter);
         else epilogue6<T, EPI>(acc, g, smem, wave, lane, row0, col0, bias, cs, rs0, rrs, prefetch_dma, prefetch_bias, dbg_iter);
         PG_TS(g, dbg_iter, wave, 9);
         ++dbg_iter;
@@ -461,10 +545,10 @@ __global__ __launch_bounds__(512) void gemm_pp6_kernel(GemmArgs g) {
     }
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, bool PARK = false>
 int launch_pp6(const GemmArgs& g, int nblk, hipStream_t s) {
     static bool attr_set = false;
-    auto kfn = gemm_pp6_kernel<T, EPI>;
+    auto kfn = gemm_pp6_kernel<T, EPI, PARK>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P6_LDS);
         if (e != hipSuccess) { pg_set_error("gemm_pp6: set LDS attr: %s", hipGetErrorString(e)); return PG_EHIP; }
@@ -472,6 +556,18 @@ int launch_pp6(const GemmArgs& g, int nblk, hipStream_t s) {
     }
     hipLaunchKernelGGL(kfn, dim3(nblk), dim3(512), P6_LDS, s, g);
     return pg_check_launch("gemm_pp6");
+}
+
+// 16-bit epilogues of the 384 x 256 kernel: finished in the accumulator layout, 16-bit slabs (epilogue6_park16).  Tools build:
+// PIGEON_GEMM_PARK16=0 selects round 2's fp32-slab epilogue6 (A/B arm; same bits).
+bool park16_enabled() {
+#ifdef PIGEON_ABLATIONS
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PIGEON_GEMM_PARK16"); v = e ? (atoi(e) != 0) : 1; }
+    return v != 0;
+#else
+    return true;
+#endif
 }
 
 int cus6() {
@@ -507,17 +603,24 @@ int pg_gemm_pp6_launch(int dtype, GemmArgs g, int epi, hipStream_t s) {
     const int nblk = g.ntiles < cap ? g.ntiles : cap;
     if ((epi == EPI_QKV_LN || epi == EPI_GELU_LN) && (!g.ex.colsum || !g.ex.rowstat)) { pg_set_error("gemm_pp6: LN epilogue needs colsum / rowstat"); return PG_EINVAL; }
     if (epi == EPI_RESID_STAT && (!g.ex.x16 || !g.ex.statpart || g.ex.ldx != g.ldc || !g.bias)) { pg_set_error("gemm_pp6: EPI_RESID_STAT needs bias, x16 / statpart and ldx == ldc"); return PG_EINVAL; }
+    const bool park = park16_enabled();
+#ifdef PIGEON_ABLATIONS
+#define P6_OLD16(TT, E) launch_pp6<TT, E, false>(g, nblk, s)
+#else
+#define P6_OLD16(TT, E) launch_pp6<TT, E, true>(g, nblk, s)      /* the product library carries the production epilogue only */
+#endif
 #define P6_DISPATCH(TT)                                                          \
     switch (epi) {                                                               \
-        case EPI_QKV: return launch_pp6<TT, EPI_QKV>(g, nblk, s);                \
-        case EPI_GELU: return launch_pp6<TT, EPI_GELU>(g, nblk, s);              \
-        case EPI_QKV_LN: return launch_pp6<TT, EPI_QKV_LN>(g, nblk, s);          \
+        case EPI_QKV: return park ? launch_pp6<TT, EPI_QKV, true>(g, nblk, s) : P6_OLD16(TT, EPI_QKV);                \
+        case EPI_GELU: return park ? launch_pp6<TT, EPI_GELU, true>(g, nblk, s) : P6_OLD16(TT, EPI_GELU);              \
+        case EPI_QKV_LN: return park ? launch_pp6<TT, EPI_QKV_LN, true>(g, nblk, s) : P6_OLD16(TT, EPI_QKV_LN);          \
         case EPI_RESID_STAT: return launch_pp6<TT, EPI_RESID_STAT>(g, nblk, s);  \
-        default: return launch_pp6<TT, EPI_GELU_LN>(g, nblk, s);                 \
+        default: return park ? launch_pp6<TT, EPI_GELU_LN, true>(g, nblk, s) : P6_OLD16(TT, EPI_GELU_LN);                 \
     }
     if (dtype == PG_DTYPE_F16) { P6_DISPATCH(T_F16) }
     if (dtype == PG_DTYPE_BF16) { P6_DISPATCH(T_BF16) }
 #undef P6_DISPATCH
+#undef P6_OLD16
     pg_set_error("gemm_pp6: operand dtype must be PG_DTYPE_F16 or PG_DTYPE_BF16 (got %d)", dtype);
     return PG_EINVAL;
 }

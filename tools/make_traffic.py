@@ -32,11 +32,11 @@ def kernel_avg_ms():
 
 avg_ms = kernel_avg_ms()
 # kernel-name patterns per class: the LayerNorm-folded chain (default) uses epilogues 6 / 7 / 5, the separate-LayerNorm chain 0 / 1 / 2
-CLASSES = {"gemm_qkv": (("gemm_pp6_kernel<T_F16, 6>", "gemm_pp6_kernel<T_F16, 0>", "gemm_pp_kernel<T_F16, 6,", "gemm_pp_kernel<T_F16, 0,"), 2 * 1024 + 2 * 3072),
-           "gemm_fc1": (("gemm_pp6_kernel<T_F16, 7>", "gemm_pp6_kernel<T_F16, 1>", "gemm_pp_kernel<T_F16, 7,", "gemm_pp_kernel<T_F16, 1,"), 2 * 1024 + 2 * 4096),
+CLASSES = {"gemm_qkv": (("gemm_pp6_kernel<T_F16, 6", "gemm_pp6_kernel<T_F16, 0", "gemm_pp_kernel<T_F16, 6,", "gemm_pp_kernel<T_F16, 0,"), 2 * 1024 + 2 * 3072),
+           "gemm_fc1": (("gemm_pp6_kernel<T_F16, 7", "gemm_pp6_kernel<T_F16, 1", "gemm_pp_kernel<T_F16, 7,", "gemm_pp_kernel<T_F16, 1,"), 2 * 1024 + 2 * 4096),
            # round 3: fc2 runs the residual epilogue on the 384 x 256 kernel, the out-projection stays on 256 x 256 (both EPI 5);
            # before that the two shared one kernel name ("gemm_out_fc2_mixed")
-           "gemm_fc2": (("gemm_pp6_kernel<T_F16, 5>",), 2 * 4096 + 4 * 1024 + 4 * 1024 + 2 * 1024),
+           "gemm_fc2": (("gemm_pp6_kernel<T_F16, 5",), 2 * 4096 + 4 * 1024 + 4 * 1024 + 2 * 1024),
            "gemm_out": (("gemm_pp_kernel<T_F16, 5,", "gemm_pp_kernel<T_F16, 2,"), 2 * 1024 + 4 * 1024 + 4 * 1024 + 2 * 1024),
            "attention": (("attention",), 2 * 3072 + 2 * 1024),
            "layernorm": (("layernorm_kernel",), 4 * 1024 + 2 * 1024),
