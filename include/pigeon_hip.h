@@ -37,7 +37,7 @@ extern "C" {
 #define PG_DTYPE_F16     2
 #define PG_DTYPE_F64     3
 
-#define PG_ABI_VERSION   1
+#define PG_ABI_VERSION   2   /* 2: pg_vit_cfg.precise, pg_vit_forward_precise, pg_head_margin (round 4) */
 
 const char* pg_last_error(void);
 int pg_abi_version(void);
@@ -65,6 +65,8 @@ typedef struct pg_vit_cfg {
     int32_t mma_dtype;    /* 16-bit MFMA operand format for weights and activations: PG_DTYPE_F16, PG_DTYPE_BF16, or
                              0 = default (fp16, unless env PIGEON_MMA_DTYPE=bf16).  Same MFMA rate on gfx950; fp16
                              keeps embeddings within 1e-3 of the fp32 reference, bf16 measures 2e-3. */
+    int32_t precise;      /* != 0: pg_vit_finalize also packs the split-fp16 weight copy pg_vit_forward_precise needs (3x the
+                             16-bit weight memory: 1.8 GB for ViT-L); 0: the exact mode is not available on this handle */
 } pg_vit_cfg;
 
 int pg_vit_create(pg_vit** out, int device, const pg_vit_cfg* cfg);
@@ -89,6 +91,17 @@ int pg_vit_forward(pg_vit* h, const void* pixels, int pix_dtype, int n_images, f
  * may be NULL).  Used by parity tests to compare last_hidden_state itself. */
 int pg_vit_forward_hidden(pg_vit* h, const void* pixels, int pix_dtype, int n_images, float* emb_out,
                           float* hidden_out, void* workspace, size_t workspace_bytes, void* stream);
+/* EXACT MODE (round 4).  The same encoder in near-fp32 arithmetic, for the few inputs whose downstream decision the 16-bit
+ * operands cannot settle -- the reference's geocell `torch.argmax` (models/super_guessr.py:454) is fp32 end to end, and a panorama
+ * whose top-1 / top-2 logit margin lies inside the fast path's error band (pg_head_margin below) may flip.  Every GEMM operand is
+ * split into two fp16 halves (x = hi + lo, W = Wh + Wl) and the products hi.Wh + lo.Wh + hi.Wl are accumulated in fp32 by the same
+ * persistent MFMA kernels over a 3x longer K; LayerNorm, attention (fp32 MFMA), QuickGELU (expf, IEEE division) and the residual
+ * stream are fp32.  Measured against the fp32 reference: embeddings to ~1e-6 relative (fast path: 2.7e-4), at ~5x the time per
+ * image.  Needs cfg.precise at creation.  Workspace from pg_vit_precise_workspace_bytes (50 KB per token row, chunks of 64 images).
+ * hidden_out (DEVICE (n_images,577,1024) fp32, may be NULL) receives last_hidden_state. */
+int pg_vit_precise_workspace_bytes(const pg_vit* h, int n_images, size_t* bytes);
+int pg_vit_forward_precise(pg_vit* h, const void* pixels, int pix_dtype, int n_images, float* emb_out, float* hidden_out,
+                           void* workspace, size_t workspace_bytes, void* stream);
 int pg_vit_destroy(pg_vit* h);
 /* The operand format the handle resolved to (PG_DTYPE_F16 or PG_DTYPE_BF16). */
 int pg_vit_mma_dtype(const pg_vit* h);
@@ -147,6 +160,16 @@ int pg_vit_range_alarm_read(pg_vit* h, int64_t* rows, int reset);
 int pg_head_forward(const float* emb, int B, int P, const float* W, const float* bias,
                     const double* centroids, int C, int k, float* logits,
                     float* topk_val, int64_t* topk_idx, int64_t* argmax, double* pred_llh, void* stream);
+
+/* Certainty of the top-1 (round 4; reference models/super_guessr.py:454 `torch.argmax`): per row of `logits` (B,C) as written by
+ * pg_head_forward,
+ *   margin DEVICE (B) fp32 out = logit(top-1) - logit(top-2)   (value desc, index asc -- the order of the selection above)
+ *   sens   DEVICE (B) fp32 out = |mean_p emb|_2 * |W[top1] - W[top2]|_2 / sqrt(1024): the change of the margin per unit RELATIVE
+ *          embedding error in a random direction; the host calls a row certain when margin > kappa * eps * sens, eps = its bound
+ *          on the encoder's relative embedding error (pigeon_amd/super_guessr.py)
+ *   top2   DEVICE (B) int64 out, may be NULL: the runner-up cell.   C == 1: margin = +inf, sens = 0, top2 = top1. */
+int pg_head_margin(const float* logits, int B, int C, const float* emb, int P, const float* W, float* margin, float* sens,
+                   int64_t* top2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * ProtoRefiner prototype-distance refinement over a CSR prototype bank.
@@ -293,6 +316,15 @@ int pg_op_im2col(const void* pixels, int pix_dtype, void* out, int out_dtype, in
 int pg_op_token_mean(const float* x, float* out, int n_images, void* stream);
 /* fp32 -> fp16/bf16 (round to nearest even; fp16 saturates), n elements. */
 int pg_op_cast_f32(const float* x, void* y, int out_dtype, int64_t n, void* stream);
+/* Exact-mode building blocks (csrc/precise.hip).  A "triple" of an fp32 row of `cols` values is the fp16 row
+ * [hi | lo | hi * 2^-8] of 3 * cols values (hi = fp16(x), lo = fp16(x - hi)); multiplied by weight rows [Wh | Wh | (W - Wh) * 2^8]
+ * through pg_op_gemm16 (epi 2 / 3 / 4, K = 3 * cols) it yields the fp32-grade product.
+ *   pg_op_x3_split      x fp32 (rows,cols) -> triple (rows, 3 cols); gelu != 0: through QuickGELU first (expf, IEEE division)
+ *   pg_op_x3_layernorm  LayerNorm(x fp32 (rows,1024)) -> triple (rows, 3072)
+ *   pg_op_attention_f32 fused QKV fp32 (n_images*577, 3072), Q NOT pre-scaled -> softmax(q k^T / 8) v, fp32 (n_images*577, 1024) */
+int pg_op_x3_split(const float* x, void* y3, int64_t rows, int cols, int gelu, void* stream);
+int pg_op_x3_layernorm(const float* x, const float* gamma, const float* beta, void* y3, int64_t rows, float eps, void* stream);
+int pg_op_attention_f32(const float* qkv, float* out, int n_images, void* stream);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,7 @@ class PigeonHipError(RuntimeError):
 class VitCfg(C.Structure):
     _fields_ = [("layers", C.c_int32), ("image_size", C.c_int32), ("patch", C.c_int32), ("hidden", C.c_int32),
                 ("heads", C.c_int32), ("mlp", C.c_int32), ("ln_eps", C.c_float), ("max_chunk", C.c_int32),
-                ("mma_dtype", C.c_int32)]
+                ("mma_dtype", C.c_int32), ("precise", C.c_int32)]
 
 
 class Bank(C.Structure):
@@ -44,6 +44,8 @@ SIGNATURES = {
     "pg_vit_workspace_bytes": (_I, [_P, _I, C.POINTER(_SZ)]),
     "pg_vit_forward": (_I, [_P, _P, _I, _I, _P, _P, _SZ, _P]),
     "pg_vit_forward_hidden": (_I, [_P, _P, _I, _I, _P, _P, _P, _SZ, _P]),
+    "pg_vit_precise_workspace_bytes": (_I, [_P, _I, C.POINTER(_SZ)]),
+    "pg_vit_forward_precise": (_I, [_P, _P, _I, _I, _P, _P, _P, _SZ, _P]),
     "pg_vit_destroy": (_I, [_P]),
     "pg_vit_mma_dtype": (_I, [_P]),
     "pg_vit_profile_enable": (_I, [_P, _I]),
@@ -72,6 +74,7 @@ SIGNATURES = {
     "pg_haversine_pairs": (_I, [_P, _P, _I, _I64, _P, _P]),
     "pg_smooth_labels": (_I, [_P, _I, _I, _D, _P, _P]),
     "pg_head_forward": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "pg_head_margin": (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
     "pg_refine_forward": (_I, [C.POINTER(Bank), _P, _I, _I, _P, _P, _P, _I, _I, _F, _D, _P, _P, _P, _P, _P]),
     "pg_op_gemm16": (_I, [_I, _P, _I64, _P, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _P, _I, _P]),
     "pg_op_gemm16_ld": (_I, [_I, _P, _I64, _P, _I64, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _P, _I, _P]),
@@ -84,6 +87,9 @@ SIGNATURES = {
     "pg_op_im2col": (_I, [_P, _I, _P, _I, _I, _P]),
     "pg_op_token_mean": (_I, [_P, _P, _I, _P]),
     "pg_op_cast_f32": (_I, [_P, _P, _I, _I64, _P]),
+    "pg_op_x3_split": (_I, [_P, _P, _I64, _I, _I, _P]),
+    "pg_op_x3_layernorm": (_I, [_P, _P, _P, _P, _I64, _F, _P]),
+    "pg_op_attention_f32": (_I, [_P, _P, _I, _P]),
 }
 
 _lib = None

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libpigeon_hip.so")
 # the product library: production kernels only
-SOURCES = ["vit.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_pp6.hip", "gemm_tail.hip", "attention.hip", "rowops.hip",
+SOURCES = ["vit.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_pp6.hip", "gemm_tail.hip", "attention.hip", "rowops.hip", "precise.hip",
            "preprocess.hip", "geo_proto.hip", "head.hip", "refine.hip", "comm.hip"]
 # additionally in the tools build (--dev): experimental kernel generations kept for A/B work (variant 64, gemm_w4.hip)
 DEV_SOURCES = ["gemm_w4.hip"]

@@ -51,6 +51,8 @@ class HipCLIPVisionModel(torch.nn.Module):
         self._enc: Optional[hip_ops.VitEncoder] = None
         self._enc_device = None
         self._max_chunk = max_chunk
+        # exact mode (`embed_precise`): the encoder additionally packs the split-fp16 weight copy (3x the 16-bit weight memory)
+        self._precise = os.environ.get("PIGEON_EXACT_TOP1", "0") not in ("", "0")
         self._dummy = torch.nn.Parameter(torch.zeros(1), requires_grad=False)   # lets .to()/is_cuda work
 
     # ---- nn.Module protocol over the plain weight dict ----
@@ -78,9 +80,21 @@ class HipCLIPVisionModel(torch.nn.Module):
         if self._enc is None or self._enc_device != idx:
             if self._enc is not None:
                 self._enc.close()
-            self._enc = hip_ops.VitEncoder(self._sd, device=idx, max_chunk=self._max_chunk)
+            self._enc = hip_ops.VitEncoder(self._sd, device=idx, max_chunk=self._max_chunk, precise=self._precise)
             self._enc_device = idx
         return self._enc
+
+    def enable_precise(self, on: bool = True):
+        """Make `embed_precise` available (the packed encoder is rebuilt with the split-weight copy on next use)."""
+        if bool(on) != self._precise:
+            self._precise = bool(on)
+            self._weights_changed()
+
+    def embed_precise(self, pixel_values: Tensor) -> Tensor:
+        """The exact mode of `embed`: near-fp32 arithmetic (pg_vit_forward_precise), ~5x the time per image."""
+        self.enable_precise(True)
+        pixel_values = _to_device_pixels(pixel_values, self._dummy.device)
+        return self._encoder(pixel_values.device).forward_precise(pixel_values)
 
     def embed(self, pixel_values: Tensor) -> Tensor:
         pixel_values = _to_device_pixels(pixel_values, self._dummy.device)

@@ -169,3 +169,70 @@ extern "C" int pg_head_forward(const float* emb, int B, int P, const float* W, c
     hipLaunchKernelGGL(head_row_kernel, dim3(B), dim3(256), lds, s, logits, C, k, centroids, topk_val, topk_idx, argmax, pred_llh);
     return pg_check_launch("head_row");
 }
+
+// ---- certainty of the top-1 (round 4) ----------------------------------------------------------------------------------------
+// margin[b]  = logit(top-1) - logit(top-2) of row b (value desc, index asc: the same order as the selection above);
+// sens[b]    = |mean_p emb[b]|_2 * |W[top1] - W[top2]|_2 / sqrt(1024): the size of the margin change a unit RELATIVE error of the
+//              embedding in a random direction causes.  A caller holding a bound eps on the encoder's relative embedding error
+//              (pigeon_amd/super_guessr.py: calibrated against the reference fixtures) calls the top-1 CERTAIN when
+//              margin > kappa * eps * sens, and re-encodes the rest in the exact mode (pg_vit_forward_precise).
+// One block per row; C == 1: margin = +inf, sens = 0, top2 = top1.
+__global__ __launch_bounds__(256) void head_margin_kernel(const float* __restrict__ logits, int C, const float* __restrict__ emb, int P,
+                                                          const float* __restrict__ W, float* __restrict__ margin,
+                                                          float* __restrict__ sens, int64_t* __restrict__ top2) {
+    __shared__ ValIdx red[4];
+    __shared__ float redf[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* row = logits + (int64_t)b * C;
+    ValIdx b1; b1.v = -FLT_MAX; b1.i = 0x7fffffff;
+    bool any = false;
+    for (int c = tid; c < C; c += 256) { const float v = row[c]; if (!any || better(v, c, b1.v, b1.i)) { b1.v = v; b1.i = c; any = true; } }
+    if (!any) { b1.v = -FLT_MAX; b1.i = 0x7fffffff; }
+    const ValIdx t1 = block_argbest(b1, red);
+    ValIdx b2; b2.v = -FLT_MAX; b2.i = 0x7fffffff;
+    any = false;
+    for (int c = tid; c < C; c += 256) {
+        if (c == t1.i) continue;
+        const float v = row[c];
+        if (!any || better(v, c, b2.v, b2.i)) { b2.v = v; b2.i = c; any = true; }
+    }
+    if (!any) { b2.v = -FLT_MAX; b2.i = 0x7fffffff; }
+    __syncthreads();
+    const ValIdx t2 = block_argbest(b2, red);
+    const bool have2 = C > 1 && t2.i >= 0 && t2.i < C;
+    // |mean_p e|^2 and |w1 - w2|^2: thread owns 4 columns
+    float se = 0.f, sw = 0.f;
+    {
+        const int c0 = tid * 4;
+        const float invP = 1.0f / (float)P;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = 0.f;
+            for (int p = 0; p < P; ++p) a += emb[((int64_t)b * P + p) * VIT_HIDDEN + c0 + e];
+            a *= invP;
+            se += a * a;
+            if (have2) { const float d = W[(int64_t)t1.i * VIT_HIDDEN + c0 + e] - W[(int64_t)t2.i * VIT_HIDDEN + c0 + e]; sw += d * d; }
+        }
+    }
+    se = wave_sum(se); sw = wave_sum(sw);
+    __syncthreads();
+    if ((tid & 63) == 0) { redf[tid >> 6] = se; redf[4 + (tid >> 6)] = sw; }
+    __syncthreads();
+    if (tid == 0) {
+        se = (redf[0] + redf[1]) + (redf[2] + redf[3]);
+        sw = (redf[4] + redf[5]) + (redf[6] + redf[7]);
+        margin[b] = have2 ? t1.v - t2.v : INFINITY;
+        sens[b] = have2 ? sqrtf(se) * sqrtf(sw) * (1.0f / 32.0f) : 0.f;
+        if (top2) top2[b] = have2 ? t2.i : t1.i;
+    }
+}
+
+extern "C" int pg_head_margin(const float* logits, int B, int C, const float* emb, int P, const float* W, float* margin, float* sens,
+                              int64_t* top2, void* stream) {
+    if (B < 0) { pg_set_error("head_margin: B = %d", B); return PG_EINVAL; }
+    if (B == 0) return PG_OK;
+    if (!logits || !emb || !W || !margin || !sens) { pg_set_error("head_margin: null pointer argument"); return PG_EINVAL; }
+    if (P < 1 || C < 1) { pg_set_error("head_margin: bad P=%d C=%d", P, C); return PG_EINVAL; }
+    hipLaunchKernelGGL(head_margin_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, C, emb, P, W, margin, sens, top2);
+    return pg_check_launch("head_margin");
+}

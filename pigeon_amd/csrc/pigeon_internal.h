@@ -57,3 +57,8 @@ int pg_rowstat_finalize_launch(const float* statpart, int slots, float* rowstat,
 int pg_count_sat16_launch(const void* buf, int64_t rows, int cols, int64_t ld, int dtype, unsigned long long* counter, hipStream_t s);
 // attention.hip
 int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hipStream_t s);
+// precise.hip (exact mode)
+int pg_x3_ln_launch(const float* x, const float* gamma, const float* beta, void* y3, int64_t rows, float eps, hipStream_t s);
+int pg_x3_split_launch(const float* x, void* y3, int64_t rows, int C, int gelu, hipStream_t s);
+int pg_x3_im2col_launch(const void* pixels, int pix_dtype, void* out3, int n_images, hipStream_t s);
+int pg_attention_f32_launch(const float* qkv, float* out, int n_images, hipStream_t s);

@@ -1,0 +1,265 @@
+// precise.hip -- the kernels of the encoder's EXACT mode (pg_vit_forward_precise, vit.hip): a second, near-fp32 pass over the few
+// panoramas whose geocell top-1 / top-2 logit margin is inside the error band of the 16-bit path (reference
+// models/super_guessr.py:447-459: `torch.argmax(geocell_probs)` is fp32 end to end).
+//
+// Arithmetic.  fp32 everywhere the fast path is fp32 (residual stream, LayerNorm, softmax), and the GEMMs on the SAME persistent
+// fp16 MFMA kernels (gemm_pp.hip, EPI_F32 / EPI_RESID / EPI_PATCH) with every fp32 operand split in two fp16 halves and the three
+// significant partial products laid side by side along K:
+//     x = hi + lo,  W = Wh + Wl          (hi = fp16(x), lo = fp16(x - hi): 22 significant bits together)
+//     x . W  ~=  hi.Wh + lo.Wh + hi.Wl   (lo.Wl ~ 2^-24 of the product: dropped)
+//     A' = [ hi | lo | hi * 2^-8 ]   (row of 3K fp16),   W' = [ Wh | Wh | Wl * 2^8 ]   (row of 3K fp16)
+// so one K' = 3K GEMM with fp32 accumulation delivers the fp32-grade product (the 2^8 keeps Wl -- ~2^-12 |W| ~ 5e-6 for
+// |W| ~ 0.02 -- out of fp16's subnormal range; lo needs no scale: its absolute error is bounded by the subnormal quantum 2^-24).
+// 3x the MFMA work of the fast path per image, 1/5 of what fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak) would cost.
+// Attention (8.6 % of the FLOPs) runs in plain fp32 on that fp32 MFMA: attention_f32_kernel below.
+//
+// Kernels here (all HBM-bound streaming except attention):
+//   im2col_x3_kernel   pixels (n,3,336,336) -> patch matrix triple [576 n][3 * 640] fp16
+//   ln_x3_kernel       LayerNorm of fp32 rows -> triple [M][3 * 1024]
+//   split_x3_kernel    fp32 [M][C] (optionally through QuickGELU) -> triple [M][3 * C]
+//   attention_f32_kernel  fp32 QKV [M][3072] -> fp32 O [M][1024], softmax(q k^T / 8) v per (image, head)
+#include "common.h"
+#include "pigeon_internal.h"
+
+#define X3_SHIFT_DOWN 0.00390625f          // 2^-8 on the activation side ...
+#define X3_SHIFT_UP 256.0f                 // ... 2^8 on the weight side (vit.hip packs the weights with it)
+
+struct X3 { uint16_t hi, lo, hs; };
+__device__ __forceinline__ X3 x3_split(float v) {
+    X3 r;
+    r.hi = f32_to_f16_bits(v);                                   // RNE, saturating at +-65504
+    const float hf = f16_bits_to_f32(r.hi);
+    r.lo = __builtin_bit_cast(uint16_t, (_Float16)(v - hf));     // exact difference, |lo| <= ulp16(v) / 2
+    r.hs = __builtin_bit_cast(uint16_t, (_Float16)(hf * X3_SHIFT_DOWN));
+    return r;
+}
+// 4 consecutive columns c..c+3 of logical width C -> the three 8-byte pieces of the triple row
+__device__ __forceinline__ void x3_store4(uint16_t* row, int C, int c, const f32x4& v) {
+    X3 a = x3_split(v[0]), b = x3_split(v[1]), d = x3_split(v[2]), e = x3_split(v[3]);
+    u32x2 hi = {(uint32_t)a.hi | ((uint32_t)b.hi << 16), (uint32_t)d.hi | ((uint32_t)e.hi << 16)};
+    u32x2 lo = {(uint32_t)a.lo | ((uint32_t)b.lo << 16), (uint32_t)d.lo | ((uint32_t)e.lo << 16)};
+    u32x2 hs = {(uint32_t)a.hs | ((uint32_t)b.hs << 16), (uint32_t)d.hs | ((uint32_t)e.hs << 16)};
+    *(u32x2*)(row + c) = hi;
+    *(u32x2*)(row + C + c) = lo;
+    *(u32x2*)(row + 2 * C + c) = hs;
+}
+
+// ---- LayerNorm -> triple; one wave per 1024-float row (layernorm_kernel's arithmetic, rowops.hip) ------------------------------
+__global__ __launch_bounds__(256) void ln_x3_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, uint16_t* __restrict__ y, int64_t rows, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * VIT_HIDDEN;
+    f32x4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *(const f32x4*)(xr + i * 256 + lane * 4);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) * (1.0f / VIT_HIDDEN);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / VIT_HIDDEN) + eps);
+    uint16_t* yr = y + row * (3 * VIT_HIDDEN);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = i * 256 + lane * 4;
+        const f32x4 g4 = *(const f32x4*)(gamma + c);
+        const f32x4 b4 = *(const f32x4*)(beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
+        x3_store4(yr, VIT_HIDDEN, c, o);
+    }
+}
+int pg_x3_ln_launch(const float* x, const float* gamma, const float* beta, void* y3, int64_t rows, float eps, hipStream_t s) {
+    if (rows <= 0) return PG_OK;
+    hipLaunchKernelGGL(ln_x3_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, gamma, beta, (uint16_t*)y3, rows, eps);
+    return pg_check_launch("ln_x3");
+}
+
+// ---- fp32 [rows][C] -> triple [rows][3C], optionally through QuickGELU x * sigmoid(1.702 x) (modeling_clip.py QuickGELUActivation)
+// with the accurate expf and an IEEE division (the fast path's v_exp / v_rcp forms are good to ~1e-6 relative, not to the last ulp)
+template <bool GELU>
+__global__ __launch_bounds__(256) void split_x3_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t rows, int C) {
+    const int64_t vec_per_row = C / 4, total = rows * vec_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / vec_per_row;
+        const int c = (int)(i - r * vec_per_row) * 4;
+        f32x4 v = *(const f32x4*)(x + r * C + c);
+        if (GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-1.702f * v[e]));
+        }
+        x3_store4(y + r * (3 * (int64_t)C), C, c, v);
+    }
+}
+int pg_x3_split_launch(const float* x, void* y3, int64_t rows, int C, int gelu, hipStream_t s) {
+    if (rows <= 0) return PG_OK;
+    if (C % 4) { pg_set_error("split_x3: C must be a multiple of 4"); return PG_EINVAL; }
+    int64_t blocks = (rows * (C / 4) + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (gelu) hipLaunchKernelGGL(split_x3_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, x, (uint16_t*)y3, rows, C);
+    else hipLaunchKernelGGL(split_x3_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, x, (uint16_t*)y3, rows, C);
+    return pg_check_launch("split_x3");
+}
+
+// ---- im2col -> triple [576 n][3 * 640]; k order == Conv2d weight [1024,3,14,14] flattened, columns 588..639 zero ----------------
+template <typename PIX, int PIXKIND>   // PIXKIND 0 fp32, 1 bf16 bits, 2 fp16 bits
+__global__ __launch_bounds__(256) void im2col_x3_kernel(const PIX* __restrict__ pix, uint16_t* __restrict__ out) {
+    const int img = blockIdx.x / 24, py = blockIdx.x % 24;
+    const PIX* src = pix + (int64_t)img * 3 * VIT_IMG * VIT_IMG;
+    uint16_t* dst = out + ((int64_t)img * VIT_PATCHES + py * 24) * (3 * VIT_PATCH_KPAD);
+    for (int idx = threadIdx.x; idx < 42 * VIT_IMG; idx += 256) {
+        const int line = idx / VIT_IMG, xcol = idx - line * VIT_IMG;   // line = c*14 + ky
+        const int c = line / 14, ky = line - c * 14;
+        const int px = xcol / 14, kx = xcol - px * 14;
+        const PIX raw = src[((int64_t)c * VIT_IMG + py * 14 + ky) * VIT_IMG + xcol];
+        float v;
+        if (PIXKIND == 0) v = (float)raw;
+        else if (PIXKIND == 2) v = f16_bits_to_f32((uint16_t)raw);
+        else v = bf16_bits_to_f32((uint16_t)raw);
+        const X3 t = x3_split(v);
+        uint16_t* d = dst + px * (3 * VIT_PATCH_KPAD) + c * 196 + ky * 14 + kx;
+        d[0] = t.hi; d[VIT_PATCH_KPAD] = t.lo; d[2 * VIT_PATCH_KPAD] = t.hs;
+    }
+    const int pad = VIT_PATCH_KPAD - VIT_PATCH_K;
+    for (int idx = threadIdx.x; idx < 24 * 3 * pad; idx += 256) {
+        const int px = idx / (3 * pad), rem = idx % (3 * pad), seg = rem / pad, k = rem % pad;
+        dst[px * (3 * VIT_PATCH_KPAD) + seg * VIT_PATCH_KPAD + VIT_PATCH_K + k] = 0;
+    }
+}
+int pg_x3_im2col_launch(const void* pixels, int pix_dtype, void* out3, int n_images, hipStream_t s) {
+    if (n_images <= 0) return PG_OK;
+    dim3 grid(n_images * 24), block(256);
+    if (pix_dtype == PG_DTYPE_F32) hipLaunchKernelGGL((im2col_x3_kernel<float, 0>), grid, block, 0, s, (const float*)pixels, (uint16_t*)out3);
+    else if (pix_dtype == PG_DTYPE_BF16) hipLaunchKernelGGL((im2col_x3_kernel<uint16_t, 1>), grid, block, 0, s, (const uint16_t*)pixels, (uint16_t*)out3);
+    else if (pix_dtype == PG_DTYPE_F16) hipLaunchKernelGGL((im2col_x3_kernel<uint16_t, 2>), grid, block, 0, s, (const uint16_t*)pixels, (uint16_t*)out3);
+    else { pg_set_error("im2col_x3: unsupported pixel dtype %d", pix_dtype); return PG_EINVAL; }
+    return pg_check_launch("im2col_x3");
+}
+
+// ---- fp32 attention on v_mfma_f32_32x32x2_f32 ------------------------------------------------------------------------------------
+// Block = 4 waves = 128 queries of one (image, head); 5 blocks per (image, head).  A wave owns 32 queries.  K / V stream through
+// LDS in 32-key tiles (double buffered, next tile's global loads in flight during the MFMAs).
+//   S^T[key][query] = K . Q^T      A = K tile (lane: key l%32, d = 2t + l/32 from LDS, row stride 66 floats: conflict-free),
+//                                  B = Q^T (32 registers per lane, loaded once: Q[query l%32][2t + l/32], scaled by 1/8)
+//   accumulator layout of 32x32: lane holds query l%32 and keys 8j + 4(l/32) + i (register 4j + i) -> a lane owns ONE query:
+//   row max / sum are in-lane over 16 keys + one exchange with lane^32.
+//   O^T[d][query] += V^T . P^T     B = the lane's own probability register (key 8j + 4(l/32) + i of query l%32 -- exactly the
+//                                  k index the B operand of step (j,i) wants from this lane), A = V[that key][d = l%32 (+32)]
+//                                  from LDS (row stride 72 floats: the two lane halves land in different banks).
+// Online softmax in base 2 on s * log2(e) (v_exp_f32; <= 1 ulp), keys past token 576 masked to -inf.
+#define AF_KS 66
+#define AF_VS 72
+typedef __attribute__((ext_vector_type(16))) float af16;
+
+__global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n_images) {
+    __shared__ float Ks[2][32 * AF_KS];
+    __shared__ float Vs[2][32 * AF_VS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qb = blockIdx.x % 5, head = (blockIdx.x / 5) % VIT_HEADS, img = blockIdx.x / (5 * VIT_HEADS);
+    const int half = lane >> 5, l32 = lane & 31;
+    const int64_t row0 = (int64_t)img * VIT_TOKENS;
+    const float* base = qkv + row0 * (3 * VIT_HIDDEN) + head * VIT_HEAD_DIM;
+    const int q = qb * 128 + wave * 32 + l32;
+    const bool q_ok = q < VIT_TOKENS;
+    const bool wave_ok = qb * 128 + wave * 32 < VIT_TOKENS;
+    // Q^T operand registers: Q[q][2t + half] * (1/8) * log2(e)  (the 1/8 is exact; one rounding for log2(e))
+    float qr[32];
+    {
+        const float* qp = base + (int64_t)(q_ok ? q : 0) * (3 * VIT_HIDDEN) + half;
+#pragma unroll
+        for (int t = 0; t < 32; ++t) qr[t] = q_ok ? (qp[2 * t] * 0.125f) * 1.4426950408889634f : 0.f;
+    }
+    // cooperative tile loads: thread -> key tid/16 (+16), d4 = (tid%16)*4
+    const int lk = tid >> 4, ld4 = (tid & 15) * 4;
+    f32x4 pk[2], pv[2];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int key = t * 32 + lk + 16 * h;
+            if (key < VIT_TOKENS) {
+                const float* p = base + (int64_t)key * (3 * VIT_HIDDEN) + ld4;
+                pk[h] = *(const f32x4*)(p + VIT_HIDDEN);
+                pv[h] = *(const f32x4*)(p + 2 * VIT_HIDDEN);
+            } else { pk[h] = f32x4{0.f, 0.f, 0.f, 0.f}; pv[h] = pk[h]; }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float* kd = &Ks[buf][(lk + 16 * h) * AF_KS + ld4];
+            kd[0] = pk[h][0]; kd[1] = pk[h][1]; kd[2] = pk[h][2]; kd[3] = pk[h][3];   // stride 66: 8-byte aligned only
+            *(f32x4*)&Vs[buf][(lk + 16 * h) * AF_VS + ld4] = pv[h];
+        }
+    };
+    af16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m = -INFINITY, lsum = 0.f;
+    const int NT = (VIT_TOKENS + 31) / 32;     // 19
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < NT; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < NT) load_tile(t + 1);
+        if (wave_ok) {
+            af16 sc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+            const float* kp = &Ks[buf][l32 * AF_KS + half];
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * kk], qr[kk], sc, 0, 0, 0);
+            if (t == NT - 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                    if (key >= VIT_TOKENS) sc[r] = -INFINITY;
+                }
+            }
+            float tm = sc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tm = fmaxf(tm, sc[r]);
+            tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+            const float mn = fmaxf(m, tm);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);      // m = -inf on the first tile -> 0
+            m = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sc[r] = __builtin_amdgcn_exp2f(sc[r] - mn); ps += sc[r]; }
+            lsum = lsum * alpha + ps;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            const float* vp = &Vs[buf][(4 * half) * AF_VS + l32];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int krow = 8 * (r >> 2) + (r & 3);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[krow * AF_VS], sc[r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[krow * AF_VS + 32], sc[r], o1, 0, 0, 0);
+            }
+        }
+        if (t + 1 < NT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    if (!q_ok) return;
+    lsum += __shfl_xor(lsum, 32, 64);
+    float* op = out + (row0 + q) * VIT_HIDDEN + head * VIT_HEAD_DIM + 4 * half;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 a = {o0[4 * j] / lsum, o0[4 * j + 1] / lsum, o0[4 * j + 2] / lsum, o0[4 * j + 3] / lsum};
+        f32x4 b = {o1[4 * j] / lsum, o1[4 * j + 1] / lsum, o1[4 * j + 2] / lsum, o1[4 * j + 3] / lsum};
+        *(f32x4*)(op + 8 * j) = a;
+        *(f32x4*)(op + 32 + 8 * j) = b;
+    }
+}
+int pg_attention_f32_launch(const float* qkv, float* out, int n_images, hipStream_t s) {
+    if (n_images <= 0) return PG_OK;
+    hipLaunchKernelGGL(attention_f32_kernel, dim3(n_images * VIT_HEADS * 5), dim3(256), 0, s, qkv, out, n_images);
+    return pg_check_launch("attention_f32");
+}

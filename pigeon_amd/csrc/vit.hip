@@ -127,6 +127,10 @@ struct LayerW {
     // LayerNorm folded into the following GEMM (cfg ln_fold): wqkv / w1 then hold gamma-scaled weights, bqkv / b1 hold
     // beta.W^T + b, and sqkv / s1 the row sums of the ROUNDED folded weights
     float *sqkv = nullptr, *s1 = nullptr;
+    // exact mode (cfg.precise): split-fp16 triples [N][3K] = [Wh | Wh | (W - Wh) * 2^8] of the UNFOLDED weights (precise.hip) and the
+    // raw fp32 biases of the two GEMMs whose fast-path bias carries the LayerNorm fold
+    uint16_t *wqkv3 = nullptr, *wo3 = nullptr, *w13 = nullptr, *w23 = nullptr;
+    float *bqkv_raw = nullptr, *b1_raw = nullptr;
 };
 
 struct pg_vit {
@@ -137,6 +141,7 @@ struct pg_vit {
     std::map<std::string, std::vector<float>> host;      // staged fp32 parameters until finalize
     std::vector<void*> allocs;
     uint16_t* wpatch = nullptr;                           // [1024][640] bf16 (K zero padded)
+    uint16_t* wpatch3 = nullptr;                          // exact mode: [1024][3 * 640] split-fp16 triple
     float *cls = nullptr, *pos = nullptr, *preg = nullptr, *preb = nullptr;
     std::vector<LayerW> layers;
     // two half-batches on two HIP streams (env PIGEON_VIT_STREAMS=2): the tail of a persistent GEMM of one half -- a partial last
@@ -274,6 +279,21 @@ static void fold_ln(int dt, const float* W, const float* b, const float* gamma, 
     }
 }
 
+// exact mode (precise.hip): row n of W [N][K] -> [Wh | Wh | fp16((W - Wh) * 2^8)], K zero padded to Kpad
+static void pack_x3(const float* W, size_t N, size_t K, size_t Kpad, std::vector<uint16_t>& w3) {
+    w3.assign(N * 3 * Kpad, 0);
+    for (size_t n = 0; n < N; ++n) {
+        uint16_t* r = w3.data() + n * 3 * Kpad;
+        for (size_t k = 0; k < K; ++k) {
+            const float w = W[n * K + k];
+            const uint16_t hb = host_f16(w);
+            const float hf = host_uncvt(PG_DTYPE_F16, hb);
+            r[k] = hb; r[Kpad + k] = hb;
+            r[2 * Kpad + k] = host_f16((w - hf) * 256.0f);
+        }
+    }
+}
+
 static int need(pg_vit* h, const std::string& k, size_t n, const std::vector<float>** out) {
     auto it = h->host.find(k);
     if (it == h->host.end()) { pg_set_error("vit_finalize: missing parameter %s", k.c_str()); return PG_ESTATE; }
@@ -314,6 +334,7 @@ extern "C" int pg_vit_finalize(pg_vit* h) {
         for (size_t n = 0; n < D; ++n)
             for (size_t k = 0; k < VIT_PATCH_K; ++k) w[n * VIT_PATCH_KPAD + k] = host_cvt(dt, (*p)[n * VIT_PATCH_K + k]);
         RC(upload_bf16(h, w, &h->wpatch));
+        if (h->cfg.precise) { std::vector<uint16_t> w3; pack_x3(p->data(), D, VIT_PATCH_K, VIT_PATCH_KPAD, w3); RC(upload_bf16(h, w3, &h->wpatch3)); }
     }
     RC(need(h, "embeddings.class_embedding", D, &p));                 RC(upload_f32(h, p->data(), D, &h->cls));
     RC(need(h, "embeddings.position_embedding.weight", VIT_TOKENS * D, &p)); RC(upload_f32(h, p->data(), VIT_TOKENS * D, &h->pos));
@@ -333,6 +354,11 @@ extern "C" int pg_vit_finalize(pg_vit* h) {
             std::vector<float> wf(3 * D * D), b(3 * D);
             for (size_t i = 0; i < D * D; ++i) { wf[i] = (*wq)[i]; wf[D * D + i] = (*wk)[i]; wf[2 * D * D + i] = (*wv)[i]; }
             for (size_t i = 0; i < D; ++i) { b[i] = (*bq)[i]; b[D + i] = (*bk)[i]; b[2 * D + i] = (*bv)[i]; }
+            if (h->cfg.precise) {
+                std::vector<uint16_t> w3; pack_x3(wf.data(), 3 * D, D, D, w3);
+                RC(upload_bf16(h, w3, &L.wqkv3));
+                RC(upload_f32(h, b.data(), 3 * D, &L.bqkv_raw));
+            }
             if (h->ln_fold) {
                 std::vector<uint16_t> w; std::vector<float> cs, cb;
                 fold_ln(dt, wf.data(), b.data(), g1->data(), be1->data(), 3 * D, D, w, cs, cb);
@@ -371,6 +397,18 @@ extern "C" int pg_vit_finalize(pg_vit* h) {
             RC(up_w(pre + "mlp.fc1.weight", F * D, &L.w1));        RC(up_f(pre + "mlp.fc1.bias", F, &L.b1));
         }
         RC(up_w(pre + "mlp.fc2.weight", D * F, &L.w2));            RC(up_f(pre + "mlp.fc2.bias", D, &L.b2));
+        if (h->cfg.precise) {
+            auto up_w3 = [&](const std::string& k, size_t N, size_t K, uint16_t** dst) -> int {
+                const std::vector<float>* q;
+                RC(need(h, k, N * K, &q));
+                std::vector<uint16_t> w3; pack_x3(q->data(), N, K, K, w3);
+                return upload_bf16(h, w3, dst);
+            };
+            RC(up_w3(pre + "self_attn.out_proj.weight", D, D, &L.wo3));
+            RC(up_w3(pre + "mlp.fc1.weight", F, D, &L.w13));
+            RC(up_w3(pre + "mlp.fc2.weight", D, F, &L.w23));
+            RC(up_f(pre + "mlp.fc1.bias", F, &L.b1_raw));
+        }
         RC(up_f(pre + "layer_norm1.weight", D, &L.ln1g));          RC(up_f(pre + "layer_norm1.bias", D, &L.ln1b));
         RC(up_f(pre + "layer_norm2.weight", D, &L.ln2g));          RC(up_f(pre + "layer_norm2.bias", D, &L.ln2b));
     }
@@ -559,6 +597,79 @@ extern "C" int pg_vit_forward(pg_vit* h, const void* pixels, int pix_dtype, int 
     return pg_vit_forward_hidden(h, pixels, pix_dtype, n_images, emb_out, nullptr, workspace, workspace_bytes, stream);
 }
 
+// ------------------------------------------------------------------------------------------------ exact mode
+// pg_vit_forward_precise: the same encoder in near-fp32 arithmetic (precise.hip: split-fp16 GEMM operands on the persistent MFMA
+// kernels, fp32 LayerNorm / attention / QuickGELU / residual), for the panoramas whose top-1 margin the 16-bit path cannot decide.
+// Workspace per token row: X fp32 4 KB | T3 triple of a 1024-wide row 6 KB | F fp32 QKV (12 KB) / fc1 (16 KB) | G3 triple of the
+// 4096-wide activation 24 KB (the im2col triple and the fp32 attention output live there too) = 50 KB; chunks of <= 64 images.
+#define PG_PRECISE_CHUNK 64
+static size_t precise_ws_bytes_for(int chunk) {
+    const size_t M = (size_t)chunk * VIT_TOKENS;
+    return align_up(M * VIT_HIDDEN * 4, 256) + align_up(M * 3 * VIT_HIDDEN * 2, 256) + align_up(M * VIT_MLP * 4, 256) +
+           align_up(M * 3 * VIT_MLP * 2, 256) + 256;
+}
+extern "C" int pg_vit_precise_workspace_bytes(const pg_vit* h, int n_images, size_t* bytes) {
+    if (!h || !bytes || n_images < 0) { pg_set_error("vit_precise_workspace_bytes: bad argument"); return PG_EINVAL; }
+    const int chunk = n_images < PG_PRECISE_CHUNK ? n_images : PG_PRECISE_CHUNK;
+    *bytes = precise_ws_bytes_for(chunk > 0 ? chunk : 1);
+    return PG_OK;
+}
+
+static int vit_precise_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n, float* emb_out, float* hidden_out, char* ws,
+                             hipStream_t s) {
+    const int64_t M = (int64_t)n * VIT_TOKENS;
+    const int D = VIT_HIDDEN, F = VIT_MLP;
+    float* X = (float*)ws;
+    uint16_t* T3 = (uint16_t*)(ws + align_up((size_t)M * D * 4, 256));
+    float* Fb = (float*)((char*)T3 + align_up((size_t)M * 3 * D * 2, 256));
+    uint16_t* G3 = (uint16_t*)((char*)Fb + align_up((size_t)M * F * 4, 256));
+    float* O = (float*)G3;                                    // fp32 attention output, dead before G3 is written
+    const float eps = h->cfg.ln_eps;
+    const int dt = PG_DTYPE_F16, V = 36;                      // the 256 x 256 persistent kernel takes every epilogue used here
+    RC(pg_x3_im2col_launch(pixels, pix_dtype, G3, n, s));
+    RC(pg_gemm_launch(dt, G3, 3 * VIT_PATCH_KPAD, h->wpatch3, 3 * VIT_PATCH_KPAD, nullptr, X, D, n * VIT_PATCHES, D, 3 * VIT_PATCH_KPAD,
+                      EPI_PATCH, 1.f, 0, h->pos, V, s));
+    RC(pg_preln_launch(X, h->cls, h->pos, h->preg, h->preb, M, eps, s));
+    for (int l = 0; l < h->cfg.layers; ++l) {
+        const LayerW& L = h->layers[l];
+        RC(pg_x3_ln_launch(X, L.ln1g, L.ln1b, T3, M, eps, s));
+        RC(pg_gemm_launch(dt, T3, 3 * D, L.wqkv3, 3 * D, L.bqkv_raw, Fb, 3 * D, (int)M, 3 * D, 3 * D, EPI_F32, 1.f, 0, nullptr, V, s));
+        RC(pg_attention_f32_launch(Fb, O, n, s));
+        RC(pg_x3_split_launch(O, T3, M, D, 0, s));
+        RC(pg_gemm_launch(dt, T3, 3 * D, L.wo3, 3 * D, L.bo, X, D, (int)M, D, 3 * D, EPI_RESID, 1.f, 0, nullptr, V, s));
+        RC(pg_x3_ln_launch(X, L.ln2g, L.ln2b, T3, M, eps, s));
+        RC(pg_gemm_launch(dt, T3, 3 * D, L.w13, 3 * D, L.b1_raw, Fb, F, (int)M, F, 3 * D, EPI_F32, 1.f, 0, nullptr, V, s));
+        RC(pg_x3_split_launch(Fb, G3, M, F, 1, s));
+        RC(pg_gemm_launch(dt, G3, 3 * F, L.w23, 3 * F, L.b2, X, D, (int)M, D, 3 * F, EPI_RESID, 1.f, 0, nullptr, V, s));
+    }
+    RC(pg_token_mean_launch(X, emb_out, n, s));
+    if (hidden_out) PG_HIP(hipMemcpyAsync(hidden_out, X, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
+    return PG_OK;
+}
+
+extern "C" int pg_vit_forward_precise(pg_vit* h, const void* pixels, int pix_dtype, int n_images, float* emb_out, float* hidden_out,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h) { pg_set_error("vit_forward_precise: null handle"); return PG_EINVAL; }
+    if (!h->finalized) { pg_set_error("vit_forward_precise: handle not finalized"); return PG_ESTATE; }
+    if (!h->cfg.precise) { pg_set_error("vit_forward_precise: the handle was created without cfg.precise (no split-weight copy)"); return PG_ESTATE; }
+    if (n_images < 0) { pg_set_error("vit_forward_precise: n_images = %d", n_images); return PG_EINVAL; }
+    if (n_images == 0) return PG_OK;
+    if (!pixels || !emb_out || !workspace) { pg_set_error("vit_forward_precise: null argument"); return PG_EINVAL; }
+    if (pix_dtype != PG_DTYPE_F32 && pix_dtype != PG_DTYPE_BF16 && pix_dtype != PG_DTYPE_F16) { pg_set_error("vit_forward_precise: bad pixel dtype"); return PG_EINVAL; }
+    size_t needb = 0;
+    pg_vit_precise_workspace_bytes(h, n_images, &needb);
+    if (workspace_bytes < needb) { pg_set_error("vit_forward_precise: workspace %zu < required %zu bytes", workspace_bytes, needb); return PG_ENOMEM; }
+    if (((uintptr_t)workspace & 255) != 0) { pg_set_error("vit_forward_precise: workspace must be 256-byte aligned"); return PG_EINVAL; }
+    const size_t esz = pix_dtype == PG_DTYPE_F32 ? 4 : 2;
+    const size_t img_elems = (size_t)3 * VIT_IMG * VIT_IMG;
+    for (int s0 = 0; s0 < n_images; s0 += PG_PRECISE_CHUNK) {
+        const int n = (n_images - s0) < PG_PRECISE_CHUNK ? (n_images - s0) : PG_PRECISE_CHUNK;
+        RC(vit_precise_chunk(h, (const char*)pixels + (size_t)s0 * img_elems * esz, pix_dtype, n, emb_out + (size_t)s0 * VIT_HIDDEN,
+                             hidden_out ? hidden_out + (size_t)s0 * VIT_TOKENS * VIT_HIDDEN : nullptr, (char*)workspace, (hipStream_t)stream));
+    }
+    return PG_OK;
+}
+
 extern "C" int pg_vit_destroy(pg_vit* h) {
     if (!h) return PG_OK;
     for (void* p : h->allocs) (void)hipFree(p);
@@ -695,4 +806,18 @@ extern "C" int pg_op_token_mean(const float* x, float* out, int n_images, void* 
 extern "C" int pg_op_cast_f32(const float* x, void* y, int out_dtype, int64_t n, void* stream) {
     if (!x || !y) { pg_set_error("op_cast_f32: null argument"); return PG_EINVAL; }
     return pg_cast_f32_launch(x, y, out_dtype, n, (hipStream_t)stream);
+}
+
+// exact-mode building blocks (precise.hip), exported for the parity tests
+extern "C" int pg_op_x3_split(const float* x, void* y3, int64_t rows, int cols, int gelu, void* stream) {
+    if (!x || !y3) { pg_set_error("op_x3_split: null argument"); return PG_EINVAL; }
+    return pg_x3_split_launch(x, y3, rows, cols, gelu, (hipStream_t)stream);
+}
+extern "C" int pg_op_x3_layernorm(const float* x, const float* gamma, const float* beta, void* y3, int64_t rows, float eps, void* stream) {
+    if (!x || !gamma || !beta || !y3) { pg_set_error("op_x3_layernorm: null argument"); return PG_EINVAL; }
+    return pg_x3_ln_launch(x, gamma, beta, y3, rows, eps, (hipStream_t)stream);
+}
+extern "C" int pg_op_attention_f32(const float* qkv, float* out, int n_images, void* stream) {
+    if (!qkv || !out) { pg_set_error("op_attention_f32: null argument"); return PG_EINVAL; }
+    return pg_attention_f32_launch(qkv, out, n_images, (hipStream_t)stream);
 }

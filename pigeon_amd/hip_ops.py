@@ -269,8 +269,9 @@ class VitEncoder:
     """
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], device: int = 0, max_chunk: int = 0,
-                 layers: Optional[int] = None, mma_dtype: Optional[str] = None):
-        """mma_dtype: None (library default: fp16, or env PIGEON_MMA_DTYPE=bf16), 'f16' or 'bf16'."""
+                 layers: Optional[int] = None, mma_dtype: Optional[str] = None, precise: bool = False):
+        """mma_dtype: None (library default: fp16, or env PIGEON_MMA_DTYPE=bf16), 'f16' or 'bf16'.
+        precise: also pack the split-fp16 weight copy of the exact mode (`forward_precise`; 3x the 16-bit weight memory)."""
         _lib.require_gpu()
         lib = load()
         keys = [k[len("vision_model."):] if k.startswith("vision_model.") else k for k in state_dict]
@@ -283,7 +284,9 @@ class VitEncoder:
         self.layers = layers
         self.device = device
         pgdt = {None: 0, "f16": _lib.PG_DTYPE_F16, "fp16": _lib.PG_DTYPE_F16, "bf16": _lib.PG_DTYPE_BF16}[mma_dtype]
-        cfg = VitCfg(layers, 336, 14, 1024, 16, 4096, 1e-5, max_chunk, pgdt)
+        cfg = VitCfg(layers, 336, 14, 1024, 16, 4096, 1e-5, max_chunk, pgdt, 1 if precise else 0)
+        self.precise = bool(precise)
+        self._ws_precise = None
         h = C.c_void_p()
         torch.cuda.set_device(device)
         check(lib.pg_vit_create(C.byref(h), device, C.byref(cfg)), "pg_vit_create")
@@ -327,6 +330,30 @@ class VitEncoder:
         return (emb, hid) if return_hidden else emb
 
     __call__ = forward
+
+    def forward_precise(self, pixels: torch.Tensor, return_hidden: bool = False):
+        """The exact mode (pg_vit_forward_precise): same contract as `forward`, near-fp32 arithmetic (split-fp16 GEMM operands,
+        fp32 attention / LayerNorm / QuickGELU), ~5x the time per image.  Needs `precise=True` at construction."""
+        if not self.precise:
+            raise _lib.PigeonHipError("forward_precise: the encoder was built without precise=True (no split-weight copy)")
+        _dev(pixels)
+        if pixels.dim() != 4 or tuple(pixels.shape[1:]) != (3, 336, 336):
+            raise _lib.PigeonHipError(f"pixels must be (N,3,336,336), got {tuple(pixels.shape)}")
+        if pixels.dtype not in _PIXDT:
+            raise _lib.PigeonHipError("pixels must be fp32, fp16 or bf16")
+        n = pixels.shape[0]
+        need = C.c_size_t()
+        check(load().pg_vit_precise_workspace_bytes(self._h, n, C.byref(need)), "pg_vit_precise_workspace_bytes")
+        if self._ws_precise is None or self._ws_precise.numel() < need.value + 256:
+            self._ws_precise = None
+            self._ws_precise = torch.empty(need.value + 256, dtype=torch.uint8, device=f"cuda:{self.device}")
+        ws = self._ws_precise
+        off = (-ws.data_ptr()) % 256
+        emb = torch.empty((n, HIDDEN), dtype=torch.float32, device=pixels.device)
+        hid = torch.empty((n, TOKENS, HIDDEN), dtype=torch.float32, device=pixels.device) if return_hidden else None
+        check(load().pg_vit_forward_precise(self._h, _p(pixels), _PIXDT[pixels.dtype], n, _p(emb), _p(hid),
+                                            C.c_void_p(ws.data_ptr() + off), ws.numel() - off, _stream()), "pg_vit_forward_precise")
+        return (emb, hid) if return_hidden else emb
 
     # ---- per-kernel-class timing for bench.py ----
     def profile_enable(self, on: bool = True, classes=None):
@@ -399,6 +426,56 @@ def head_forward(emb: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, centroi
     check(load().pg_head_forward(_p(emb), B, P, _p(W), _p(bias), _p(centroids), Cn, k, _p(logits), _p(tv), _p(ti),
                                  _p(am), _p(llh), _stream()), "pg_head_forward")
     return dict(logits=logits, topk_values=tv, topk_indices=ti, preds_geocell=am, preds_LLH=llh)
+
+
+def head_margin(logits: torch.Tensor, emb: torch.Tensor, W: torch.Tensor):
+    """Certainty inputs of the top-1 (pg_head_margin): logits (B,C) fp32 as written by head_forward, emb (B,P,1024) or (B,1024),
+    W (C,1024).  Returns (margin (B,) fp32 = logit(top1) - logit(top2), sens (B,) fp32 = |mean_p emb| |W[top1] - W[top2]| / 32,
+    top2 (B,) int64)."""
+    _dev(logits, torch.float32); _dev(emb, torch.float32); _dev(W, torch.float32)
+    B, Cn = logits.shape
+    P = emb.shape[1] if emb.dim() == 3 else 1
+    _shape(emb, "emb", *((B, P, HIDDEN) if emb.dim() == 3 else (B, HIDDEN)))
+    _shape(W, "W", Cn, HIDDEN)
+    margin = torch.empty((B,), dtype=torch.float32, device=logits.device)
+    sens = torch.empty((B,), dtype=torch.float32, device=logits.device)
+    top2 = torch.empty((B,), dtype=torch.int64, device=logits.device)
+    check(load().pg_head_margin(_p(logits), B, Cn, _p(emb), P, _p(W), _p(margin), _p(sens), _p(top2), _stream()), "pg_head_margin")
+    return margin, sens, top2
+
+
+# ----------------------------------------------------------------------------------------- exact-mode building blocks
+def x3_split(x: torch.Tensor, gelu: bool = False) -> torch.Tensor:
+    """fp32 (rows,cols) -> fp16 triple (rows, 3 cols) = [hi | lo | hi 2^-8]; gelu: through QuickGELU first."""
+    _dev(x, torch.float32)
+    rows, cols = x.shape
+    y = torch.empty((rows, 3 * cols), dtype=torch.float16, device=x.device)
+    check(load().pg_op_x3_split(_p(x), _p(y), rows, cols, 1 if gelu else 0, _stream()), "pg_op_x3_split")
+    return y
+
+
+def x3_layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    _dev(x, torch.float32)
+    rows = x.numel() // HIDDEN
+    y = torch.empty((rows, 3 * HIDDEN), dtype=torch.float16, device=x.device)
+    check(load().pg_op_x3_layernorm(_p(x), _p(gamma), _p(beta), _p(y), rows, float(eps), _stream()), "pg_op_x3_layernorm")
+    return y
+
+
+def x3_pack_weight(W: torch.Tensor) -> torch.Tensor:
+    """Host-side mirror of the library's weight triple (vit.hip pack_x3), for the building-block tests: W fp32 (N,K) ->
+    fp16 (N,3K) = [Wh | Wh | (W - Wh) 2^8]."""
+    Wh = W.to(torch.float16)
+    Wl = ((W - Wh.float()) * 256.0).to(torch.float16)
+    return torch.cat([Wh, Wh, Wl], dim=1).contiguous()
+
+
+def attention_f32(qkv: torch.Tensor, n_images: int) -> torch.Tensor:
+    _dev(qkv, torch.float32)
+    _shape(qkv, "qkv", n_images * TOKENS, 3 * HIDDEN)
+    out = torch.empty((n_images * TOKENS, HIDDEN), dtype=torch.float32, device=qkv.device)
+    check(load().pg_op_attention_f32(_p(qkv), _p(out), n_images, _stream()), "pg_op_attention_f32")
+    return out
 
 
 # ----------------------------------------------------------------------------------------- refiner

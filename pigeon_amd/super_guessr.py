@@ -8,6 +8,8 @@ Only the inference branch that evaluation/evaluate.py:42-44 constructs is accele
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import pandas as pd
 import torch
@@ -33,9 +35,29 @@ class SuperGuessr(nn.Module):
         into the HIP encoder on first use.
         One extra keyword, `geocell_path`, overrides config.GEOCELL_PATH(_YFCC) (the reference hard-wires the
         path through its config module, :87-88).
+
+        Certainty of the top-1 (round 4).  The reference's `torch.argmax(geocell_probs)` (:454) is fp32 end to end; this path's
+        embeddings carry the rounding of 16-bit MFMA operands (2.7e-4 relative on default-init weights, 6e-4 on the high-gain
+        `pipeline24_spread` tower), so a panorama whose top-1 / top-2 logit margin is smaller than that error moves the logits may
+        come out with the runner-up cell.  After every forward the model exposes, per sample (ModelOutput keeps its 12 fields):
+          .last_margin   (B,) fp32  logit(top-1) - logit(top-2)
+          .last_bound    (B,) fp32  margin_kappa * rel_tol * |emb| |W[top1] - W[top2]| / sqrt(1024): the margin change a relative
+                                    embedding error of `rel_tol` in a random direction causes, times a safety factor
+          .last_certain  (B,) bool  margin > bound: the reference's argmax is this cell
+          .last_reencoded (n,) int64  the samples the exact mode re-encoded (empty when it is off)
+        Extra keywords: `exact_top1` (default: env PIGEON_EXACT_TOP1=1) -- samples that are not certain are re-encoded FROM THE
+        PIXELS in the encoder's exact mode (pg_vit_forward_precise: split-fp16 GEMM operands, fp32 attention; ~1e-6 relative, ~5x
+        the time per image) and their head outputs recomputed, so that their top-1 is the fp32 one; `margin_rel_tol` (default
+        1e-3 = the embedding tolerance of the contract, 1.5-4x the measured error) and `margin_kappa` (default 4).
         """
         super(SuperGuessr, self).__init__()
         geocell_path = kwargs.pop('geocell_path', None)
+        exact_top1 = kwargs.pop('exact_top1', None)
+        self.exact_top1 = (os.environ.get('PIGEON_EXACT_TOP1', '0') not in ('', '0')) if exact_top1 is None else bool(exact_top1)
+        self.margin_rel_tol = float(kwargs.pop('margin_rel_tol', os.environ.get('PIGEON_MARGIN_REL_TOL', 1e-3)))
+        self.margin_rel_tol_exact = float(kwargs.pop('margin_rel_tol_exact', 2e-5))
+        self.margin_kappa = float(kwargs.pop('margin_kappa', os.environ.get('PIGEON_MARGIN_KAPPA', 4.0)))
+        self.last_margin = self.last_bound = self.last_certain = self.last_reencoded = None
         if len(kwargs) > 0:
             print(f'Not using keyword arguments: {list(kwargs.keys())}')
         if hierarchical or multi_task or heading:
@@ -165,8 +187,10 @@ class SuperGuessr(nn.Module):
                 head_in = layer_input[:, 0].contiguous()                        # :440-441
             else:
                 head_in = layer_input
-            o = hip_ops.head_forward(head_in.contiguous(), self.cell_layer.weight.data, self.cell_layer.bias.data,
+            head_in = head_in.contiguous()
+            o = hip_ops.head_forward(head_in, self.cell_layer.weight.data, self.cell_layer.bias.data,
                                      self.lla_geocells.data, self.num_candidates)          # :447-459
+            embedding = self._certainty(o, head_in, embedding, pixel_values)
             logits = o['logits']
             geocell_preds = o['preds_geocell']
             pred_LLH = o['preds_LLH']
@@ -185,6 +209,38 @@ class SuperGuessr(nn.Module):
             loss = loss_clf
             return ModelOutput(loss, loss_clf, 0, 0, 0, pred_LLH, geocell_preds, None, None, None,
                                geocell_topk, embedding)
+
+    def _certainty(self, o, head_in: Tensor, embedding: Tensor, pixel_values) -> Tensor:
+        """Margin / bound / certain per sample; with exact_top1, re-encode the uncertain samples from their pixels in the
+        encoder's exact mode and overwrite their rows of the head outputs `o` (and of the returned embedding)."""
+        W = self.cell_layer.weight.data
+        margin, sens, _ = hip_ops.head_margin(o['logits'], head_in, W)
+        bound = sens * (self.margin_kappa * self.margin_rel_tol)
+        certain = margin > bound
+        self.last_reencoded = torch.empty((0,), dtype=torch.int64, device=margin.device)
+        if self.exact_top1 and pixel_values is not None and self.base_model is not None and not bool(certain.all()):
+            idx = torch.nonzero(~certain).flatten()
+            P = 4 if self.panorama else 1
+            px = pixel_values.reshape((-1, P, 3, 336, 336))[idx.to(pixel_values.device)].reshape((-1, 3, 336, 336))
+            emb_x = self._encoder().embed_precise(px.to(W.device))
+            emb_x = emb_x.reshape((idx.numel(), P, emb_x.shape[-1])) if self.panorama else emb_x
+            embedding = embedding.clone()
+            embedding[idx] = emb_x
+            if self.panorama:
+                hin = emb_x
+            elif emb_x.dim() == 3 and emb_x.size(1) == 4:
+                hin = emb_x[:, 0].contiguous()
+            else:
+                hin = emb_x
+            o2 = hip_ops.head_forward(hin.contiguous(), W, self.cell_layer.bias.data, self.lla_geocells.data, self.num_candidates)
+            for k in ('logits', 'topk_values', 'topk_indices', 'preds_geocell', 'preds_LLH'):
+                o[k][idx] = o2[k]
+            m2, s2, _ = hip_ops.head_margin(o2['logits'], hin.contiguous(), W)
+            b2 = s2 * (self.margin_kappa * self.margin_rel_tol_exact)
+            margin[idx], bound[idx], certain[idx] = m2, b2, m2 > b2
+            self.last_reencoded = idx
+        self.last_margin, self.last_bound, self.last_certain = margin, bound, certain
+        return embedding
 
     def __str__(self):
         rep = 'SuperGuessr(\n'

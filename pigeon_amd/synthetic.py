@@ -120,6 +120,35 @@ def make_vit_weights_trained_like(seed: int = 21, layers: int = LAYERS) -> Dict[
     return sd
 
 
+def make_vit_weights_spread(seed: int = 31, layers: int = LAYERS, q_bias_std: float = 3.5, k_gain: float = 4.0,
+                            v_gain: float = 4.0, heads_frac: float = 0.25) -> Dict[str, torch.Tensor]:
+    """Random weights whose EMBEDDINGS spread the way a trained tower's do (round 4 fixture `pipeline24_spread`).
+
+    A default-init tower maps every image to nearly the same token mean (pairwise cos-sim 0.94 .. 0.96): every per-token
+    feature of iid pixels concentrates under the 577-token mean, and what is left is the input-independent part the MLPs
+    write.  Trained towers escape that with GLOBAL, input-dependent attention: here a quarter of the heads of every layer
+    (chosen per layer) get a large query BIAS (the query is then nearly the same for every token), a key projection with
+    gain `k_gain` (score spread over the keys ~ q_bias_std * k_gain * 0.144 -> a softmax dominated by the few best-matching
+    tokens of THIS image) and a value projection with gain `v_gain`: each such head writes the value of an input-selected
+    token into every row of the residual stream, which survives the token mean at full strength.  No constant bias is
+    added anywhere on the residual path; biases / LayerNorm parameters are jittered (affine_jitter) so that every term of
+    the kernels is live.  Measured through the real reference on seeded N(0,1) pixels: pairwise cos-sim of the 24-layer
+    embeddings 0.66 .. 0.77 (default init: 0.96).  High-gain attention is also where 16-bit Q / K operands cost the most:
+    tools/precision_sim.py predicts 5.9e-4 relative embedding error for fp16 operands on these weights (2.7e-4 default init).
+    """
+    sd = make_vit_weights(seed=seed, layers=layers, affine_jitter=True)
+    g = torch.Generator().manual_seed(seed + 500)
+    nh = max(1, int(HEADS * heads_frac))
+    for i in range(layers):
+        p = f"encoder.layers.{i}."
+        for h in torch.randperm(HEADS, generator=g)[:nh].tolist():
+            sl = slice(HEAD_DIM * h, HEAD_DIM * (h + 1))
+            sd[p + "self_attn.q_proj.bias"][sl] = torch.empty(HEAD_DIM).normal_(0, q_bias_std, generator=g)
+            sd[p + "self_attn.k_proj.weight"][sl] *= k_gain
+            sd[p + "self_attn.v_proj.weight"][sl] *= v_gain
+    return sd
+
+
 def make_pixels(n_images: int, seed: int = 1234, panorama: bool = False) -> torch.Tensor:
     """Seeded N(0,1) pixels, the statistics of CLIP-normalised images.
 
