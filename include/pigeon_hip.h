@@ -102,6 +102,12 @@ int pg_vit_forward_hidden(pg_vit* h, const void* pixels, int pix_dtype, int n_im
 int pg_vit_precise_workspace_bytes(const pg_vit* h, int n_images, size_t* bytes);
 int pg_vit_forward_precise(pg_vit* h, const void* pixels, int pix_dtype, int n_images, float* emb_out, float* hidden_out,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* hipGraph of the encoder (round 4).  pg_vit_forward replays the ~250 launches between im2col and the token mean -- they touch only
+ * the workspace and the handle's weights -- from a graph captured at the second forward with the same (workspace, n_images); default
+ * on (env PIGEON_VIT_GRAPH=0: off).  Results are bit-identical either way (same kernels, same order).  Forwards run un-graphed while
+ * pg_vit_profile_enable / pg_vit_saturation_check are on.  on = 1 / 0 switches it, any other value only queries; replays / captures
+ * (may be NULL) return the counts since creation. */
+int pg_vit_graph(pg_vit* h, int on, int64_t* replays, int64_t* captures);
 int pg_vit_destroy(pg_vit* h);
 /* The operand format the handle resolved to (PG_DTYPE_F16 or PG_DTYPE_BF16). */
 int pg_vit_mma_dtype(const pg_vit* h);

@@ -46,6 +46,7 @@ SIGNATURES = {
     "pg_vit_forward_hidden": (_I, [_P, _P, _I, _I, _P, _P, _P, _SZ, _P]),
     "pg_vit_precise_workspace_bytes": (_I, [_P, _I, C.POINTER(_SZ)]),
     "pg_vit_forward_precise": (_I, [_P, _P, _I, _I, _P, _P, _P, _SZ, _P]),
+    "pg_vit_graph": (_I, [_P, _I, C.POINTER(_I64), C.POINTER(_I64)]),
     "pg_vit_destroy": (_I, [_P]),
     "pg_vit_mma_dtype": (_I, [_P]),
     "pg_vit_profile_enable": (_I, [_P, _I]),

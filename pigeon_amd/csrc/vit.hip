@@ -155,6 +155,17 @@ struct pg_vit {
     // always-on fp16 range alarm (rowstat_finalize_kernel): rows of the residual stream whose sum of squares reaches 65504^2
     unsigned long long* range_alarm = nullptr;
     float range_alarm_sumsq = 0.f;
+    // hipGraph of the encoder body (round 4): the ~250 launches between im2col and the token mean touch only the workspace and the
+    // weights, so one captured graph per (workspace, n_images) replays them with one host call.  Built at the SECOND forward of a
+    // key (the first runs eagerly: it also sets the kernels' LDS attributes, which is not a stream operation), on an internal
+    // stream (torch's current stream is usually the legacy default stream, which cannot be captured), launched on the caller's.
+    // Off while profiling events / the saturation scan / the multi-stream mode are on, and with env PIGEON_VIT_GRAPH=0.
+    struct GraphEntry { const void* ws; int n; int seen; hipGraph_t graph; hipGraphExec_t exec; unsigned long long last_use; };
+    std::vector<GraphEntry> graphs;
+    bool use_graph = true;
+    hipStream_t capture_stream = nullptr;
+    unsigned long long graph_clock = 0;
+    long long graph_replays = 0, graph_captures = 0;
     // profiling
     bool prof = false;
     unsigned prof_mask = 0xFFFFFFFFu;                      // classes bracketed while prof is on (bit c = class c)
@@ -215,6 +226,7 @@ extern "C" int pg_vit_create(pg_vit** out, int device, const pg_vit_cfg* cfg) {
         PG_HIP(hipMemset(h->range_alarm, 0, sizeof(unsigned long long)));
         h->range_alarm_sumsq = 65504.0f * 65504.0f;
     }
+    { const char* e = getenv("PIGEON_VIT_GRAPH"); h->use_graph = !(e && e[0] == '0'); }
     { const char* e = getenv("PIGEON_VIT_STREAMS"); h->streams = e ? atoi(e) : PG_DEFAULT_VIT_STREAMS; }
     if (h->streams < 1 || h->streams > 4) h->streams = 1;
     if (h->streams > 1) {
@@ -455,15 +467,14 @@ struct ProfScope {
 
 #define SAT(buf, rows, cols, ld) do { if (h->sat_check) RC(pg_count_sat16_launch((buf), (rows), (cols), (ld), dt, h->sat_counter, s)); } while (0)
 
-static int vit_forward_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n, float* emb_out, float* hidden_out,
-                             char* ws, hipStream_t s) {
+// everything between the im2col and the token mean: reads / writes the workspace and the handle's weights only
+static int vit_forward_body(pg_vit* h, int n, char* ws, hipStream_t s) {
     const int64_t M = (int64_t)n * VIT_TOKENS;
     float* X = (float*)ws;
     uint16_t* Xn = (uint16_t*)(ws + align_up((size_t)M * VIT_HIDDEN * 4, 256));
     uint16_t* big = (uint16_t*)((char*)Xn + align_up((size_t)M * VIT_HIDDEN * 2, 256));
     const float eps = h->cfg.ln_eps;
     const int dt = h->cfg.mma_dtype;
-    { ProfScope p(h, s, 7); RC(pg_im2col_launch(pixels, pix_dtype, big, dt, n, s)); }
     SAT(big, (int64_t)n * VIT_PATCHES, VIT_PATCH_KPAD, VIT_PATCH_KPAD);
     { ProfScope p(h, s, 4);
       RC(pg_gemm_launch(dt, big, VIT_PATCH_KPAD, h->wpatch, VIT_PATCH_KPAD, nullptr, X, VIT_HIDDEN, n * VIT_PATCHES, VIT_HIDDEN, VIT_PATCH_KPAD,
@@ -538,6 +549,67 @@ static int vit_forward_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n
         { ProfScope p(h, s, 3);
           RC(pg_gemm_launch(dt, big, VIT_MLP, L.w2, VIT_MLP, L.b2, X, VIT_HIDDEN, (int)M, VIT_HIDDEN, VIT_MLP, EPI_RESID, 1.f, 0, nullptr, 0, s)); }
     }
+    return PG_OK;
+}
+
+static void graph_entry_free(pg_vit::GraphEntry& e) {
+    if (e.exec) (void)hipGraphExecDestroy(e.exec);
+    if (e.graph) (void)hipGraphDestroy(e.graph);
+    e.exec = nullptr; e.graph = nullptr;
+}
+// Run the body through its captured graph if there is one for (ws, n); capture it at the second sight of the key; else eagerly.
+static int vit_forward_body_graphed(pg_vit* h, int n, char* ws, hipStream_t s) {
+    const bool ok = h->use_graph && !h->prof && !h->sat_check;
+    if (!ok) return vit_forward_body(h, n, ws, s);
+    pg_vit::GraphEntry* ent = nullptr;
+    for (auto& e : h->graphs) if (e.ws == ws && e.n == n) { ent = &e; break; }
+    if (!ent) {
+        if (h->graphs.size() >= 8) {                          // evict the least recently used key
+            size_t lru = 0;
+            for (size_t i = 1; i < h->graphs.size(); ++i) if (h->graphs[i].last_use < h->graphs[lru].last_use) lru = i;
+            graph_entry_free(h->graphs[lru]);
+            h->graphs.erase(h->graphs.begin() + lru);
+        }
+        h->graphs.push_back({ws, n, 0, nullptr, nullptr, 0});
+        ent = &h->graphs.back();
+    }
+    ent->last_use = ++h->graph_clock;
+    if (ent->exec) {
+        PG_HIP(hipGraphLaunch(ent->exec, s));
+        ++h->graph_replays;
+        return PG_OK;
+    }
+    if (ent->seen++ == 0) return vit_forward_body(h, n, ws, s);      // first sight: eager (sets kernel attributes, warms caches)
+    if (!h->capture_stream) PG_HIP(hipStreamCreateWithFlags(&h->capture_stream, hipStreamNonBlocking));
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { (void)hipGetLastError(); h->use_graph = false; return vit_forward_body(h, n, ws, s); }
+    const int rc = vit_forward_body(h, n, ws, h->capture_stream);
+    e = hipStreamEndCapture(h->capture_stream, &graph);
+    if (rc != PG_OK || e != hipSuccess || !graph) {
+        (void)hipGetLastError();
+        if (graph) (void)hipGraphDestroy(graph);
+        h->use_graph = false;                                  // capture is not available here: stay eager from now on
+        return vit_forward_body(h, n, ws, s);
+    }
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess || !exec) { (void)hipGetLastError(); (void)hipGraphDestroy(graph); h->use_graph = false; return vit_forward_body(h, n, ws, s); }
+    ent->graph = graph; ent->exec = exec;
+    ++h->graph_captures;
+    PG_HIP(hipGraphLaunch(exec, s));
+    ++h->graph_replays;
+    return PG_OK;
+}
+
+static int vit_forward_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n, float* emb_out, float* hidden_out,
+                             char* ws, hipStream_t s) {
+    const int64_t M = (int64_t)n * VIT_TOKENS;
+    float* X = (float*)ws;
+    uint16_t* Xn = (uint16_t*)(ws + align_up((size_t)M * VIT_HIDDEN * 4, 256));
+    uint16_t* big = (uint16_t*)((char*)Xn + align_up((size_t)M * VIT_HIDDEN * 2, 256));
+    { ProfScope p(h, s, 7); RC(pg_im2col_launch(pixels, pix_dtype, big, h->cfg.mma_dtype, n, s)); }
+    RC(vit_forward_body_graphed(h, n, ws, s));
     { ProfScope p(h, s, 8); RC(pg_token_mean_launch(X, emb_out, n, s)); }
     if (hidden_out) PG_HIP(hipMemcpyAsync(hidden_out, X, (size_t)M * VIT_HIDDEN * 4, hipMemcpyDeviceToDevice, s));
     return PG_OK;
@@ -676,6 +748,8 @@ extern "C" int pg_vit_destroy(pg_vit* h) {
     for (int i = 0; i < 3; ++i) { if (h->sx[i]) (void)hipStreamDestroy(h->sx[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& g : h->graphs) graph_entry_free(g);
+    if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
     delete h;
     return PG_OK;
 }
@@ -684,6 +758,7 @@ extern "C" int pg_vit_range_alarm_read(pg_vit* h, int64_t* rows, int reset) {
     if (!h || !rows) { pg_set_error("range_alarm_read: null argument"); return PG_EINVAL; }
     *rows = 0;
     if (!h->range_alarm) return PG_OK;                       // bf16 operands, or the separate-LayerNorm chain: no alarm
+    PG_HIP(hipSetDevice(h->device));                         // the counter lives on the handle's device, whatever is current
     PG_HIP(hipDeviceSynchronize());
     unsigned long long v = 0;
     PG_HIP(hipMemcpy(&v, h->range_alarm, sizeof(v), hipMemcpyDeviceToHost));
@@ -707,11 +782,20 @@ extern "C" int pg_vit_saturation_read(pg_vit* h, int64_t* count, int reset) {
     if (!h || !count) { pg_set_error("saturation_read: null argument"); return PG_EINVAL; }
     *count = 0;
     if (!h->sat_counter) return PG_OK;
+    PG_HIP(hipSetDevice(h->device));
     PG_HIP(hipDeviceSynchronize());
     unsigned long long v = 0;
     PG_HIP(hipMemcpy(&v, h->sat_counter, sizeof(v), hipMemcpyDeviceToHost));
     *count = (int64_t)v;
     if (reset) PG_HIP(hipMemset(h->sat_counter, 0, sizeof(v)));
+    return PG_OK;
+}
+
+extern "C" int pg_vit_graph(pg_vit* h, int on, int64_t* replays, int64_t* captures) {
+    if (!h) { pg_set_error("vit_graph: null handle"); return PG_EINVAL; }
+    if (on == 0 || on == 1) h->use_graph = on != 0;          // any other value: query only
+    if (replays) *replays = h->graph_replays;
+    if (captures) *captures = h->graph_captures;
     return PG_OK;
 }
 

@@ -355,6 +355,12 @@ class VitEncoder:
                                             C.c_void_p(ws.data_ptr() + off), ws.numel() - off, _stream()), "pg_vit_forward_precise")
         return (emb, hid) if return_hidden else emb
 
+    def graph(self, on: Optional[bool] = None):
+        """Switch the encoder's hipGraph replay on / off (None: query only) -> (replays, captures) since creation."""
+        r, c = C.c_int64(), C.c_int64()
+        check(load().pg_vit_graph(self._h, -1 if on is None else int(bool(on)), C.byref(r), C.byref(c)), "pg_vit_graph")
+        return int(r.value), int(c.value)
+
     # ---- per-kernel-class timing for bench.py ----
     def profile_enable(self, on: bool = True, classes=None):
         """classes: None = every kernel class, else an iterable of class names (_lib.PROF_CLASSES) to bracket with events."""

@@ -69,7 +69,8 @@ def test_split_gemm_vs_fp64(env, capsys):
     # the triple reconstructs the fp32 value to 2^-22
     t = A3.cpu().float()
     rec = t[:, :K] + t[:, K:2 * K]
-    erec = float(((rec.double() - A.double()).abs() / A.double().abs().clamp_min(1e-30)).max())
+    # ... or, below fp16's normal range, to half the subnormal quantum 2^-24
+    erec = float(((rec.double() - A.double()).abs() / A.double().abs().clamp_min(2.0 ** -4)).max())
     with capsys.disabled():
         print(f"\nsplit GEMM vs fp64: triple {e3:.2e}, plain fp16 {e1:.2e}, torch fp32 on the CPU {e32:.2e}; hi+lo reconstructs x to {erec:.2e}")
     assert torch.equal(t[:, 2 * K:], (t[:, :K] * (1.0 / 256)).half().float())
@@ -252,3 +253,32 @@ def test_exact_top1_pipeline24_spread(env, golden_dir, tmp_path, capsys):
     g = np.load(os.path.join(golden_dir, "pipeline24_spread.npz"))
     assert g["image_cos_sim"][2] <= 0.8, "the fixture's embeddings must spread (pairwise cos-sim <= 0.8)"
     _top1_run(env, golden_dir, tmp_path, "pipeline24_spread", capsys)
+
+
+def test_encoder_graph_replay_bit_identical(env, capsys):
+    """pg_vit_forward replays the encoder body from a captured hipGraph from the second forward of a (workspace, n) key on:
+    same kernels, same order -> the same bits as the eager launches; profiling switches the replay off for the call."""
+    ops, syn = env["ops"], env["syn"]
+    sd = syn.make_vit_weights(seed=11, layers=2, affine_jitter=True)
+    enc = ops.VitEncoder(sd, layers=2)
+    px = syn.make_pixels(24, seed=5).to(DEV)
+    enc.graph(False)
+    eager = enc(px).clone()
+    enc.graph(True)
+    r0, c0 = enc.graph()
+    outs = [enc(px).clone() for _ in range(4)]          # 1st: eager (first sight of the key), 2nd: capture + launch, then replays
+    torch.cuda.synchronize()
+    r1, c1 = enc.graph()
+    with capsys.disabled():
+        print(f"\nencoder graph: {r1 - r0} replays, {c1 - c0} capture(s) in 4 forwards")
+    assert c1 - c0 == 1 and r1 - r0 == 3, "the graph path did not engage (capture unsupported on this runtime?)"
+    for o in outs:
+        assert torch.equal(o, eager)
+    other = enc(px[:8].contiguous())                     # another key: eager again, same rows
+    assert torch.equal(other, eager[:8])
+    enc.profile_enable(True)
+    prof = enc(px).clone()
+    enc.profile_enable(False)
+    assert torch.equal(prof, eager) and enc.graph()[0] == r1     # bracketed with events: no replay
+    assert enc.profile_read()["gemm_fc1"][0] == 2
+    enc.close()
