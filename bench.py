@@ -81,13 +81,19 @@ def parse(argv=None):
     ap.add_argument("--topk", type=int, default=5)
     ap.add_argument("--layers", type=int, default=24)
     ap.add_argument("--pixel-batches", type=int, default=4, help="distinct resident pixel batches used in turn")
-    ap.add_argument("--cpu-images", type=int, default=64, help="images in the bounded CPU-baseline / parity sample (0 = skip)")
-    ap.add_argument("--cpu-module-images", type=int, default=32, help="images through transformers.CLIPVisionModel on the CPU (0 = skip)")
+    ap.add_argument("--cpu-images", type=int, default=256, help="images in the bounded CPU-baseline / parity sample (0 = skip); 256 = 64 panoramas")
+    ap.add_argument("--cpu-port-images", type=int, default=64, help="images through the oracle restatement (kind 'port') on the CPU (0 = skip)")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="CPU-baseline worker processes x 16 threads (0 = hardware threads / 16)")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)       # internal: run one CPU-baseline worker from a spec file
+    ap.add_argument("--exact-steps", type=int, default=3, help="steps of the exact-mode leg after the timed region (0 = skip)")
     ap.add_argument("--no-refine", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip ingest / other configs / secondary baseline (profiling runs)")
-    ap.add_argument("--profile", choices=["all", "dominant", "none"], default="all",
-                    help="HIP events inside the timed region: around every encoder launch / around the dominant GEMM class only (the "
-                         "other classes are then timed in one extra step after the timed region) / none (A/B of the events' own cost)")
+    ap.add_argument("--profile", choices=["graph", "all", "dominant", "none"], default="graph",
+                    help="graph (default): the timed region runs the product path -- encoder body replayed from its hipGraph, no events "
+                         "inside -- and per-kernel HIP events bracket every launch of --profile-steps extra un-graphed steps right after it; "
+                         "all / dominant: events around every launch / the dominant GEMM class INSIDE the timed region (graph off); "
+                         "none: un-graphed, no events (A/B arm)")
+    ap.add_argument("--profile-steps", type=int, default=5, help="bracketed un-graphed steps after the timed region (--profile graph / none / dominant)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: stub model / refiner on the CPU, gloo collectives, tiny tensors -- the launch, sharding, gather, "
                          "timing and JSON control flow of the real run (CPU contract test)")
@@ -157,29 +163,125 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(args, vit_sd, model, bank_t, px):
-    """Oracle = CPU restatement of the reference path, on a bounded sample of the SAME workload; px (S,12,336,336) on the host.
-    Returns (json dict, oracle head outputs, oracle refined (llh, cell) or None)."""
+def cpu_worker_main(spec_path):
+    """One CPU-baseline worker process (`bench.py --cpu-worker spec.json`): pins itself to its cores, rebuilds the seeded weights,
+    runs its shard of images through transformers.CLIPVisionModel (kind "module": the module the reference itself calls,
+    models/clip_embedder.py:63) or the oracle restatement (kind "port") and saves the token-mean embeddings.  The timed part
+    starts when the parent drops the `go` file, after every worker has loaded its weights."""
+    spec = json.load(open(spec_path))
+    if spec.get("cpus"):
+        try:
+            os.sched_setaffinity(0, spec["cpus"])
+        except OSError:
+            pass
+    import torch
+    torch.set_num_threads(int(spec["threads"]))
+    from pigeon_amd import synthetic
+    px = torch.load(spec["pixels"])
+    sd = synthetic.make_vit_weights(seed=spec["weight_seed"], layers=spec["layers"])
+    if spec["kind"] == "module":
+        from transformers import CLIPVisionConfig, CLIPVisionModel
+        cfg = CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=spec["layers"], num_attention_heads=16,
+                               image_size=336, patch_size=14, projection_dim=768)
+        with contextlib.redirect_stdout(io.StringIO()):
+            hf = CLIPVisionModel(cfg)
+        hf.load_state_dict(sd, strict=True)
+        hf.eval()
+
+        def run(x):
+            with torch.no_grad():
+                return hf(pixel_values=x).last_hidden_state.mean(dim=1)
+    else:
+        from oracle import pigeon_oracle as orc
+
+        def run(x):
+            return orc.clip_embedding(sd, x)
+    open(spec["ready"], "w").close()
+    t_wait = time.time() + 600
+    while not os.path.exists(spec["go"]):
+        if time.time() > t_wait:
+            raise SystemExit("cpu worker: no go signal")
+        time.sleep(0.01)
+    t0 = time.time()
+    bs = int(spec.get("batch", 4))
+    outs = [run(px[i:i + bs]) for i in range(0, px.shape[0], bs)]
+    t1 = time.time()
+    torch.save(torch.cat(outs), spec["out"])
+    json.dump({"seconds": t1 - t0, "end": t1, "images": int(px.shape[0])}, open(spec["done"], "w"))
+
+
+def cpu_pool(kind, px_images, layers, workers, threads, weight_seed=0):
+    """`workers` independent processes x `threads` torch threads on disjoint core slices and disjoint image shards (torch's CPU
+    GEMMs regress past 32 threads in ONE process -- a fact about one process, not about the box).  Returns (embeddings in image
+    order, wall seconds from the common go signal to the last worker's result, per-worker seconds, cores busy)."""
+    import torch
+    n = px_images.shape[0]
+    workers = max(1, min(workers, n))
+    avail = sorted(os.sched_getaffinity(0))
+    threads = max(1, min(threads, len(avail) // workers if len(avail) >= workers else 1))
+    tmp = tempfile.mkdtemp(prefix="pigeon_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    bounds = [round(i * n / workers) for i in range(workers + 1)]
+    procs, specs = [], []
+    go = os.path.join(tmp, "go")
+    for w in range(workers):
+        lo, hi = bounds[w], bounds[w + 1]
+        spec = {"kind": kind, "threads": threads, "layers": layers, "weight_seed": weight_seed, "cpus": avail[w * threads:(w + 1) * threads],
+                "pixels": os.path.join(tmp, f"px_{w}.pt"), "out": os.path.join(tmp, f"emb_{w}.pt"), "ready": os.path.join(tmp, f"ready_{w}"),
+                "done": os.path.join(tmp, f"done_{w}.json"), "go": go, "batch": 4}
+        torch.save(px_images[lo:hi].clone(), spec["pixels"])
+        sp = os.path.join(tmp, f"spec_{w}.json")
+        json.dump(spec, open(sp, "w"))
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", sp], env=env,
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.PIPE))
+        specs.append(spec)
+    try:
+        t_end = time.time() + 900
+        while not all(os.path.exists(sp["ready"]) for sp in specs):
+            bad = [i for i, pr in enumerate(procs) if pr.poll() not in (None, 0)]
+            if bad or time.time() > t_end:
+                err = procs[bad[0]].stderr.read().decode()[-400:] if bad else "timeout while loading"
+                raise RuntimeError(f"cpu worker {bad} failed before the go signal: {err}")
+            time.sleep(0.05)
+        t0 = time.time()
+        open(go, "w").close()
+        for i, pr in enumerate(procs):
+            if pr.wait(timeout=1800) != 0:
+                raise RuntimeError(f"cpu worker {i} failed: {pr.stderr.read().decode()[-400:]}")
+        emb = torch.cat([torch.load(sp["out"]) for sp in specs])
+        done = [json.load(open(sp["done"])) for sp in specs]
+        per = [d["seconds"] for d in done]
+        wall = max(d["end"] for d in done) - t0              # go signal -> last worker's last image (same host clock); not the
+                                                             # interpreter teardown of the worker processes
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    return emb, wall, per, workers * threads
+
+
+def cpu_baseline(args, model, bank_t, px):
+    """The reference's CPU path on THIS box's host cores, on a bounded sample of the SAME workload; px (S,12,336,336) on the host.
+    Encoder: transformers.CLIPVisionModel -- the module the reference itself calls -- in hardware_threads / 16 independent
+    16-thread processes on disjoint shards (kind "reference-module"); head + refinement: the oracle restatement on those
+    embeddings (serial, added to the time).  Sub-field `port`: the oracle's own ViT restatement on --cpu-port-images of them.
+    Returns (json dict, oracle head outputs, oracle refined (llh, cell, bank) or None)."""
     import torch
     from oracle import pigeon_oracle as orc
     npano = px.shape[0]
     cores = os.cpu_count() or 1
-    # thread count: timed, not assumed.  torch's CPU GEMMs regress badly past 32-64 threads at this size (round 2 measured the
-    # full 256 hardware threads of the EPYC 9575F box at 0.047 images/s, 85 s for one panorama), so the sweep stops at 64.
-    sweep = {}
-    for nt in sorted({min(cores, 16), min(cores, 32), min(cores, 64)}):
-        torch.set_num_threads(nt)
-        t0 = time.time()
-        orc.clip_embedding(vit_sd, px[0].reshape(4, 3, 336, 336)[:2])
-        sweep[nt] = 2 / (time.time() - t0)
-    best = max(sweep, key=sweep.get)
-    torch.set_num_threads(best)
+    workers = args.cpu_workers if args.cpu_workers > 0 else max(1, cores // 16)
+    images = px.reshape(-1, 3, 336, 336)
+    emb_i, wall, per, busy = cpu_pool("module", images, args.layers, workers, 16)
+    emb = emb_i.reshape(npano, 4, 1024)
     W = model.cell_layer.weight.data.cpu()
     b = model.cell_layer.bias.data.cpu()
     cen = model.lla_geocells.data.cpu()
+    torch.set_num_threads(min(cores, 32))
     t0 = time.time()
-    o = orc.super_guessr_forward(W, b, cen, args.topk, vit_sd=vit_sd, pixel_values=px)
-    t_vit = time.time() - t0
+    o = orc.super_guessr_forward(W, b, cen, args.topk, embedding=emb)
     refined = None
     if bank_t is not None:
         class B:
@@ -194,40 +296,30 @@ def cpu_baseline(args, vit_sd, model, bank_t, px):
         _, r_llh, r_cell = orc.proto_refiner_forward(hb, o["embedding"], o["preds_LLH"], o["topk"].indices, o["topk"].values,
                                                      args.topk, 1.6, 1000)
         refined = (r_llh, r_cell, hb)
-    dt = time.time() - t0
-    res = {"value": npano * 4 / dt, "unit": "images/s", "cores": best, "box_cores": cores, "kind": "port",
-           "thread_sweep_images_per_s": {str(k): round(v, 3) for k, v in sweep.items()},
-           "sample": f"{npano} panoramas ({npano * 4} images = BASELINE configs[0]'s 64-image size when --cpu-images 64) through the "
-                     f"oracle ViT-L/14 fp32 + head + top-{args.topk} refine (torch CPU, {best} threads = the fastest of the sweep, "
-                     f"{dt:.1f} s, ViT+head {t_vit:.1f} s); linear in images",
-           "cpu_model": _cpu_model()}
+    t_tail = time.time() - t0
+    dt = wall + t_tail
+    res = {"value": npano * 4 / dt, "unit": "images/s", "cores": busy, "box_cores": cores, "kind": "reference-module",
+           "workers": len(per), "threads_per_worker": busy // max(1, len(per)),
+           "encoder_images_per_s": npano * 4 / wall, "per_worker_seconds": [round(x, 2) for x in per],
+           "sample": f"{npano} panoramas = {npano * 4} images of this run's resident pixel batches through transformers.CLIPVisionModel "
+                     f"(ViT-L/14-336 config, this run's weights; the module the reference calls) fp32 + token mean in {len(per)} "
+                     f"independent processes x {busy // max(1, len(per))} threads on disjoint cores and image shards ({wall:.1f} s from a "
+                     f"common start signal, weights already loaded), then the oracle's head + top-{args.topk} refinement on those "
+                     f"embeddings ({t_tail:.1f} s, serial); linear in images",
+           "transformers": __import__("transformers").__version__, "cpu_model": _cpu_model()}
+    if args.cpu_port_images > 0:
+        try:
+            n_port = min(args.cpu_port_images, images.shape[0])
+            # spread over the sample so that the restatement is checked against the module on every resident batch
+            sel = torch.linspace(0, images.shape[0] - 1, n_port).round().long()
+            emb_p, wall_p, per_p, busy_p = cpu_pool("port", images[sel], args.layers, min(workers, n_port), 16)
+            res["port"] = {"value": n_port / wall_p, "unit": "images/s", "cores": busy_p, "kind": "port",
+                           "sample": f"{n_port} of those images through oracle/pigeon_oracle.py (the CPU restatement of the reference's "
+                                     f"encoder path), same process layout, {wall_p:.1f} s",
+                           "embedding_rel_err_vs_module": orc.rel_err(emb_p, emb_i[sel])}
+        except Exception as e:  # noqa
+            res["port"] = {"error": repr(e)}
     return res, o, refined
-
-
-def cpu_reference_module(args, vit_sd, px_images, threads, port_emb):
-    """transformers.CLIPVisionModel -- the module the reference itself calls (models/clip_embedder.py:63) -- on the host cores."""
-    import torch
-    from transformers import CLIPVisionConfig, CLIPVisionModel
-    from oracle import pigeon_oracle as orc
-    cfg = CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=args.layers, num_attention_heads=16,
-                           image_size=336, patch_size=14, projection_dim=768)
-    with contextlib.redirect_stdout(io.StringIO()):
-        hf = CLIPVisionModel(cfg)
-    hf.load_state_dict(vit_sd, strict=True)
-    hf.eval()
-    torch.set_num_threads(threads)
-    n = px_images.shape[0]
-    outs = []
-    t0 = time.time()
-    with torch.no_grad():
-        for s in range(0, n, 8):
-            outs.append(hf(pixel_values=px_images[s:s + 8]).last_hidden_state.mean(dim=1))
-    dt = time.time() - t0
-    emb = torch.cat(outs)
-    return {"value": n / dt, "unit": "images/s", "cores": threads, "kind": "reference-module",
-            "sample": f"{n} images through transformers.CLIPVisionModel(ViT-L/14-336 config, same weights) fp32 + token mean on the CPU, "
-                      f"batches of 8, {dt:.1f} s", "transformers": __import__("transformers").__version__,
-            "embedding_rel_err_vs_port": orc.rel_err(port_emb[:n], emb)}
 
 
 def flip_analysis(ref_logits, hip_logits, hip_cell, where):
@@ -272,6 +364,7 @@ def parity_report(args, dev, model, o, refined, hip):
     assert torch.equal(torch.topk(o["logits"], 1, dim=-1).indices[:, 0], o["preds_geocell"])
     rep = {"n_panoramas": n, "from": "pixels (oracle ViT fp32 on the host) vs this run's step outputs",
            "embedding_rel_err": orc.rel_err(hip["embedding"].cpu(), o["embedding"]),
+           "oracle": "transformers.CLIPVisionModel fp32 on the host (cpu_baseline's encoder leg) + the oracle's head / refinement",
            "embedding_rel_err_worst_image": orc.max_rel_err_rows(hip["embedding"].cpu().reshape(-1, 1024), o["embedding"].reshape(-1, 1024))}
     rep.update(fa)
     if refined is not None and "refined_geocell" in hip:
@@ -468,6 +561,9 @@ def worker(args):
     from pigeon_amd import distributed
     # control plane (gloo); the data-path collective is RCCL through the C ABI.  --dry-run never touches a GPU, also on a GPU box
     comm = distributed.init_from_env(set_device=not args.dry_run)
+    # N = 1 included: the two grouped all-gathers of a step go through a (1-rank) RCCL communicator, so that a single-GPU line
+    # exercises csrc/comm.hip and the RCCL binding exactly as the N > 1 lines do (PIGEON_FORCE_RCCL=0: the identity shortcut)
+    comm.force_rccl = os.environ.get("PIGEON_FORCE_RCCL", "1") not in ("", "0") and not args.dry_run
     # every rank, on every way out: the gloo group is torn down explicitly (alive at interpreter exit it aborts the process --
     # a finished rank would then fail its launcher); the RCCL communicator only on the regular way out (_worker does it after
     # its last barrier), a failing rank abandons it
@@ -507,6 +603,11 @@ def _worker(args, comm):
             raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but this box has {torch.cuda.device_count()} GPU(s)")
         torch.cuda.set_device(local)
         dev = torch.device(f"cuda:{local}")
+        # host side of one-process-per-GPU: this rank's launch thread stays on the cores next to its GPU (8 launch-heavy processes
+        # on a 2-socket box otherwise migrate across sockets); PIGEON_BENCH_PIN=0 switches it off
+        pinned = None
+        if os.environ.get("PIGEON_BENCH_PIN", "1") not in ("", "0"):
+            pinned = distributed.pin_to_gpu_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
         # ---- model, head, bank (identical replicas on every rank) ----
         vit_sd = synthetic.make_vit_weights(seed=0, layers=args.layers)
         base = HipCLIPVisionModel(vit_sd, layers=args.layers)
@@ -562,9 +663,13 @@ def _worker(args, comm):
             enc.profile_enable(True)
         elif args.profile == "dominant":
             enc.profile_enable(True, classes=["gemm_fc1"])       # the dominant class of this workload (checked below)
+        elif args.profile == "none":
+            enc.graph(False)                                     # A/B arm: eager launches, no events
+        g0 = enc.graph()
         pipe.refine_events = [] if (refiner is not None and args.profile != "none") else None
     refine_rows = []
     outs_by_batch = {}
+    certain_by_batch = {}
 
     # ---- timed region: exactly K steps between barrier + synchronize on both sides ----
     comm.barrier()
@@ -573,25 +678,40 @@ def _worker(args, comm):
     for i in range(args.steps):
         out = pipe.step(pixel_batches[i % nb], index)
         outs_by_batch[i % nb] = out                               # references only; read after the timed region
+        if not dry:
+            certain_by_batch[i % nb] = (model.last_certain, model.last_margin, model.last_bound)
         if refiner is not None and not dry:
             refine_rows.append(refiner.last_scratch)             # device tensor kept; summed after the timed region
     sync()
     comm.barrier()
     dt = time.perf_counter() - t0
     prof = {}
+    ungraphed = None
     if not dry:
+        g1 = enc.graph()
         enc.profile_enable(False)
         prof = enc.profile_read()
         if args.profile != "all":
-            # the other kernel classes: ONE extra, fully bracketed step after the timed region (not part of `value`)
+            # per-kernel timing: --profile-steps extra steps right after the timed region, every encoder launch bracketed with HIP
+            # events on the launch stream (which also switches the graph replay off for them); not part of `value`
             live = {k: v for k, v in prof.items() if v[0]}
             enc.profile_reset()
             enc.profile_enable(True)
-            pipe.step(pixel_batches[args.steps % nb], index)
+            ksteps = max(1, args.profile_steps)
             torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for i in range(ksteps):
+                pipe.step(pixel_batches[(args.steps + i) % nb], index)
+            torch.cuda.synchronize()
+            tp = (time.perf_counter() - tp) / ksteps
             enc.profile_enable(False)
             prof = enc.profile_read()
             prof.update(live)                                     # classes measured inside the timed region win
+            ungraphed = {"ms_per_step": tp * 1e3, "value": args.panoramas * 4 / tp, "steps": ksteps,
+                         "what": "the same step with the encoder launched kernel by kernel and every launch bracketed with HIP events "
+                                 "(this rank, right after the timed region): where `kernels` / `roofline` are measured"}
+        enc.graph(True)
+    rank_ms = [x / args.steps * 1e3 for x in comm.all_values(dt)]
     dt = comm.max_over_ranks(dt)
 
     # ---- what every rank (rank 0 in particular) holds after the last step: the whole batch, restorable to sample order ----
@@ -613,6 +733,21 @@ def _worker(args, comm):
     # right after a barrier (ncclCommDestroy wants all ranks of a node; a gloo group alive at interpreter exit aborts the
     # process); rank 0 then goes on alone with the roofline / CPU-baseline / parity legs.
     rccl_ranks = comm.rccl_ranks()
+    gather_us = None
+    if not dry and rccl_ranks:
+        # what the step's two grouped all-gathers cost on this rank (RCCL group launch + copies), on the launch stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        own_rows = [out[k][own].contiguous() for k in ("embedding", "topk_indices", "topk_values", "preds_LLH", "index")]
+        small = [out["refined_LLH"][own].contiguous(), out["refined_geocell"][own].contiguous()] if refiner is not None else None
+        for it in range(22):
+            if it == 2:
+                e0.record()
+            comm.gather_many(own_rows)
+            if small is not None:
+                comm.gather_many(small)
+        e1.record()
+        torch.cuda.synchronize()
+        gather_us = e0.elapsed_time(e1) * 1e3 / 20
     comm.barrier()
     comm.close()
     if rank != 0:
@@ -623,7 +758,8 @@ def _worker(args, comm):
     result = {
         "metric": "images/sec end-to-end (ViT+head+refine), 4x336x336",
         "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": step_ms, "per_rank_ms_per_step": [round(x, 3) for x in rank_ms],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32-stub" if dry else enc.mma_dtype, "data": "synthetic",
         "config": {"workload": "BASELINE configs[3]: SuperGuessr 4-panorama ViT-L/14-336 + 10k-geocell head + ProtoRefiner "
                                "top-5 over 1Mx1024 bank" + (" (configs[4] shape: sharded over GPUs, all-gather before refinement)" if world > 1 else ""),
@@ -642,10 +778,11 @@ def _worker(args, comm):
 
     from pigeon_amd import _lib
     kernels = {}
-    per_step = {"gemm_qkv": args.layers, "gemm_out": args.layers, "gemm_fc1": args.layers, "gemm_fc2": args.layers, "attention": args.layers}
+    prof_steps = args.steps if args.profile == "all" else max(1, args.profile_steps)
     for name, (cnt, ms) in prof.items():
         if cnt:
-            kernels[name] = {"launches": cnt, "avg_ms": ms / cnt, "launches_per_step": per_step.get(name, 1)}
+            in_region = args.profile == "all" or (args.profile == "dominant" and name == "gemm_fc1")
+            kernels[name] = {"launches": cnt, "avg_ms": ms / cnt, "launches_per_step": cnt / (args.steps if in_region else prof_steps)}
     # per-launch rows: the encoder processes <= max_chunk (512) images per internal pass, so a 512-image step launches
     # every layer kernel once with M = 512*577 rows
     chunk_rows = min(args.panoramas * 4, enc.max_chunk) * 577
@@ -660,21 +797,39 @@ def _worker(args, comm):
     achieved = kernels[dom]["tflops"]
     traffic, traffic_detail = _committed_traffic(dom, chunk_rows)
     result["mfma_frac_end_to_end"] = value * FLOP_PER_IMAGE / (world * PEAK_MFMA)
+    result["graph"] = {"encoder_body_replays_in_timed_region": g1[0] - g0[0], "captures_total": g1[1],
+                       "what": "pg_vit_forward replays the ~250 launches between im2col and the token mean from a hipGraph captured at the "
+                               "second forward of a (workspace, n_images) key; bit-identical to the eager launches (tests/test_gpu_precise.py)"}
+    if ungraphed is not None:
+        result["ungraphed_evented"] = ungraphed
+    cf = [c[0].float().mean().item() for c in certain_by_batch.values() if c[0] is not None]
+    if cf:
+        result["certain_frac"] = float(np.mean(cf))
+        result["certainty_rule"] = (f"top-1 certain when logit(top1) - logit(top2) > {model.margin_kappa:g} x {model.margin_rel_tol:g} x |emb| "
+                                    "|W[top1] - W[top2]| / sqrt(1024) (pg_head_margin; calibrated on the 128-panorama reference fixtures: "
+                                    "observed margin change <= 1.2e-3 in those units, profiles/r04)")
+    if pinned:
+        result["config"]["rank0_cores"] = f"{len(pinned)} cores next to GPU {local} (sched_setaffinity)"
     result["roofline"] = {"bound": "mfma", "kernel": f"gemm16 {dom}: M={chunk_rows} rows x {GEMM_FLOPS[dom]} FLOP/row per launch",
                           "achieved": achieved, "peak": PEAK_MFMA / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_MFMA / 1e12),
                           "traffic": traffic, "traffic_detail": traffic_detail,
                           "timing": {"all": "HIP events around every encoder launch on the launch stream, inside the timed region (in-process number)",
                                      "dominant": "HIP events around the dominant class's launches (gemm_fc1) inside the timed region; the other "
                                                  "classes of `kernels` from one extra bracketed step after it",
-                                     "none": "no events inside the timed region (A/B arm); `kernels` from one extra bracketed step after it"}[args.profile]}
+                                     "graph": f"HIP events around every encoder launch on the launch stream during {prof_steps} un-graphed steps run right "
+                                              "after the timed region (same process, same resident inputs); the timed region itself replays the "
+                                              "encoder body from its hipGraph and carries no events",
+                                     "none": "no events inside the timed region (A/B arm); `kernels` from extra bracketed steps after it"}[args.profile]}
     if traffic_detail and traffic_detail.get("rocprof_avg_ms"):
         # the committed rocprofv3 --kernel-trace --stats average of the same kernel (another box of the pool: +-4 %)
         result["roofline"]["frac_rocprof"] = GEMM_FLOPS[dom] * chunk_rows / (traffic_detail["rocprof_avg_ms"] * 1e-3) / PEAK_MFMA
     result["kernels"] = kernels
     result["fp16_range_alarm_rows"] = enc.range_alarm_read()       # always-on: residual rows that came near the fp16 limit (0 = none)
-    if world > 1:
+    if rccl_ranks:
         result["rccl"] = {"nranks": rccl_ranks, "version": _lib.load().pg_comm_rccl_version(),
-                          "collective": "pg_allgather_many (C ABI, csrc/comm.hip): 5 buffers before refinement + 2 after, one grouped launch each"}
+                          "collective": "pg_allgather_many (C ABI, csrc/comm.hip): 5 buffers before refinement + 2 after, one grouped launch each",
+                          "inside_timed_region": True, "both_gathers_us_per_step": gather_us,
+                          "forced_at_one_rank": bool(world == 1)}
     if refiner is not None and pipe.refine_events:
         ms = [a.elapsed_time(b_) for a, b_ in pipe.refine_events]
         rows = [float(s[..., 3].sum()) for s in refine_rows]
@@ -736,28 +891,68 @@ def _worker(args, comm):
             oc.append({"error": repr(e)})
         result["other_configs"] = oc
 
+    # ---- exact mode: the same step with SuperGuessr(exact_top1): panoramas whose top-1 margin is inside the 16-bit path's error
+    # band are re-encoded from their pixels in near-fp32 arithmetic (pg_vit_forward_precise) -- its cost, stated next to `value` ----
+    exact_outs = {}
+    if world == 1 and args.exact_steps > 0:
+        try:
+            base.enable_precise(True)                             # repacks the encoder with the split-weight copy (one-off)
+            model.exact_top1 = True
+            pipe.refine_events = None
+            pipe.step(pixel_batches[0], index)                    # warm-up: weight packing, exact-mode workspace
+            torch.cuda.synchronize()
+            n_re = []
+            te = time.perf_counter()
+            for i in range(args.exact_steps):
+                exact_outs[i % nb] = pipe.step(pixel_batches[i % nb], index)
+                n_re.append(model.last_reencoded)
+            torch.cuda.synchronize()
+            te = (time.perf_counter() - te) / args.exact_steps
+            for i in range(args.exact_steps, nb):                 # the parity sample below wants every resident batch (untimed)
+                exact_outs[i] = pipe.step(pixel_batches[i], index)
+            torch.cuda.synchronize()
+            n_re = [int(x.numel()) for x in n_re]
+            result["exact_mode"] = {
+                "value": args.panoramas * 4 / te, "unit": "images/s", "ms_per_step": te * 1e3, "steps": args.exact_steps,
+                "cost_vs_default": te * 1e3 / step_ms, "reencoded_panoramas_per_step": n_re, "panoramas_per_step": args.panoramas,
+                "what": "PIGEON_EXACT_TOP1=1 / SuperGuessr(exact_top1=True): after the fast pass, panoramas that are not certain (see "
+                        "certainty_rule) are re-encoded FROM THE PIXELS by pg_vit_forward_precise (split-fp16 GEMM operands on the same "
+                        "MFMA kernels, fp32 attention / LayerNorm / QuickGELU: ~1e-6 relative vs 2.7e-4) and their head outputs recomputed; "
+                        "refinement then runs on the corrected candidates.  Synchronises once per step (the uncertain set is data dependent)"}
+            model.exact_top1 = False
+        except Exception as e:  # noqa
+            import traceback
+            result["exact_mode"] = {"error": repr(e), "trace": traceback.format_exc()[-600:]}
+            model.exact_top1 = False
+
     if world == 1 and args.cpu_images > 0:
         try:
             # sample: the first panoramas of EVERY resident pixel batch the timed region used, in turn
             used = sorted(outs_by_batch)
             per = max(1, args.cpu_images // 4 // len(used))
             px = torch.cat([pixel_batches[j][:per] for j in used]).cpu()
-            hip = {"embedding": torch.cat([outs_by_batch[j]["embedding"][:per] for j in used]),
-                   "preds_geocell": torch.cat([outs_by_batch[j]["preds_geocell"][:per] for j in used]),
-                   "where": [f"batch {j} #{i}" for j in used for i in range(per)]}
-            if refiner is not None:
-                hip["refined_geocell"] = torch.cat([outs_by_batch[j]["refined_geocell"][:per] for j in used])
-                hip["refined_LLH"] = torch.cat([outs_by_batch[j]["refined_LLH"][:per] for j in used])
-            cb, o, refined = cpu_baseline(args, vit_sd, model, bank_t if refiner is not None else None, px)
+
+            def take(outs):
+                h = {"embedding": torch.cat([outs[j]["embedding"][:per] for j in used]),
+                     "preds_geocell": torch.cat([outs[j]["preds_geocell"][:per] for j in used]),
+                     "where": [f"batch {j} #{i}" for j in used for i in range(per)]}
+                if refiner is not None:
+                    h["refined_geocell"] = torch.cat([outs[j]["refined_geocell"][:per] for j in used])
+                    h["refined_LLH"] = torch.cat([outs[j]["refined_LLH"][:per] for j in used])
+                return h
+            hip = take(outs_by_batch)
+            hip["certain"] = torch.cat([certain_by_batch[j][0][:per] for j in used]).cpu()
+            cb, o, refined = cpu_baseline(args, model, bank_t if refiner is not None else None, px)
             result["cpu_baseline"] = cb
-            result["parity_vs_oracle_sample"] = parity_report(args, dev, model, o, refined, hip)
-            if args.cpu_module_images > 0:
-                try:
-                    nimg = min(args.cpu_module_images, px.shape[0] * 4)
-                    cb["reference_module"] = cpu_reference_module(args, vit_sd, px.reshape(-1, 3, 336, 336)[:nimg], cb["cores"],
-                                                                  o["embedding"].reshape(-1, 1024))
-                except Exception as e:  # noqa
-                    cb["reference_module"] = {"error": repr(e)}
+            rep = parity_report(args, dev, model, o, refined, hip)
+            cert = hip["certain"]
+            rep["certain"] = f"{int(cert.sum())}/{cert.numel()}"
+            rep["flips_among_certain"] = int(sum(1 for r in rep["flipped"] if bool(cert[hip["where"].index(r["panorama"])])))
+            if exact_outs and all(j in exact_outs for j in used):
+                rx = parity_report(args, dev, model, o, refined, take(exact_outs))
+                rep["exact_mode"] = {k: rx[k] for k in ("embedding_rel_err", "logit_abs_err_max", "flips", "flipped", "geocell_argmax_equal",
+                                                         "refined_cell_equal_where_argmax_equal", "refined_lnglat_equal_where_argmax_equal") if k in rx}
+            result["parity_vs_oracle_sample"] = rep
         except Exception as e:  # noqa
             import traceback
             result["cpu_baseline"] = {"error": str(e), "trace": traceback.format_exc()[-800:]}
@@ -770,6 +965,9 @@ def _worker(args, comm):
 
 def main():
     args = parse()
+    if args.cpu_worker:
+        cpu_worker_main(args.cpu_worker)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     worker(args)

@@ -29,8 +29,13 @@ class Communicator:
     the torch.distributed process group, which is only the CONTROL plane here (bootstrap, barrier; "gloo" by default).
     Host tensors (the CPU tests) use that process group directly."""
 
-    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, force_rccl: Optional[bool] = None):
+        """force_rccl (default: env PIGEON_FORCE_RCCL=1): with ONE rank, device tensors still go through a 1-rank RCCL communicator
+        (`pg_allgather_many`) instead of being returned as they are -- a single-GPU run then exercises csrc/comm.hip, the RCCL
+        binding and the group launch exactly as an N-rank run does (bench.py switches it on: its N = 1 line is the early
+        warning for the N > 1 ones)."""
         self.group = group
+        self.force_rccl = (os.environ.get("PIGEON_FORCE_RCCL", "0") not in ("", "0")) if force_rccl is None else bool(force_rccl)
         if dist.is_available() and dist.is_initialized():
             self.rank = dist.get_rank(group)
             self.world_size = dist.get_world_size(group)
@@ -60,7 +65,8 @@ class Communicator:
             buf = C.create_string_buffer(128)
             _lib.check(lib.pg_comm_unique_id(buf), "pg_comm_unique_id")
             ident = [buf.raw]
-        dist.broadcast_object_list(ident, src=0, group=self.group)         # control plane: 128 bytes
+        if self.world_size > 1:
+            dist.broadcast_object_list(ident, src=0, group=self.group)     # control plane: 128 bytes
         h = C.c_void_p()
         with torch.cuda.device(device):
             _lib.check(lib.pg_comm_init_rank(C.byref(h), self.world_size, ident[0], self.rank), "pg_comm_init_rank")
@@ -100,7 +106,7 @@ class Communicator:
     def gather_many(self, tensors: List[torch.Tensor]) -> List[torch.Tensor]:
         """Gather several tensors (same leading dimension on every rank) in ONE grouped collective; every result is
         rank-major and contiguous -- no packing, no unpacking copies."""
-        if self.world_size == 1:
+        if self.world_size == 1 and not (self.force_rccl and len(tensors) and all(t.is_cuda for t in tensors)):
             return list(tensors)
         devs = {t.device for t in tensors}
         if len(devs) != 1:
@@ -123,6 +129,14 @@ class Communicator:
                 dist.all_gather(list(o.chunk(self.world_size, dim=0)), t, group=self.group)
         return outs
 
+    def all_values(self, value: float) -> List[float]:
+        """Control-plane all-gather of one host scalar per rank (bench: every rank's step time, not only the maximum)."""
+        if self.world_size == 1:
+            return [float(value)]
+        out: List = [None] * self.world_size
+        dist.all_gather_object(out, float(value), group=self.group)
+        return [float(v) for v in out]
+
     def max_over_ranks(self, value: float) -> float:
         """Control-plane MAX reduction of a host scalar (bench timing)."""
         if self.world_size == 1:
@@ -140,7 +154,7 @@ class Communicator:
     wait_for_everyone = barrier
 
 
-def init_from_env(backend: Optional[str] = None, set_device: bool = True) -> Communicator:
+def init_from_env(backend: Optional[str] = None, set_device: bool = True, join_timeout_s: float = 300.0) -> Communicator:
     """Initialise the control-plane process group from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun's env);
     no-op for a single process.  Default backend "gloo": the data path does not use it (see Communicator).
     set_device=False: do not bind this process to cuda:LOCAL_RANK (host-only runs: the CPU tests, `bench.py --dry-run`)."""
@@ -153,11 +167,104 @@ def init_from_env(backend: Optional[str] = None, set_device: bool = True) -> Com
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        rank = int(os.environ.get("RANK", "0"))
+        _await_all_ranks(rank, world, float(os.environ.get("PIGEON_JOIN_TIMEOUT_S", join_timeout_s)))
         dist.init_process_group(backend=backend or "gloo")
         comm = Communicator()
         comm._owns_group = True
         return comm
     return Communicator()
+
+
+def _await_all_ranks(rank: int, world: int, timeout_s: float) -> None:
+    """Bounded wait that NAMES who is missing, in front of torch's own rendezvous.  torch's env:// rendezvous just blocks (30
+    minutes by default) when a rank never shows up -- on an 8-GPU launch the useful message is "rank(s) [5] did not join".
+    One node, one launcher (the contract of this path: one process per GPU of ONE node): every rank drops a file
+    `rank_<r>` into a directory named after the launcher's pid and MASTER_PORT and waits until all `world` files are there or
+    `timeout_s` is over.  Files are removed at exit.  Any filesystem trouble skips the check -- torch's rendezvous then does its
+    own waiting (this must never break a launch that would have worked)."""
+    import atexit
+    import tempfile
+    import time
+    try:
+        d = os.path.join(tempfile.gettempdir(), f"pigeon_join_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}")
+        os.makedirs(d, exist_ok=True)
+        mine = os.path.join(d, f"rank_{rank}")
+        with open(mine, "w") as f:
+            f.write(str(os.getpid()))
+
+        def _cleanup():
+            try:
+                os.remove(mine)
+                os.rmdir(d)
+            except OSError:
+                pass
+        atexit.register(_cleanup)
+    except OSError:
+        return
+    t_end = time.time() + timeout_s
+    while True:
+        missing = [r for r in range(world) if not os.path.exists(os.path.join(d, f"rank_{r}"))]
+        if not missing:
+            return
+        if time.time() > t_end:
+            raise TimeoutError(f"rank {rank}: rank(s) {missing} of {world} did not join within {timeout_s:.0f} s "
+                               f"(launcher pid {os.getppid()}, MASTER_PORT {os.environ.get('MASTER_PORT')})")
+        time.sleep(0.05)
+
+
+def gpu_cpu_affinity(local_cpulists: List[Optional[str]], local_rank: int) -> Optional[List[int]]:
+    """Host cores for the process that drives GPU `local_rank`: the cores of the GPU's NUMA node (`local_cpulist` of its PCI
+    device), split evenly between the local ranks whose GPUs hang off the same node.  local_cpulists[r] is rank r's sysfs string
+    ("0-31,128-159") or None (unknown -> no pinning).  Pure function: tests/test_distributed_cpu.py."""
+    mine = local_cpulists[local_rank] if 0 <= local_rank < len(local_cpulists) else None
+    if not mine:
+        return None
+    cpus = parse_cpulist(mine)
+    peers = [r for r, s in enumerate(local_cpulists) if s and parse_cpulist(s) == cpus]
+    if not cpus or local_rank not in peers:
+        return None
+    k, n = peers.index(local_rank), len(peers)
+    per = len(cpus) // n
+    if per == 0:
+        return cpus
+    return cpus[k * per:(k + 1) * per]
+
+
+def parse_cpulist(s: str) -> List[int]:
+    out: List[int] = []
+    for part in s.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return sorted(set(out))
+
+
+def gpu_local_cpulist(device_index: int) -> Optional[str]:
+    """sysfs `local_cpulist` of the PCI device behind cuda:<device_index> (None when it cannot be read)."""
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/local_cpulist") as f:
+            return f.read().strip() or None
+    except Exception:  # noqa
+        return None
+
+
+def pin_to_gpu_numa(local_rank: int, local_world: int) -> Optional[List[int]]:
+    """sched_setaffinity of this process to its share of the cores next to its GPU; returns the cores (None: not pinned)."""
+    try:
+        lists = [gpu_local_cpulist(r) for r in range(local_world)]
+        cpus = gpu_cpu_affinity(lists, local_rank)
+        if cpus:
+            allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+            if allowed:
+                os.sched_setaffinity(0, allowed)
+                return allowed
+    except Exception:  # noqa
+        pass
+    return None
 
 
 def _is_sample_list(b) -> bool:
