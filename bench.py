@@ -68,6 +68,10 @@ GEMM_FLOPS = {                       # algorithmic FLOPs per token row of each G
     "gemm_qkv": 2 * 1024 * 3072, "gemm_out": 2 * 1024 * 1024, "gemm_fc1": 2 * 1024 * 4096, "gemm_fc2": 2 * 4096 * 1024,
 }
 RAW_HW = 640                         # synthetic raw image geometry of the ingest leg (Street View panels are 640 x 640)
+try:
+    ORIG_AFFINITY = os.sched_getaffinity(0)      # before pin_to_gpu_numa narrows it; the CPU-baseline workers get the whole set back
+except (AttributeError, OSError):
+    ORIG_AFFINITY = None
 
 
 def parse(argv=None):
@@ -81,8 +85,8 @@ def parse(argv=None):
     ap.add_argument("--topk", type=int, default=5)
     ap.add_argument("--layers", type=int, default=24)
     ap.add_argument("--pixel-batches", type=int, default=4, help="distinct resident pixel batches used in turn")
-    ap.add_argument("--cpu-images", type=int, default=256, help="images in the bounded CPU-baseline / parity sample (0 = skip); 256 = 64 panoramas")
-    ap.add_argument("--cpu-port-images", type=int, default=64, help="images through the oracle restatement (kind 'port') on the CPU (0 = skip)")
+    ap.add_argument("--cpu-images", type=int, default=64, help="images in the bounded CPU-baseline / CPU-oracle parity sample (0 = skip); 64 = 16 panoramas")
+    ap.add_argument("--cpu-port-images", type=int, default=16, help="images through the oracle restatement (kind 'port') on the CPU (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="CPU-baseline worker processes x 16 threads (0 = hardware threads / 16)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)       # internal: run one CPU-baseline worker from a spec file
     ap.add_argument("--exact-steps", type=int, default=3, help="steps of the exact-mode leg after the timed region (0 = skip)")
@@ -153,6 +157,24 @@ class _LazyRows:
         return self.t[idx].cpu()
 
 
+def cpu_quota_cores():
+    """CPUs' worth of time this container may use: min(visible cpus, cgroup v2 cpu.max quota / period, cgroup v1 cfs quota)."""
+    n = float(len(os.sched_getaffinity(0)))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, float(q) / float(per))
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, q / per)
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -217,7 +239,7 @@ def cpu_pool(kind, px_images, layers, workers, threads, weight_seed=0):
     import torch
     n = px_images.shape[0]
     workers = max(1, min(workers, n))
-    avail = sorted(os.sched_getaffinity(0))
+    avail = sorted(ORIG_AFFINITY or os.sched_getaffinity(0))     # not the GPU-side pinning of the bench process itself
     threads = max(1, min(threads, len(avail) // workers if len(avail) >= workers else 1))
     tmp = tempfile.mkdtemp(prefix="pigeon_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     bounds = [round(i * n / workers) for i in range(workers + 1)]
@@ -272,7 +294,11 @@ def cpu_baseline(args, model, bank_t, px):
     from oracle import pigeon_oracle as orc
     npano = px.shape[0]
     cores = os.cpu_count() or 1
-    workers = args.cpu_workers if args.cpu_workers > 0 else max(1, cores // 16)
+    quota = cpu_quota_cores()
+    # the host's USABLE cores: the GPU boxes of this pool show 256 hardware threads but run the container under a cgroup quota of 16
+    # CPUs (cpu.max 1600000 100000; tools/cpu_probe.sh: 1 x 16 threads 1.40 TFLOP/s fp32, 16 x 16 threads 0.97 with 917 throttled
+    # periods) -- threads beyond the quota only add throttling, so the pool is sized to the quota, in 16-thread processes
+    workers = args.cpu_workers if args.cpu_workers > 0 else max(1, int(quota) // 16)
     images = px.reshape(-1, 3, 336, 336)
     emb_i, wall, per, busy = cpu_pool("module", images, args.layers, workers, 16)
     emb = emb_i.reshape(npano, 4, 1024)
@@ -298,7 +324,8 @@ def cpu_baseline(args, model, bank_t, px):
         refined = (r_llh, r_cell, hb)
     t_tail = time.time() - t0
     dt = wall + t_tail
-    res = {"value": npano * 4 / dt, "unit": "images/s", "cores": busy, "box_cores": cores, "kind": "reference-module",
+    res = {"value": npano * 4 / dt, "unit": "images/s", "cores": busy, "box_cores": cores, "cgroup_cpu_quota_cores": quota,
+           "kind": "reference-module",
            "workers": len(per), "threads_per_worker": busy // max(1, len(per)),
            "encoder_images_per_s": npano * 4 / wall, "per_worker_seconds": [round(x, 2) for x in per],
            "sample": f"{npano} panoramas = {npano * 4} images of this run's resident pixel batches through transformers.CLIPVisionModel "
@@ -375,6 +402,58 @@ def parity_report(args, dev, model, o, refined, hip):
         rep["refined_cell_equal_where_argmax_equal"] = f"{int((hip['refined_geocell'].cpu()[keep] == r_cell[keep]).sum())}/{int(keep.sum())}"
         same_ll = (hip["refined_LLH"].cpu()[keep] == r_llh[keep]).all(dim=1)
         rep["refined_lnglat_equal_where_argmax_equal"] = f"{int(same_ll.sum())}/{int(keep.sum())}"
+    return rep
+
+
+def gpu_module_parity(args, dev, vit_sd, model, pixel_batches, used, outs_default, certain_by_batch, outs_exact, cpu_sample_emb, per):
+    """Top-1 parity over EVERY panorama of the resident pixel batches (4 x 128 = 512), which the 16-CPU quota of these boxes puts out
+    of the CPU oracle's reach: the reference's own module -- transformers.CLIPVisionModel, fp32, eager attention, stock
+    PyTorch-ROCm -- runs on this GPU (never part of the product path), the oracle's head turns its embeddings into logits, and the
+    default and exact-mode outputs of this run are compared with that.  The CPU oracle's embeddings of the bounded sample pin
+    the GPU-fp32 module first (`vs_cpu_oracle_embedding_rel_err`)."""
+    import torch
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    from oracle import pigeon_oracle as orc
+    cfg = CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=args.layers, num_attention_heads=16,
+                           image_size=336, patch_size=14, projection_dim=768)
+    with contextlib.redirect_stdout(io.StringIO()):
+        hf = CLIPVisionModel._from_config(cfg, attn_implementation="eager")    # explicit matmul / softmax / matmul in fp32
+    hf.load_state_dict(vit_sd, strict=True)
+    hf = hf.to(dev).eval()
+    torch.backends.cuda.matmul.allow_tf32 = False
+    embs = []
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for j in used:
+            px = pixel_batches[j].reshape(-1, 3, 336, 336)
+            embs.append(torch.cat([hf(pixel_values=px[i:i + 32]).last_hidden_state.mean(dim=1) for i in range(0, px.shape[0], 32)]))
+    torch.cuda.synchronize()
+    t_ref = time.perf_counter() - t0
+    ref_emb = torch.cat(embs).reshape(-1, 4, 1024).cpu()
+    del hf
+    torch.cuda.empty_cache()
+    W, b, cen = model.cell_layer.weight.data.cpu(), model.cell_layer.bias.data.cpu(), model.lla_geocells.data.cpu()
+    o = orc.super_guessr_forward(W, b, cen, args.topk, embedding=ref_emb)
+    n_per = pixel_batches[0].shape[0]
+    where = [f"batch {j} #{i}" for j in used for i in range(n_per)]
+
+    def take(outs):
+        return {"embedding": torch.cat([outs[j]["embedding"] for j in used]), "preds_geocell": torch.cat([outs[j]["preds_geocell"] for j in used]),
+                "where": where}
+    rep = parity_report(args, dev, model, o, None, take(outs_default))
+    rep["from"] = "pixels through transformers.CLIPVisionModel fp32 (eager attention, stock PyTorch-ROCm) on this GPU vs this run's step outputs"
+    rep["oracle"] = "the reference's module in fp32 on the GPU + the oracle's head; pinned to the CPU oracle on the bounded sample below"
+    rep["reference_seconds"] = t_ref
+    cert = torch.cat([certain_by_batch[j][0] for j in used]).cpu()
+    rep["certain"] = f"{int(cert.sum())}/{cert.numel()}"
+    rep["flips_among_certain"] = int(sum(1 for r in rep["flipped"] if bool(cert[where.index(r["panorama"])])))
+    rep.pop("smallest_margins", None)
+    if outs_exact and all(j in outs_exact for j in used):
+        rx = parity_report(args, dev, model, o, None, take(outs_exact))
+        rep["exact_mode"] = {k: rx[k] for k in ("embedding_rel_err", "logit_abs_err_max", "flips", "flipped", "geocell_argmax_equal")}
+    if cpu_sample_emb is not None:
+        sel = torch.cat([ref_emb[k * n_per:k * n_per + per] for k in range(len(used))])
+        rep["vs_cpu_oracle_embedding_rel_err"] = orc.rel_err(sel, cpu_sample_emb)
     return rep
 
 
@@ -894,6 +973,7 @@ def _worker(args, comm):
     # ---- exact mode: the same step with SuperGuessr(exact_top1): panoramas whose top-1 margin is inside the 16-bit path's error
     # band are re-encoded from their pixels in near-fp32 arithmetic (pg_vit_forward_precise) -- its cost, stated next to `value` ----
     exact_outs = {}
+    cpu_sample_emb, cpu_per = None, 0
     if world == 1 and args.exact_steps > 0:
         try:
             base.enable_precise(True)                             # repacks the encoder with the split-weight copy (one-off)
@@ -915,6 +995,8 @@ def _worker(args, comm):
             result["exact_mode"] = {
                 "value": args.panoramas * 4 / te, "unit": "images/s", "ms_per_step": te * 1e3, "steps": args.exact_steps,
                 "cost_vs_default": te * 1e3 / step_ms, "reencoded_panoramas_per_step": n_re, "panoramas_per_step": args.panoramas,
+                "margin_rel_tol_calibrated": model.margin_rel_tol, "margin_kappa": model.margin_kappa,
+                "fast_vs_exact_embedding_rms": (model._cal_sumsq / max(1, model._cal_n)) ** 0.5, "calibration_samples": model._cal_n,
                 "what": "PIGEON_EXACT_TOP1=1 / SuperGuessr(exact_top1=True): after the fast pass, panoramas that are not certain (see "
                         "certainty_rule) are re-encoded FROM THE PIXELS by pg_vit_forward_precise (split-fp16 GEMM operands on the same "
                         "MFMA kernels, fp32 attention / LayerNorm / QuickGELU: ~1e-6 relative vs 2.7e-4) and their head outputs recomputed; "
@@ -953,9 +1035,18 @@ def _worker(args, comm):
                 rep["exact_mode"] = {k: rx[k] for k in ("embedding_rel_err", "logit_abs_err_max", "flips", "flipped", "geocell_argmax_equal",
                                                          "refined_cell_equal_where_argmax_equal", "refined_lnglat_equal_where_argmax_equal") if k in rx}
             result["parity_vs_oracle_sample"] = rep
+            cpu_sample_emb, cpu_per = o["embedding"], per
         except Exception as e:  # noqa
             import traceback
             result["cpu_baseline"] = {"error": str(e), "trace": traceback.format_exc()[-800:]}
+    if world == 1 and not args.no_extras:
+        try:
+            used = sorted(outs_by_batch)
+            result["parity_vs_reference_module_gpu_fp32"] = gpu_module_parity(
+                args, dev, vit_sd, model, pixel_batches, used, outs_by_batch, certain_by_batch, exact_outs, cpu_sample_emb, cpu_per)
+        except Exception as e:  # noqa
+            import traceback
+            result["parity_vs_reference_module_gpu_fp32"] = {"error": repr(e), "trace": traceback.format_exc()[-600:]}
     if world == 1 and not args.no_extras:
         del pixel_batches
         torch.cuda.empty_cache()

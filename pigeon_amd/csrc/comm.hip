@@ -11,6 +11,8 @@
 #include "pigeon_internal.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <rccl/rccl.h>
@@ -93,7 +95,15 @@ extern "C" int pg_comm_init_rank(void** comm, int nranks, const void* unique_id,
     if (hipGetDevice(&c->device) != hipSuccess) { delete c; pg_set_error("comm_init_rank: no current HIP device"); return PG_EHIP; }
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
+    // RCCL 2.26 prints a two-line version banner on STDOUT (through C stdio) when its first communicator comes up; a host program
+    // whose stdout is a protocol (bench.py: ONE JSON line) must not carry it: stdout is pointed at stderr for the duration of the
+    // call, flushed on both sides.
+    fflush(stdout);
+    const int saved = dup(STDOUT_FILENO);
+    if (saved >= 0) (void)dup2(STDERR_FILENO, STDOUT_FILENO);
     ncclResult_t e = R->CommInitRank(&c->comm, nranks, id, rank);
+    fflush(stdout);
+    if (saved >= 0) { (void)dup2(saved, STDOUT_FILENO); (void)close(saved); }
     if (e != ncclSuccess) { pg_set_error("ncclCommInitRank failed: %s", R->GetErrorString(e)); delete c; return PG_EHIP; }
     *comm = c;
     return PG_OK;

@@ -48,7 +48,9 @@ class SuperGuessr(nn.Module):
         Extra keywords: `exact_top1` (default: env PIGEON_EXACT_TOP1=1) -- samples that are not certain are re-encoded FROM THE
         PIXELS in the encoder's exact mode (pg_vit_forward_precise: split-fp16 GEMM operands, fp32 attention; ~1e-6 relative, ~5x
         the time per image) and their head outputs recomputed, so that their top-1 is the fp32 one; `margin_rel_tol` (default
-        1e-3 = the embedding tolerance of the contract, 1.5-4x the measured error) and `margin_kappa` (default 4).
+        1e-3 = the embedding tolerance of the contract, 1.5-4x the measured error; in exact mode it is re-calibrated on the fly to
+        1.25 x the RMS difference between the fast and the exact embeddings of the re-encoded samples, `margin_autocalibrate`)
+        and `margin_kappa` (default 4: a z-score, the margin change being Gaussian in units of rel_tol * sens).
         """
         super(SuperGuessr, self).__init__()
         geocell_path = kwargs.pop('geocell_path', None)
@@ -57,6 +59,8 @@ class SuperGuessr(nn.Module):
         self.margin_rel_tol = float(kwargs.pop('margin_rel_tol', os.environ.get('PIGEON_MARGIN_REL_TOL', 1e-3)))
         self.margin_rel_tol_exact = float(kwargs.pop('margin_rel_tol_exact', 2e-5))
         self.margin_kappa = float(kwargs.pop('margin_kappa', os.environ.get('PIGEON_MARGIN_KAPPA', 4.0)))
+        self.margin_autocalibrate = bool(kwargs.pop('margin_autocalibrate', True))
+        self._cal_sumsq, self._cal_n = 0.0, 0
         self.last_margin = self.last_bound = self.last_certain = self.last_reencoded = None
         if len(kwargs) > 0:
             print(f'Not using keyword arguments: {list(kwargs.keys())}')
@@ -224,6 +228,17 @@ class SuperGuessr(nn.Module):
             px = pixel_values.reshape((-1, P, 3, 336, 336))[idx.to(pixel_values.device)].reshape((-1, 3, 336, 336))
             emb_x = self._encoder().embed_precise(px.to(W.device))
             emb_x = emb_x.reshape((idx.numel(), P, emb_x.shape[-1])) if self.panorama else emb_x
+            # what the 16-bit path's embedding error IS on this model: the exact re-encode of the uncertain samples measures it
+            # (panel-mean embeddings, relative L2).  1.25 x its running RMS replaces the conservative default of `margin_rel_tol`
+            # once 8 samples have been seen -- the margin change it explains is Gaussian in those units (observed max over 128
+            # panoramas: 2.8 x the RMS), so kappa is a z-score
+            fast_mean = head_in[idx].reshape(idx.numel(), -1, head_in.shape[-1]).mean(dim=1) if head_in.dim() == 3 else head_in[idx]
+            exact_mean = emb_x.mean(dim=1) if emb_x.dim() == 3 else emb_x
+            rel2 = ((fast_mean - exact_mean).norm(dim=1) / exact_mean.norm(dim=1).clamp_min(1e-30)) ** 2
+            self._cal_sumsq += float(rel2.sum())
+            self._cal_n += int(rel2.numel())
+            if self.margin_autocalibrate and self._cal_n >= 8:
+                self.margin_rel_tol = max(1.25 * (self._cal_sumsq / self._cal_n) ** 0.5, 4 * self.margin_rel_tol_exact)
             embedding = embedding.clone()
             embedding[idx] = emb_x
             if self.panorama:
