@@ -106,6 +106,28 @@ class HipCLIPVisionModel(torch.nn.Module):
         return SimpleNamespace(last_hidden_state=hid, pooler_output=None, token_mean=emb)
 
 
+def load_pretrained_clip(name: Optional[str] = None) -> HipCLIPVisionModel:
+    """`CLIPVisionModel.from_pretrained(CLIP_MODEL)` of the reference (models/clip_embedder.py:26, evaluation/evaluate.py:36), offline:
+    `name` (default: env PIGEON_CLIP_MODEL, else config.CLIP_MODEL) is resolved by transformers with `local_files_only=True` -- a
+    directory written by `save_pretrained`, or the hub id if it sits in the local HuggingFace cache -- and its vision-tower state
+    dict is packed into a `HipCLIPVisionModel`.  A full CLIPModel checkpoint works as well (its `vision_model.*` keys are taken).
+    Raises RuntimeError with the reason when neither is there (this container has no network and no cache)."""
+    name = name or os.environ.get("PIGEON_CLIP_MODEL") or CLIP_MODEL
+    try:
+        from transformers import CLIPVisionModel
+        hf = CLIPVisionModel.from_pretrained(name, local_files_only=True)
+    except Exception as e:  # noqa  (OSError: not cached; ImportError: no transformers; ValueError: bad directory)
+        raise RuntimeError(f"CLIPVisionModel.from_pretrained({name!r}, local_files_only=True) failed: {type(e).__name__}: {e}") from e
+    cfg = hf.config
+    geom = (cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.image_size, cfg.patch_size)
+    if geom != (1024, 4096, 16, 336, 14):
+        raise RuntimeError(f"{name!r} is not a ViT-L/14-336 vision tower (hidden, mlp, heads, image, patch = {geom}); "
+                           "the HIP encoder is built for that geometry only")
+    m = HipCLIPVisionModel(hf.state_dict(), layers=cfg.num_hidden_layers)
+    m.config._name_or_path = name
+    return m
+
+
 def _to_device_pixels(pixel_values: Tensor, device) -> Tensor:
     if not pixel_values.is_cuda:
         dev = device if (isinstance(device, torch.device) and device.type == "cuda") else torch.device("cuda")
@@ -166,8 +188,8 @@ def _preprocessor(in_h: int, in_w: int, device_index: int) -> "hip_ops.Preproces
         p = hip_ops.Preprocessor(key[0], key[1], device=key[2])
     _PREPROCESSORS[key] = p                                        # most recently used last
     while len(_PREPROCESSORS) > _PREPROCESSORS_MAX:
-        _, old = _PREPROCESSORS.popitem(last=False)
-        torch.cuda.synchronize(key[2])                             # its tables may still be read by a queued kernel
+        old_key, old = _PREPROCESSORS.popitem(last=False)
+        torch.cuda.synchronize(old_key[2])                         # ITS device: its tables may still be read by a queued kernel
         old.close()
     return p
 
@@ -213,8 +235,9 @@ class CLIPEmbedding(torch.nn.Module):
         """CLIP embedding model (not trainable) -- reference models/clip_embedder.py:11-40.
 
         Args follow the reference.  The reference pulls the base weights from the HuggingFace hub
-        (`CLIPVisionModel.from_pretrained(CLIP_MODEL)`, :26), which is impossible offline; the two extra keyword
-        arguments supply them instead: `state_dict` (transformers CLIPVisionModel names) or a ready
+        (`CLIPVisionModel.from_pretrained(CLIP_MODEL)`, :26); here the same call runs with `local_files_only=True`
+        (`load_pretrained_clip`: the local HF cache, or a `save_pretrained` directory named by env PIGEON_CLIP_MODEL), and two extra
+        keyword arguments can supply the weights instead: `state_dict` (transformers CLIPVisionModel names) or a ready
         `clip_model`.  With `load_checkpoint=True`, `model_name` is a torch checkpoint copied over the weights by
         name with the leading `base_model.` component stripped, exactly as :30-32 does.
         """
@@ -225,15 +248,20 @@ class CLIPEmbedding(torch.nn.Module):
             self.clip_model = clip_model
         elif state_dict is not None:
             self.clip_model = HipCLIPVisionModel(state_dict)
-        elif load_checkpoint and os.path.exists(model_name):
-            ckpt = torch.load(model_name, map_location='cpu')
-            ckpt = {('.'.join(k.split('.')[1:]) if 'base_model' in k else k): v for k, v in ckpt.items()}
-            self.clip_model = HipCLIPVisionModel(ckpt)
-            load_checkpoint = False
         else:
-            raise RuntimeError(
-                "CLIPEmbedding: no weights. The reference downloads openai/clip-vit-large-patch14-336 from the hub; "
-                "offline, pass state_dict=... / clip_model=... or a checkpoint path with load_checkpoint=True.")
+            try:                                                     # the reference's way (:25-26), from local files only
+                self.clip_model = load_pretrained_clip()
+            except RuntimeError as why:
+                if load_checkpoint and os.path.exists(model_name):   # no base weights here, but the checkpoint carries the tower
+                    ckpt = torch.load(model_name, map_location='cpu')
+                    ckpt = {('.'.join(k.split('.')[1:]) if 'base_model' in k else k): v for k, v in ckpt.items()}
+                    self.clip_model = HipCLIPVisionModel(ckpt)
+                    load_checkpoint = False
+                else:
+                    raise RuntimeError(
+                        "CLIPEmbedding: no weights. The reference downloads openai/clip-vit-large-patch14-336 from the hub; offline, "
+                        "point PIGEON_CLIP_MODEL at a directory written by save_pretrained (or have the hub id in the local HF cache), "
+                        "pass state_dict=... / clip_model=..., or a checkpoint path with load_checkpoint=True.  " + str(why)) from why
         self.panorama = panorama
 
         if load_checkpoint:

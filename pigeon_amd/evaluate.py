@@ -119,7 +119,10 @@ def evaluate(model: str, dataset, yfcc: bool, landmarks: bool, base_model=None, 
              dataset_path=None, bank=None, head_state: Optional[str] = None):
     """reference evaluation/evaluate.py:10-85.
 
-    `base_model`: a `HipCLIPVisionModel` (or None to evaluate on precomputed embeddings).  `model` is the path of
+    `base_model`: as in the reference a STRING -- config.CLIP_MODEL for the pretrained tower, or the path of a checkpoint whose
+    weights are copied over it by name (`load_state_dict`, :36-40; the pretrained tower is resolved from local files only, see
+    `clip_embedder.load_pretrained_clip`) -- or, additionally, a ready module (`HipCLIPVisionModel`, or any module with a
+    transformers CLIPVisionModel state dict), or None to evaluate on precomputed embeddings.  `model` is the path of
     the head checkpoint (`full_model.load_state(model)`, :46); evaluate() uses the reference's two refiner
     parameter sets (:73-80): first build -> ProtoRefiner(20, False, 10000, temperature=1); cached prototypes ->
     ProtoRefiner(40, False, 100000, temperature=0.6).  "Cached" means, in this order: a `bank` argument, the packed CSR
@@ -129,6 +132,28 @@ def evaluate(model: str, dataset, yfcc: bool, landmarks: bool, base_model=None, 
     """
     import os
     from . import config as cfg
+    if isinstance(base_model, str):                                               # reference :36-40
+        from .clip_embedder import HipCLIPVisionModel, load_pretrained_clip
+        from .utils import load_state_dict
+        path = base_model
+        try:
+            base_model = load_pretrained_clip()                                   # CLIP_MODEL, or the directory env PIGEON_CLIP_MODEL names
+            if path != cfg.CLIP_MODEL:
+                state_dict = torch.load(path, map_location='cpu')
+                load_state_dict(base_model, state_dict)
+                print(f'Initialized base model with weights from: {path}')
+        except RuntimeError as why:
+            if path == cfg.CLIP_MODEL or not os.path.exists(path):
+                raise
+            # no pretrained tower on this machine, but the checkpoint may carry all of it (base_model.* / vision_model.* names)
+            state_dict = torch.load(path, map_location='cpu')
+            state_dict = {('.'.join(k.split('.')[1:]) if 'base_model' in k.split('.')[0] else k): v for k, v in state_dict.items()}
+            keys = {k[len('vision_model.'):] if k.startswith('vision_model.') else k for k in state_dict}
+            if 'embeddings.patch_embedding.weight' not in keys or 'encoder.layers.0.mlp.fc2.weight' not in keys:
+                raise RuntimeError(f'evaluate: {path!r} does not hold a complete vision tower and the pretrained one is unavailable '
+                                   f'({why})') from why
+            base_model = HipCLIPVisionModel(state_dict)
+            print(f'Initialized base model with weights from: {path} (pretrained tower unavailable: checkpoint only)')
     full_model = SuperGuessr(base_model, panorama=True, hierarchical=False, multi_task=False, heading=heading,
                              freeze_base=True, yfcc=yfcc, num_candidates=50, geocell_path=geocell_path)
     # the reference's torch.load raises on a missing checkpoint (:46); only the explicit random-init names skip loading

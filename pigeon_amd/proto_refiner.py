@@ -176,11 +176,24 @@ def load_refiner_cache(path: str):
     class _Shell(nn.Module):
         """stands in for any class of the reference's `models` package found in the pickle"""
 
+    # A pickle executes what it names.  The reference's cache holds: its own ProtoRefiner (-> _Shell), torch tensors / parameters /
+    # module bookkeeping, `datasets` objects (per-cell Dataset, DatasetDict, features, the in-memory Arrow table), pyarrow, numpy
+    # and plain containers.  Globals of exactly those packages are resolved; anything else (os, subprocess, builtins.eval ...)
+    # is refused by name -- evaluate() reads this file implicitly whenever the packed .npz is absent.
+    allowed_roots = ('torch', 'collections', 'datasets', 'pyarrow', 'numpy', 'pandas', 'copyreg', '_codecs', 'functools', 'dill',
+                     'multiprocess', 'fsspec', 'pathlib', 'types', 'typing')
+    allowed_builtins = {'set', 'frozenset', 'list', 'dict', 'tuple', 'bytes', 'bytearray', 'str', 'int', 'float', 'bool', 'complex',
+                        'slice', 'range', 'object', 'getattr', 'NoneType'}
+
     class _Unpickler(pickle.Unpickler):
         def find_class(self, module, name):
             if module == 'models' or module.startswith('models.'):
                 return _Shell
-            return super().find_class(module, name)
+            root = module.split('.')[0]
+            if root in allowed_roots or (module in ('builtins', '__builtin__') and name in allowed_builtins):
+                return super().find_class(module, name)
+            raise pickle.UnpicklingError(f'refiner cache {path!r} names {module}.{name}: not a class a refiner cache holds '
+                                         f'(allowed: the reference\'s models.*, {", ".join(allowed_roots)}, plain containers)')
 
     pm = types.ModuleType('pigeon_amd._refiner_pickle')
     pm.Unpickler = _Unpickler

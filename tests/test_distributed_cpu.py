@@ -175,3 +175,38 @@ def test_shard_batches_takes_the_batch_size_from_a_tensor_leaf():
     assert isinstance(out[0][1], NT) and out[0][1].idx.tolist() == [6, 0, 1] and out[1][1].idx.tolist() == [2, 3, 4]
     with pytest.raises(ValueError):
         list(shard_batches([{"a": None}, {"a": None}, {"a": None}], 0, 2))
+
+
+def test_gpu_cpu_affinity_plan():
+    """One process per GPU: each rank's launch thread stays on the cores next to ITS GPU; ranks whose GPUs share a NUMA node split
+    that node's cores evenly; an unreadable topology means no pinning (pure function, bench.py applies it with sched_setaffinity)."""
+    from pigeon_amd import distributed as d
+    assert d.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    lists = ["0-7,16-23", "0-7,16-23", "8-15,24-31", None]
+    assert d.gpu_cpu_affinity(lists, 0) == [0, 1, 2, 3, 4, 5, 6, 7]
+    assert d.gpu_cpu_affinity(lists, 1) == [16, 17, 18, 19, 20, 21, 22, 23]
+    assert d.gpu_cpu_affinity(lists, 2) == [8, 9, 10, 11, 12, 13, 14, 15, 24, 25, 26, 27, 28, 29, 30, 31]
+    assert d.gpu_cpu_affinity(lists, 3) is None and d.gpu_cpu_affinity(lists, 7) is None
+    all8 = ["0-63,128-191"] * 4 + ["64-127,192-255"] * 4                       # the 8-GPU, 2-socket box
+    plans = [d.gpu_cpu_affinity(all8, r) for r in range(8)]
+    assert all(len(p) == 32 for p in plans) and len(set(sum(plans, []))) == 256
+
+
+def test_missing_rank_is_named_within_the_join_timeout(tmp_path):
+    """A rank that never shows up: the others fail after PIGEON_JOIN_TIMEOUT_S with its id in the message, instead of sitting
+    in torch's 30-minute rendezvous."""
+    import subprocess, sys, socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               PIGEON_JOIN_TIMEOUT_S="1.5", PYTHONPATH=ROOT)
+    code = "from pigeon_amd import distributed as d; d.init_from_env('gloo', set_device=False)"
+    p0 = subprocess.Popen([sys.executable, "-c", code], env=env, stderr=subprocess.PIPE, text=True)
+    p2 = subprocess.Popen([sys.executable, "-c", code], env=dict(env, RANK="2", LOCAL_RANK="2"), stderr=subprocess.PIPE, text=True)
+    e0, e2 = p0.communicate(timeout=120)[1], p2.communicate(timeout=120)[1]
+    assert p0.returncode != 0 and p2.returncode != 0
+    # (the rank that gives up first removes its own file on the way out, so the later one may list it as well)
+    assert "rank(s) [1] of 3 did not join" in e0 or "rank(s) [1] of 3 did not join" in e2
+    for e in (e0, e2):
+        assert "did not join within" in e and "1" in e.split("rank(s) [")[1].split("]")[0]

@@ -315,3 +315,90 @@ def test_load_refiner_cache_committed_reference_pickle(golden_dir, tmp_path):
     ds_dir = os.path.join(str(tmp_path), "hf_train")
     synthetic.write_bank_reference_files(bank, os.path.join(str(tmp_path), "protos.csv"), ds_dir)
     _arrays_equal(bank_from_protos(protos, ds_dir), bank)
+
+
+def test_pretrained_tower_from_local_files(tmp_path, monkeypatch):
+    """reference models/clip_embedder.py:25-26 and evaluation/evaluate.py:36-40 call `CLIPVisionModel.from_pretrained(CLIP_MODEL)`;
+    offline the same call runs with local_files_only=True against a `save_pretrained` directory (env PIGEON_CLIP_MODEL) or the HF
+    cache.  A one-layer tower of the ViT-L/14-336 geometry stands in for the hub checkpoint."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    from pigeon_amd import clip_embedder, synthetic
+    from pigeon_amd.clip_embedder import CLIPEmbedding, HipCLIPVisionModel, load_pretrained_clip
+    cfg = CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=1, num_attention_heads=16, image_size=336,
+                           patch_size=14, projection_dim=768)
+    hf = CLIPVisionModel(cfg)
+    sd = synthetic.make_vit_weights(seed=3, layers=1, affine_jitter=True)
+    hf.load_state_dict(sd, strict=True)
+    d = str(tmp_path / "clip_local")
+    hf.save_pretrained(d)
+    m = load_pretrained_clip(d)
+    assert isinstance(m, HipCLIPVisionModel) and m.config.num_hidden_layers == 1
+    got = m.state_dict()
+    for k, v in sd.items():
+        assert torch.equal(got[k], v), k
+    # nothing cached under the hub id, no directory: the reason is in the message
+    monkeypatch.delenv("PIGEON_CLIP_MODEL", raising=False)
+    with pytest.raises(RuntimeError, match="local_files_only"):
+        load_pretrained_clip()
+    with pytest.raises(RuntimeError, match="PIGEON_CLIP_MODEL"):
+        CLIPEmbedding("openai/clip-vit-large-patch14-336", device="cpu")
+    # the reference's constructor call, resolved through the environment
+    monkeypatch.setenv("PIGEON_CLIP_MODEL", d)
+    emb = CLIPEmbedding("openai/clip-vit-large-patch14-336", device="cpu")
+    assert torch.equal(emb.clip_model.state_dict()["encoder.layers.0.mlp.fc1.bias"], sd["encoder.layers.0.mlp.fc1.bias"])
+    # ... and with a checkpoint copied over it the reference's way (embedder=True strips `base_model.`)
+    ck = {"base_model." + k: v + 1 for k, v in sd.items() if k.startswith("encoder.layers.0.mlp")}
+    ckp = str(tmp_path / "embedder.ckpt")
+    torch.save(ck, ckp)
+    emb2 = CLIPEmbedding(ckp, device="cpu", load_checkpoint=True)
+    assert torch.equal(emb2.clip_model.state_dict()["encoder.layers.0.mlp.fc1.bias"], sd["encoder.layers.0.mlp.fc1.bias"] + 1)
+    assert torch.equal(emb2.clip_model.state_dict()["pre_layrnorm.weight"], sd["pre_layrnorm.weight"])
+    # a tower of another geometry is refused by name
+    small = CLIPVisionModel(CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2,
+                                             image_size=28, patch_size=14, projection_dim=32))
+    d2 = str(tmp_path / "clip_small")
+    small.save_pretrained(d2)
+    with pytest.raises(RuntimeError, match="ViT-L/14-336"):
+        load_pretrained_clip(d2)
+
+
+def test_evaluate_accepts_the_references_base_model_strings(tmp_path, monkeypatch):
+    """reference evaluation/evaluate.py:10-12,36-40: `base_model` is a STRING -- CLIP_MODEL or a checkpoint path.  The string branch
+    is resolved before any GPU work (the SuperGuessr it builds then needs the GPU: stopped there on this box)."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    from pigeon_amd import config as cfg, evaluate as ev, synthetic
+    sd = synthetic.make_vit_weights(seed=4, layers=1)
+    hf = CLIPVisionModel(CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=1, num_attention_heads=16,
+                                          image_size=336, patch_size=14, projection_dim=768))
+    hf.load_state_dict(sd, strict=True)
+    d = str(tmp_path / "clip_local")
+    hf.save_pretrained(d)
+    seen = {}
+
+    class Stop(Exception):
+        pass
+
+    def fake_sg(base_model, **kw):
+        seen["base"] = base_model
+        raise Stop()
+    monkeypatch.setattr(ev, "SuperGuessr", fake_sg)
+    monkeypatch.setenv("PIGEON_CLIP_MODEL", d)
+    with pytest.raises(Stop):
+        ev.evaluate("none", None, False, False, base_model=cfg.CLIP_MODEL)
+    assert torch.equal(seen["base"].state_dict()["pre_layrnorm.bias"], sd["pre_layrnorm.bias"])
+    ck = str(tmp_path / "base.ckpt")
+    torch.save({"vision_model.pre_layrnorm.bias": sd["pre_layrnorm.bias"] + 2}, ck)
+    with pytest.raises(Stop):
+        ev.evaluate("none", None, False, False, base_model=ck)
+    assert torch.equal(seen["base"].state_dict()["pre_layrnorm.bias"], sd["pre_layrnorm.bias"] + 2)
+    # no pretrained tower on the machine: a checkpoint that carries the whole tower still works, a partial one is refused
+    monkeypatch.delenv("PIGEON_CLIP_MODEL")
+    full = str(tmp_path / "full.ckpt")
+    torch.save({"base_model." + k: v for k, v in sd.items()}, full)
+    with pytest.raises(Stop):
+        ev.evaluate("none", None, False, False, base_model=full)
+    assert torch.equal(seen["base"].state_dict()["encoder.layers.0.mlp.fc2.bias"], sd["encoder.layers.0.mlp.fc2.bias"])
+    with pytest.raises(RuntimeError, match="complete vision tower"):
+        ev.evaluate("none", None, False, False, base_model=ck)
+    with pytest.raises(RuntimeError, match="local_files_only"):
+        ev.evaluate("none", None, False, False, base_model=cfg.CLIP_MODEL)
