@@ -17,9 +17,12 @@ LIB = os.path.join(HERE, "libpigeon_hip.so")
 # the product library: production kernels only
 SOURCES = ["vit.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_pp6.hip", "gemm_tail.hip", "attention.hip", "rowops.hip", "precise.hip",
            "preprocess.hip", "geo_proto.hip", "head.hip", "refine.hip", "comm.hip"]
-# additionally in the tools build (--dev): experimental kernel generations kept for A/B work (variant 64, gemm_w4.hip)
-DEV_SOURCES = ["gemm_w4.hip"]
+# additionally in the tools build (--dev), from tools/csrc/: kernel generations the product superseded, kept for A/B work
+# (gemm variant 64 = gemm_w4.hip; attention variants 1, 4..15 = attention_old.hip)
+DEV_DIR = os.path.join(os.path.dirname(HERE), "tools", "csrc")
+DEV_SOURCES = [os.path.join(DEV_DIR, "gemm_w4.hip"), os.path.join(DEV_DIR, "attention_old.hip")]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "pigeon_internal.h"), os.path.join(CSRC, "gemm_epi.h"),
+           os.path.join(CSRC, "attention_common.h"),
            os.path.join(os.path.dirname(HERE), "include", "pigeon_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -55,14 +58,14 @@ def _build(OBJ: str, LIB: str, FLAGS, force: bool, verbose: bool, SOURCES) -> st
     cc = hipcc()
     jobs = []
     for src in SOURCES:
-        s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        s = src if os.path.isabs(src) else os.path.join(CSRC, src)
+        o = os.path.join(OBJ, os.path.basename(src).replace(".hip", ".o"))
         if force or _stale(o, [s] + HEADERS):
             jobs.append((s, o))
 
     def compile_one(job):
         s, o = job
-        cmd = [cc] + FLAGS + (["-ffp-contract=off"] if s.endswith("preprocess.hip") else []) + ["-c", s, "-o", o]
+        cmd = [cc] + FLAGS + ["-I", CSRC] + (["-ffp-contract=off"] if s.endswith("preprocess.hip") else []) + ["-c", s, "-o", o]
         if verbose:
             print("[pigeon_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -74,7 +77,7 @@ def _build(OBJ: str, LIB: str, FLAGS, force: bool, verbose: bool, SOURCES) -> st
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 2)) as ex:
             list(ex.map(compile_one, jobs))
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [os.path.join(OBJ, os.path.basename(s).replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
         cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
