@@ -145,9 +145,17 @@ __device__ __forceinline__ void att8_wait_v(u32x4 (&vf)[4][2]) {
                  :: "memory");
 }
 
+// QB = NQB * WAVES * 16 queries per block:
+//   128 (4 waves x 32)  5 blocks per (image, head) cover 640 query slots (63 idle in the last block), 5 K/V streams per head;
+//   192 (6 waves x 32)  round 4: 577 = 3 x 192 + 1 -- 3 blocks cover queries 0..575 with no idle slot and 3 K/V streams per head;
+//                       token 576's query is left to attention_last_query_kernel below.  Same 32 queries per wave, same registers
+//                       (3 waves per SIMD: two 6-wave blocks per CU where three 4-wave blocks ran); waves 0..3 issue the tile DMAs.
 template <typename T, int NQB, int WAVES, int WPS, bool LSUM = false>
-__global__ __launch_bounds__(256, WPS) void attention8_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
-    static_assert(NQB * WAVES * 16 == ATT_QB, "a block covers 128 queries");
+__global__ __launch_bounds__(WAVES * 64, WPS) void attention8_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
+    constexpr int QB = NQB * WAVES * 16;
+    static_assert(QB == 128 || QB == 192, "a block covers 128 or 192 queries");
+    constexpr int NQBLK = QB == 192 ? 3 : ATT_NQB;
+    constexpr int DW = WAVES < 4 ? WAVES : 4;               // waves that stage the K / V tiles
     static_assert(VIT_TOKENS == 9 * ATT_KT + 1, "key tail assumes 577 tokens");
     __shared__ __attribute__((aligned(16))) char smem[4 * K_TILE_BYTES];              // K0 K1 V0 V1, 8 KB each
     char* ks0 = smem;
@@ -157,12 +165,13 @@ __global__ __launch_bounds__(256, WPS) void attention8_kernel(const uint16_t* __
     const int r16 = lane & 15, g4 = lane >> 4;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
-    const int qblk = slot % ATT_NQB;
-    const int pair = (slot / ATT_NQB) * 8 + xcd;
+    const int qblk = slot % NQBLK;
+    const int pair = (slot / NQBLK) * 8 + xcd;
     const int img = pair >> 4, head = pair & 15;
     const int64_t base = (int64_t)img * VIT_TOKENS;
-    const int q_first = qblk * ATT_QB + wave * (NQB * 16);   // wave-uniform
+    const int q_first = qblk * QB + wave * (NQB * 16);       // wave-uniform
     const bool wave_active = q_first < VIT_TOKENS;
+    constexpr int Q_END = QB == 192 ? VIT_TOKENS - 1 : VIT_TOKENS;   // 192-query blocks stop at query 575
 
     typename T::v8 qf[NQB][2];
 #pragma unroll
@@ -202,25 +211,28 @@ __global__ __launch_bounds__(256, WPS) void attention8_kernel(const uint16_t* __
         const_cast<uint16_t*>(qkv + base * QKV_LD + 1024 + head * 64), (short)0, (int)(VIT_TOKENS * QKV_LD * 2), 0x00020000);
     __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(qkv + base * QKV_LD + 2048 + head * 64), (short)0, (int)(VIT_TOKENS * QKV_LD * 2), 0x00020000);
-    constexpr int NDMA = 8 / WAVES;                          // 8-key groups of a 64-key tile this wave stages, per operand
+    constexpr int NDMA = 8 / DW;                             // 8-key groups of a 64-key tile a staging wave moves, per operand
+    const bool stager = wave < DW;
     int dvo_k[NDMA], dvo_v[NDMA];
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
-        const int row = (wave + WAVES * i) * 8 + (lane >> 3);
+        const int row = ((wave & (DW - 1)) + DW * i) * 8 + (lane >> 3);
         dvo_k[i] = row * (QKV_LD * 2) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
         dvo_v[i] = row * (QKV_LD * 2) + (((lane & 7) ^ (((row >> 1) & 3) << 1)) << 4);
     }
     constexpr int NFULL = 9;
 
-    att8_dma(rk, ks0, wave, dvo_k, NDMA, WAVES, 0);
-    att8_dma(rv, vs0, wave, dvo_v, NDMA, WAVES, 0);
+    if (stager) {
+        att8_dma(rk, ks0, wave, dvo_k, NDMA, DW, 0);
+        att8_dma(rv, vs0, wave, dvo_v, NDMA, DW, 0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int t = 0; t < NFULL; ++t) {
         const int cur = t & 1;
-        if (t + 1 < NFULL) {                                  // both tiles of step t+1 land under this tile's math
-            att8_dma(rk, ks0 + (cur ^ 1) * K_TILE_BYTES, wave, dvo_k, NDMA, WAVES, t + 1);
-            att8_dma(rv, vs0 + (cur ^ 1) * K_TILE_BYTES, wave, dvo_v, NDMA, WAVES, t + 1);
+        if (t + 1 < NFULL && stager) {                        // both tiles of step t+1 land under this tile's math
+            att8_dma(rk, ks0 + (cur ^ 1) * K_TILE_BYTES, wave, dvo_k, NDMA, DW, t + 1);
+            att8_dma(rv, vs0 + (cur ^ 1) * K_TILE_BYTES, wave, dvo_v, NDMA, DW, t + 1);
         }
         const char* ks = ks0 + cur * K_TILE_BYTES;
         const char* vs = vs0 + cur * K_TILE_BYTES;
@@ -305,7 +317,7 @@ __global__ __launch_bounds__(256, WPS) void attention8_kernel(const uint16_t* __
         lt += __shfl_xor(lt, 32, 64);
         const float inv = 1.0f / lt;
         const int qrow = q_first + 16 * qb + r16;
-        if (qrow < VIT_TOKENS) {
+        if (qrow < Q_END) {
             uint16_t* orow = out + (base + qrow) * VIT_HIDDEN + head * 64;
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
@@ -319,12 +331,100 @@ __global__ __launch_bounds__(256, WPS) void attention8_kernel(const uint16_t* __
 }
 
 
+#ifdef PIGEON_ABLATIONS
+// ---- token 576's query of every (image, head), for the 192-query blocking (tools build: the A/B arms 22 / 23 below): one wave per pair, VALU.  s_k = q . k over the 577 keys
+// (8 lanes share a key: 16-byte chunks of its row, shuffle-reduced), softmax in base 2 over LDS-resident scores (fp32 throughout:
+// P is not rounded to 16 bits here), O = sum_k p_k v_k with the same 8-keys-per-pass walk.  ~150 KB of K/V per wave from L2:
+// the main kernel has just streamed the same rows.
+template <typename T>
+__global__ __launch_bounds__(64) void attention_last_query_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out) {
+    __shared__ float sc[VIT_TOKENS + 7];
+    const int pair = blockIdx.x, img = pair >> 4, head = pair & 15, lane = threadIdx.x;
+    const int sub = lane >> 3, ch = lane & 7;
+    const int64_t base = (int64_t)img * VIT_TOKENS;
+    const uint16_t* qrow = qkv + (base + VIT_TOKENS - 1) * QKV_LD + head * 64 + ch * 8;
+    const u32x4 qq = *(const u32x4*)qrow;
+    float q[8];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { q[2 * w] = T::val((uint16_t)(qq[w] & 0xffffu)); q[2 * w + 1] = T::val((uint16_t)(qq[w] >> 16)); }
+    const uint16_t* kbase = qkv + base * QKV_LD + 1024 + head * 64 + ch * 8;
+    // 32 keys per pass (4 independent 16-byte loads per lane in flight), 8 lanes per key
+    for (int k0 = 0; k0 < VIT_TOKENS; k0 += 32) {
+        u32x4 kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = k0 + 8 * u + sub;
+            kk[u] = key < VIT_TOKENS ? *(const u32x4*)(kbase + (int64_t)key * QKV_LD) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = k0 + 8 * u + sub;
+            float p = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                p = fmaf(q[2 * w], T::val((uint16_t)(kk[u][w] & 0xffffu)), p);
+                p = fmaf(q[2 * w + 1], T::val((uint16_t)(kk[u][w] >> 16)), p);
+            }
+            p += __shfl_xor(p, 1, 64); p += __shfl_xor(p, 2, 64); p += __shfl_xor(p, 4, 64);
+            if (ch == 0 && key < VIT_TOKENS) sc[key] = p;
+        }
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int k = lane; k < VIT_TOKENS; k += 64) m = fmaxf(m, sc[k]);
+    m = wave_max(m);
+    float l = 0.f;
+    for (int k = lane; k < VIT_TOKENS; k += 64) { const float e = __builtin_amdgcn_exp2f(sc[k] - m); sc[k] = e; l += e; }
+    l = wave_sum(l);
+    __syncthreads();
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    const uint16_t* vbase = kbase + 1024;
+    for (int k0 = 0; k0 < VIT_TOKENS; k0 += 32) {
+        u32x4 vv[4];
+        float pp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = k0 + 8 * u + sub;
+            const bool ok = key < VIT_TOKENS;
+            vv[u] = ok ? *(const u32x4*)(vbase + (int64_t)key * QKV_LD) : u32x4{0u, 0u, 0u, 0u};
+            pp[u] = ok ? sc[key] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                o[2 * w] = fmaf(pp[u], T::val((uint16_t)(vv[u][w] & 0xffffu)), o[2 * w]);
+                o[2 * w + 1] = fmaf(pp[u], T::val((uint16_t)(vv[u][w] >> 16)), o[2 * w + 1]);
+            }
+    }
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = o[e];
+        v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        o[e] = v * inv;
+    }
+    if (sub == 0) {
+        u32x4 pk;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) pk[w] = pack16x2<T>(o[2 * w], o[2 * w + 1]);
+        *(u32x4*)(out + (base + VIT_TOKENS - 1) * VIT_HIDDEN + head * 64 + ch * 8) = pk;
+    }
+}
+
+#endif
+
+#ifndef PG_DEFAULT_ATTN_VARIANT
+#define PG_DEFAULT_ATTN_VARIANT 21
+#endif
 static int attention_variant() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("PIGEON_ATTN_VARIANT");
-        v = e ? atoi(e) : 21;
-        if (v < 1 || v > 21) v = 21;
+        v = e ? atoi(e) : PG_DEFAULT_ATTN_VARIANT;
+        if (v < 1 || v > 23) v = PG_DEFAULT_ATTN_VARIANT;
     }
     return v;
 }
@@ -350,6 +450,20 @@ int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hip
     const dim3 grid(pairs * ATT_NQB);
     const int variant = attention_variant();
 #ifdef PIGEON_ABLATIONS
+    // Round 4 A/B arms (tools build; profiles/r04/attention_192_query_blocks_ab.txt): 192-query blocks (577 = 3 x 192 + 1) + the last
+    // query as a micro-kernel.  22 = 6 waves x 32 queries: 1.46 vs 1.04 ms -- at 156 VGPRs (3 waves per SIMD) a CU places ONE 6-wave
+    // block (2,2,1,1 waves per SIMD; a second one would need 4 on SIMD 0), where three 4-wave blocks ran.  23 = 4 waves x 48 queries
+    // (212 VGPRs, 2 waves per SIMD): main kernel 0.97 ms (-6 %), but the last query alone streams every K / V row once more --
+    // 1.2 GB through L2, 0.24 ms as a kernel of its own: 1.21 ms in total.  It would have to ride in a block that already stages K / V.
+    if (variant == 22 || variant == 23) {                    // 192-query blocks + the last query's micro-kernel
+        const int rc = variant == 22
+            ? att_launch3(dtype, attention8_kernel<T_F16, 2, 6, 3, true>, attention8_kernel<T_BF16, 2, 6, 3, true>, dim3(pairs * 3), 384, qkv, out, s)
+            : att_launch3(dtype, attention8_kernel<T_F16, 3, 4, 2, true>, attention8_kernel<T_BF16, 3, 4, 2, true>, dim3(pairs * 3), 256, qkv, out, s);
+        if (rc != PG_OK) return rc;
+        if (dtype == PG_DTYPE_F16) hipLaunchKernelGGL(attention_last_query_kernel<T_F16>, dim3(pairs), dim3(64), 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+        else hipLaunchKernelGGL(attention_last_query_kernel<T_BF16>, dim3(pairs), dim3(64), 0, s, (const uint16_t*)qkv, (uint16_t*)out);
+        return pg_check_launch("attention (last query)");
+    }
     if (variant == 19) return att_launch3(dtype, attention8_kernel<T_F16, 4, 2, 2>, attention8_kernel<T_BF16, 4, 2, 2>, grid, 128, qkv, out, s);
     if (variant == 20) return att_launch3(dtype, attention8_kernel<T_F16, 2, 4, 3, false>, attention8_kernel<T_BF16, 2, 4, 3, false>, grid, 256, qkv, out, s);
     if (variant != 21) {

@@ -26,7 +26,9 @@ def main():
     p = torch.softmax((q @ k.transpose(-1, -2)) * 0.6931471805599453, dim=-1)       # Q carries log2(e): 2^s == e^(s ln2)
     ref = (p @ v).transpose(1, 2).reshape(n * 577, 1024)
     err = ((out - ref).norm() / ref.norm()).item()
-    print(f"ATTN variant {var}: rel err vs fp32 {err:.2e}", flush=True)
+    last = torch.tensor([576, 2 * 577 - 1])
+    err_last = ((out[last] - ref[last]).norm() / ref[last].norm()).item()
+    print(f"ATTN variant {var}: rel err vs fp32 {err:.2e} (token 576's rows: {err_last:.2e})", flush=True)
     n = args.images
     big = torch.randn((n * 577, 3072), generator=g).to(torch.float16).cuda()
     big[:, :1024] *= 0.18
