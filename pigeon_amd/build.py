@@ -88,5 +88,16 @@ def _build(OBJ: str, LIB: str, FLAGS, force: bool, verbose: bool, SOURCES) -> st
     return LIB
 
 
+def build_variant(name: str, defines, verbose: bool = True) -> str:
+    """A/B arm of the PRODUCT library with extra -D defines (kernel knobs that are compile-time constants, e.g. -DPG_P6_EARLY=8):
+    libpigeon_hip_<name>.so; select it with PIGEON_HIP_LIB.  `python -m pigeon_amd.build --variant e8 -DPG_P6_EARLY=8`."""
+    return _build(os.path.join(CSRC, f"build_{name}"), os.path.join(HERE, f"libpigeon_hip_{name}.so"), FLAGS + list(defines), False,
+                  verbose, SOURCES)
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, dev="--dev" in sys.argv))
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")]))
+    else:
+        print(build(force="--force" in sys.argv, dev="--dev" in sys.argv))

@@ -126,12 +126,25 @@ __device__ __forceinline__ void load_frag6(Frag6<T>& f, uint32_t aA, uint32_t aB
 
 // 24 MFMAs of one phase; swapped operands (weights first): a lane owns output row lane & 15 of a 16 x 16 block and the 4
 // consecutive columns 4 (lane >> 4) ..
+// P6_EARLY (round 4): the barrier that ends an MFMA phase is ARRIVED AT before the phase's last P6_EARLY MFMAs are issued.  The
+// phase stamps of the tools build (tools/stall_probe.py, profiles/r04/gemm_pp6_phase_stamps.txt) show every wave's operands in
+// place when it asks for them (12-15 ns per K tile in vmcnt(0)) and LOAD + barrier = 145 ns against 227 ns of MFMAs -- yet a
+// phase takes ~630 ns where two alternating MFMA sections would take 454: the matrix pipe idles across each of the 8 barriers of
+// a K tile, between the last MFMA issue of one wave group and the first of the other (the s_barrier round trip).  MFMAs touch
+// registers only -- the barrier orders LDS reads against the DMAs into the other stage, and schedules the two groups -- so the
+// trailing MFMAs may follow the barrier: the partner group is released while they still feed the pipe.  Same MFMA order per
+// accumulator: bit-identical.
+#ifndef PG_P6_EARLY
+#define PG_P6_EARLY 0
+#endif
+constexpr int P6_EARLY = PG_P6_EARLY;
 template <typename T, bool ZERO, int HALF>
 __device__ __forceinline__ void mma24(Acc6& acc, const Frag6<T>& f) {
 #pragma unroll
     for (int i = 0; i < P6_TM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            if (P6_EARLY > 0 && i * 4 + j == 4 * P6_TM - P6_EARLY) raw_barrier();
             if constexpr (ZERO) T::mfma16_init(acc[HALF * P6_TM + i][j], f.b[j], f.a[i]);
             else T::mfma16_acc(acc[HALF * P6_TM + i][j], f.b[j], f.a[i]);
         }
@@ -141,6 +154,33 @@ __device__ __forceinline__ void mma24(Acc6& acc, const Frag6<T>& f) {
 // baseA / baseB: LDS byte addresses of this lane's fragment row (lane & 15 of block 0) in STAGE 0 at k-step 0 (chunk
 // ((lane >> 4) ^ sw) << 4); k-step s reads chunk (4 s + (lane >> 4)) ^ sw = chunk0 ^ (4 s), i.e. address ^ (s << 6) (disjoint
 // bits).  The per-phase addresses are formed by asm (one v_add / v_xor each) so that they are NOT hoisted into live registers.
+#ifdef PIGEON_ABLATIONS
+// tools build: wall-clock ticks (100 MHz) block 0's waves 0 (leader group) and 4 (follower group) spend per K tile (a) in the
+// `s_waitcnt vmcnt(0)` that waits for the NEXT K tile's operand DMAs and (b) in the barrier right behind it; [grp][0] = (a),
+// [grp][1] = (b), [grp][2] = K tiles counted.  Read / reset with pg_dbg_stall_read (tools/stall_probe.py).
+__device__ unsigned long long pg_dbg_stall[2][4];
+// ... and, per phase of the ping-pong schedule (4 per K tile), where those two waves' time goes: [grp][0] LOAD (fragment ds_reads +
+// DMA issue, up to the lgkmcnt wait), [1] the barrier in front of the MFMAs, [2] the 24 MFMAs (issue of the first to issue of the
+// last + the setprio pair), [3] the barrier behind them, [4] phases counted.
+__device__ unsigned long long pg_dbg_phase[2][8];
+__device__ unsigned long long pg_dbg_vm[8][4];               // per wave of block 0: ticks in vmcnt(0), waits, waits > 200 ns
+extern "C" int pg_dbg_vm_read(unsigned long long* out32, int reset) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(pg_dbg_vm), sizeof(unsigned long long) * 32) != hipSuccess) return PG_EHIP;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pg_dbg_vm), z, sizeof(z)) != hipSuccess) return PG_EHIP; }
+    return PG_OK;
+}
+extern "C" int pg_dbg_stall_read(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(pg_dbg_stall), sizeof(unsigned long long) * 8) != hipSuccess) return PG_EHIP;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pg_dbg_stall), z, sizeof(z)) != hipSuccess) return PG_EHIP; }
+    return PG_OK;
+}
+extern "C" int pg_dbg_phase_read(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pg_dbg_phase), sizeof(unsigned long long) * 16) != hipSuccess) return PG_EHIP;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pg_dbg_phase), z, sizeof(z)) != hipSuccess) return PG_EHIP; }
+    return PG_OK;
+}
+#endif
+
 template <typename T, bool ZERO, int STAGE>
 __device__ __forceinline__ void ktile6(Acc6& acc, char* smem, uint32_t baseA, uint32_t baseB, const Tile6& c,
                                        int wave, int voffA, int voffW, int soff_next, bool has_next) {
@@ -149,6 +189,11 @@ __device__ __forceinline__ void ktile6(Acc6& acc, char* smem, uint32_t baseA, ui
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         // phase kk = (k-step s = kk >> 1, half = kk & 1)
+#ifdef PIGEON_ABLATIONS
+        const bool probe = blockIdx.x == 0 && (wave & 3) == 0;
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        if (probe) t0 = __builtin_amdgcn_s_memrealtime();
+#endif
         uint32_t aA, aB;
         asm volatile("v_add_u32 %0, %2, %1\n\tv_xor_b32 %0, %3, %0" : "=&v"(aA) : "v"(baseA),
                      "n"(STAGE * P6_STAGE + (kk & 1) * P6_TM * 16 * ROWB), "n"((kk >> 1) << 6));
@@ -158,17 +203,45 @@ __device__ __forceinline__ void ktile6(Acc6& acc, char* smem, uint32_t baseA, ui
         if (has_next) {
             if (kk == 0) issue_dma6<0, 5>(c, nxt, wave, voffA, voffW, soff_next);
             if (kk == 1) issue_dma6<5, 5>(c, nxt, wave, voffA, voffW, soff_next);
+#ifdef PIGEON_ABLATIONS
+            if (kk == 3) {                                   // every wave of block 0: how long for ITS next-tile DMAs, and how often > 200 ns
+                unsigned long long ta = 0;
+                if (blockIdx.x == 0) ta = __builtin_amdgcn_s_memrealtime();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
+                    const unsigned long long dtk = __builtin_amdgcn_s_memrealtime() - ta;
+                    pg_dbg_vm[wave][0] += dtk; pg_dbg_vm[wave][1] += 1; if (dtk > 20) pg_dbg_vm[wave][2] += 1;
+                }
+            }
+#else
             if (kk == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         }
         wait_lgkm0();
+#ifdef PIGEON_ABLATIONS
+        if (probe) t1 = __builtin_amdgcn_s_memrealtime();
+#endif
         raw_barrier();
+#ifdef PIGEON_ABLATIONS
+        if (probe) t2 = __builtin_amdgcn_s_memrealtime();
+#endif
         __builtin_amdgcn_s_setprio(1);
         if (kk == 0) mma24<T, ZERO, 0>(acc, f);
         if (kk == 1) mma24<T, ZERO, 1>(acc, f);
         if (kk == 2) mma24<T, false, 0>(acc, f);
         if (kk == 3) mma24<T, false, 1>(acc, f);
         __builtin_amdgcn_s_setprio(0);
-        raw_barrier();
+#ifdef PIGEON_ABLATIONS
+        if (probe) t3 = __builtin_amdgcn_s_memrealtime();
+#endif
+        if (P6_EARLY == 0) raw_barrier();
+#ifdef PIGEON_ABLATIONS
+        if (probe && (threadIdx.x & 63) == 0) {
+            const unsigned long long t4 = __builtin_amdgcn_s_memrealtime();
+            unsigned long long* d = pg_dbg_phase[wave >> 2];
+            d[0] += t1 - t0; d[1] += t2 - t1; d[2] += t3 - t2; d[3] += t4 - t3; d[4] += 1;
+        }
+#endif
     }
 }
 
