@@ -57,8 +57,9 @@ def panorama_from_request(body: Dict) -> List:
     return views
 
 
-def predict_panorama(views: Sequence, model, refiner=None, preprocess: Optional[Callable] = None) -> Dict[str, float]:
-    """views: four PIL images -> {'lat', 'lng'}.  `preprocess(list of PIL) -> (4,3,336,336)` defaults to the GPU path."""
+def predict_panorama(views: Sequence, model, refiner=None, preprocess: Optional[Callable] = None) -> Dict:
+    """views: four PIL images -> {'lat', 'lng'} (+ 'geocell_margin', 'geocell_certain', 'reencoded_exact' when the model exposes the
+    certainty of its top-1).  `preprocess(list of PIL) -> (4,3,336,336)` defaults to the GPU path."""
     import torch
     if preprocess is None:
         from .clip_embedder import gpu_preprocess
@@ -71,7 +72,13 @@ def predict_panorama(views: Sequence, model, refiner=None, preprocess: Optional[
             _, pred_llh, _ = refiner(embedding=embedding, initial_preds=pred_llh, candidate_cells=topk.indices,
                                      candidate_probs=topk.values)
     lng, lat = (float(v) for v in pred_llh.reshape(-1, 2)[0].tolist())
-    return {"lat": lat, "lng": lng}
+    res = {"lat": lat, "lng": lng}
+    # certainty of the geocell top-1 (pigeon_amd.SuperGuessr, round 4): extra keys, the extension reads lat / lng only
+    if getattr(model, "last_certain", None) is not None:
+        res["geocell_margin"] = float(model.last_margin.reshape(-1)[0])
+        res["geocell_certain"] = bool(model.last_certain.reshape(-1)[0])
+        res["reencoded_exact"] = bool(getattr(model, "last_reencoded", None) is not None and model.last_reencoded.numel() > 0)
+    return res
 
 
 def make_app(model, refiner=None, preprocess: Optional[Callable] = None, game_log: Optional[List] = None):
@@ -118,11 +125,19 @@ def main(argv=None):
     ap.add_argument("--protos", default=None)
     ap.add_argument("--dataset", default=None)
     ap.add_argument("--layers", type=int, default=24)
+    ap.add_argument("--exact-top1", action="store_true", help="re-encode panoramas whose top-1 margin is inside the 16-bit path's error "
+                                                                  "band in the encoder's exact mode (the reference's fp32 argmax)")
     ap.add_argument("--host", default="127.0.0.1")
     ap.add_argument("--port", type=int, default=5000)
     args = ap.parse_args(argv)
     kw = {"geocell_path": args.geocells} if args.geocells else {}
-    model = SuperGuessr(HipCLIPVisionModel(layers=args.layers), panorama=True, serving=True, freeze_base=True, **kw).to("cuda").eval()
+    from .clip_embedder import load_pretrained_clip
+    try:
+        base = load_pretrained_clip()                                  # CLIP_MODEL from local files (env PIGEON_CLIP_MODEL / HF cache)
+    except RuntimeError as why:
+        print(f"[serve] no pretrained tower ({why}); using a seeded random-init ViT-L/14-336 with {args.layers} layers")
+        base = HipCLIPVisionModel(seed=0, layers=args.layers)
+    model = SuperGuessr(base, panorama=True, serving=True, freeze_base=True, exact_top1=args.exact_top1, **kw).to("cuda").eval()
     if args.head:
         model.load_state(args.head)
     refiner = ProtoRefiner(proto_path=args.protos, dataset_path=args.dataset) if args.protos else None

@@ -282,3 +282,63 @@ def test_encoder_graph_replay_bit_identical(env, capsys):
     assert torch.equal(prof, eager) and enc.graph()[0] == r1     # bracketed with events: no replay
     assert enc.profile_read()["gemm_fc1"][0] == 2
     enc.close()
+
+
+def test_exact_mode_edges(env, tmp_path, capsys):
+    """The exact mode at the edges of its inputs: single-image (non-panorama) models, fp16 pixels as the GPU preprocessing writes
+    them, bf16 fast-path operands (the exact pass always uses fp16 halves), batches in which nothing / everything is re-encoded,
+    the serving tuple, and the auto-calibration of the certainty bound."""
+    from pigeon_amd.clip_embedder import HipCLIPVisionModel
+    from pigeon_amd.super_guessr import SuperGuessr
+    syn, ops = env["syn"], env["ops"]
+    C = 300
+    gp = os.path.join(str(tmp_path), "g.csv")
+    syn.write_geocell_csv(gp, syn.make_geocells(C, seed=0))
+    sd = syn.make_vit_weights(seed=11, layers=2, affine_jitter=True)
+    vit = HipCLIPVisionModel(sd, layers=2).to(DEV)
+    W, b = syn.make_head_weights(C, seed=1)
+
+    def model(**kw):
+        m = SuperGuessr(vit, freeze_base=True, num_candidates=5, geocell_path=gp, **kw)
+        with torch.no_grad():
+            m.cell_layer.weight.copy_(W * 64); m.cell_layer.bias.copy_(b)
+        return m.to(DEV).eval()
+    px = syn.make_pixels(12, seed=3).to(DEV)
+    # single images, everything uncertain (kappa huge) -> every sample re-encoded: embeddings == the exact encoder's, bit for bit
+    m = model(panorama=False, exact_top1=True, margin_kappa=1e9)
+    out = m(pixel_values=px, labels_clf=None)
+    assert m.last_reencoded.numel() == 12
+    want = vit._encoder(torch.device(DEV)).forward_precise(px)
+    assert torch.equal(out.embedding, want)
+    # ... nothing uncertain (kappa 0): the fast path's outputs, no exact pass
+    m0 = model(panorama=False, exact_top1=True, margin_kappa=0.0)
+    out0 = m0(pixel_values=px, labels_clf=None)
+    assert m0.last_reencoded.numel() == 0 and torch.equal(out0.embedding, vit.embed(px)) and bool(m0.last_certain.all())
+    # panoramas with fp16 pixels (what pg_prep_forward hands over) + the serving tuple
+    mp = model(panorama=True, serving=True, exact_top1=True, margin_kappa=1e9)
+    px16 = px.half().reshape(3, 12, 336, 336)
+    llh, topk, emb = mp(pixel_values=px16)
+    assert emb.shape == (3, 4, 1024) and mp.last_reencoded.tolist() == [0, 1, 2]
+    assert torch.equal(emb.reshape(12, 1024), vit._encoder(torch.device(DEV)).forward_precise(px.half()))
+    # exactness claim on the panorama path: agrees with the oracle's embedding of the SAME (fp16-rounded) pixels to 1e-5
+    ref = env["orc"].clip_embedding(sd, px.half().float().cpu())
+    assert _rel(emb.reshape(12, 1024).cpu(), ref) < EXACT_TOL
+    # auto-calibration: after >= 8 re-encoded samples the bound follows the measured fast-vs-exact difference
+    assert m._cal_n == 12 and 1e-5 < m.margin_rel_tol < 1e-3
+    rms = (m._cal_sumsq / m._cal_n) ** 0.5
+    assert abs(m.margin_rel_tol - 1.25 * rms) < 1e-12 and 1e-4 < rms < 5e-4
+    # bf16 operands on the fast path: the exact pass is unaffected
+    vb = HipCLIPVisionModel(sd, layers=2).to(DEV)
+    vb.enable_precise(True)
+    os.environ["PIGEON_MMA_DTYPE"] = "bf16"
+    try:
+        eb = vb.embed_precise(px[:4])
+        assert vb._encoder(torch.device(DEV)).mma_dtype == "bf16"
+    finally:
+        del os.environ["PIGEON_MMA_DTYPE"]
+    assert torch.equal(eb, want[:4])
+    # B = 0 and B = 1
+    e0 = m(pixel_values=px[:0], labels_clf=None)
+    assert e0.embedding.shape[0] == 0 and m.last_certain.numel() == 0
+    e1 = m(pixel_values=px[:1], labels_clf=None)
+    assert torch.equal(e1.embedding, want[:1])
