@@ -64,8 +64,17 @@ def gemm16(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: 
     M = A.shape[0] if M is None else M
     K = A.shape[1]
     N = W.shape[0]
-    check(load().pg_op_gemm16_ld(_dt16(A), _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
+    dst = out
+    if epi == _lib.EPI_RESID:
+        # the residual epilogue's last row tile reads up to 383 rows past row M of `out` (see gemm16_resid_stat / pigeon_hip.h)
+        have = out.untyped_storage().nbytes() - out.storage_offset() * out.element_size()
+        if have < (M + 384) * out.stride(0) * out.element_size():
+            dst = torch.zeros((M + 384, out.shape[1]), dtype=out.dtype, device=out.device)[:out.shape[0]]
+            dst.copy_(out)
+    check(load().pg_op_gemm16_ld(_dt16(A), _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(dst), dst.stride(0), M, N, K,
                                  epi, float(qscale), int(qcols), _p(aux), variant, _stream()), "pg_op_gemm16_ld")
+    if dst is not out:
+        out.copy_(dst)
     return out
 
 
@@ -90,13 +99,25 @@ def rowstat_cast(x: torch.Tensor, out_dtype: torch.dtype = torch.float16, eps: f
 
 
 def gemm16_resid_stat(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, X: torch.Tensor, variant: int = 0):
-    """X += A.W^T + bias in place; returns (x16 copy of the new X, statpart (N/64, M, 2))."""
+    """X += A.W^T + bias in place; returns (x16 copy of the new X, statpart (N/64, M, 2)).
+
+    The persistent kernels fetch the residual rows of a whole 256- / 384-row tile through a buffer descriptor whose row term rides in
+    the SGPR offset, which the hardware bounds check does not cover: in the last (partial) tile they READ up to 383 rows past row M of
+    X (never write there; the values are discarded).  Inside the encoder those rows are the workspace's next buffer.  Here X must own
+    that slack -- if its storage ends earlier the GEMM runs on a padded copy (this wrapper serves tests and tools, not the hot path)."""
     M, K = A.shape
     N = W.shape[0]
     x16 = torch.empty((M, N), dtype=A.dtype, device=A.device)
     part = torch.empty((N // 64, M, 2), dtype=torch.float32, device=A.device)
-    check(load().pg_op_gemm16_resid_stat(_dt16(A), _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(X), X.stride(0), _p(x16),
+    have = X.untyped_storage().nbytes() - X.storage_offset() * X.element_size()
+    Xr = X
+    if have < (M + 384) * X.stride(0) * X.element_size():
+        Xr = torch.zeros((M + 384, N), dtype=X.dtype, device=X.device)[:M]
+        Xr.copy_(X)
+    check(load().pg_op_gemm16_resid_stat(_dt16(A), _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(Xr), Xr.stride(0), _p(x16),
                                          x16.stride(0), _p(part), M, N, K, variant, _stream()), "pg_op_gemm16_resid_stat")
+    if Xr is not X:
+        X.copy_(Xr)
     return x16, part
 
 
