@@ -69,7 +69,7 @@ def gemm16(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: 
         # the residual epilogue's last row tile reads up to 383 rows past row M of `out` (see gemm16_resid_stat / pigeon_hip.h)
         have = out.untyped_storage().nbytes() - out.storage_offset() * out.element_size()
         if have < (M + 384) * out.stride(0) * out.element_size():
-            dst = torch.zeros((M + 384, out.shape[1]), dtype=out.dtype, device=out.device)[:out.shape[0]]
+            dst = torch.zeros((max(M, out.shape[0]) + 384, out.shape[1]), dtype=out.dtype, device=out.device)[:out.shape[0]]
             dst.copy_(out)
     check(load().pg_op_gemm16_ld(_dt16(A), _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(dst), dst.stride(0), M, N, K,
                                  epi, float(qscale), int(qcols), _p(aux), variant, _stream()), "pg_op_gemm16_ld")
