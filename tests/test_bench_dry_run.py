@@ -100,3 +100,24 @@ def test_flip_analysis_rule():
     assert r2["flips"] == 2 and r2["flips_unexplained"] == 1
     r3, _ = bench.flip_analysis(ref, ref, torch.tensor([2, 1, 0]), ["a", "b", "c"])
     assert r3["flips"] == 0 and r3["geocell_argmax_equal"] is True and r3["logit_abs_err_max"] == 0.0
+
+
+def test_cpu_baseline_pool_and_quota(tmp_path):
+    """bench.py's CPU-baseline leg without a GPU: the pool of worker processes (disjoint cores and image shards, a common go
+    signal, wall time up to the last worker's last image) returns the reference module's embeddings in image order and agrees
+    with the oracle restatement run the same way; the pool is sized to what the container may USE (cgroup quota), not to what it
+    sees."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import pigeon_oracle as orc
+    from pigeon_amd import synthetic
+    q = bench.cpu_quota_cores()
+    assert 0 < q <= len(os.sched_getaffinity(0))
+    px = synthetic.make_pixels(5, seed=3)
+    emb, wall, per, busy = bench.cpu_pool("module", px, 1, 2, 2, weight_seed=0)
+    assert emb.shape == (5, 1024) and len(per) == 2 and busy == 4 and 0 < max(per) <= wall + 0.5
+    sd = synthetic.make_vit_weights(seed=0, layers=1)
+    assert orc.rel_err(emb, orc.clip_embedding(sd, px)) < 1e-5            # image order kept across the shards (3 + 2)
+    emb_p, _, _, _ = bench.cpu_pool("port", px, 1, 5, 1, weight_seed=0)    # one image per worker
+    assert orc.rel_err(emb_p, emb) < 1e-5
