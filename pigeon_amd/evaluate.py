@@ -80,6 +80,7 @@ def evaluate_model(model: SuperGuessr, dataset, metrics: Optional[Callable] = No
         refiner.eval()
     combined_preds, combined_geocell_preds, combined_top5_cells, combined_top5_probs = [], [], [], []
     combined_loss = 0.0
+    combined_certain = []
     n_seen = 0
     with torch.no_grad():
         for data in eval_data:
@@ -97,12 +98,16 @@ def evaluate_model(model: SuperGuessr, dataset, metrics: Optional[Callable] = No
             top5 = outputs.top5_geocells
             combined_top5_cells.append(top5.indices.cpu().detach().numpy())
             combined_top5_probs.append(top5.values.cpu().detach().numpy())
+            if getattr(model, 'last_certain', None) is not None:                  # round 4: certainty of each geocell top-1
+                combined_certain.append(model.last_certain.cpu().numpy())
             n_seen += outputs.preds_geocell.shape[0]
     preds = np.concatenate(combined_preds, axis=0)
     preds_geocells = np.concatenate(combined_geocell_preds, axis=0)
     top5_geocells = np.concatenate(combined_top5_cells, axis=0)
     results = dict(preds=preds, preds_geocells=preds_geocells, top5_geocells=top5_geocells,
                    top5_probs=np.concatenate(combined_top5_probs, axis=0), loss_clf=combined_loss / max(n_seen, 1))
+    if combined_certain:        # beyond the reference's keys: which geocell predictions are certain to be the fp32 argmax
+        results['geocell_certain'] = np.concatenate(combined_certain, axis=0)
     if metrics is not None:                                                       # :122-140
         labels_lla, labels_cell = dataset['labels'], dataset['labels_clf']
         if isinstance(labels_lla, np.ndarray) == False:

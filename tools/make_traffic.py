@@ -41,6 +41,7 @@ CLASSES = {"gemm_qkv": (("gemm_pp6_kernel<T_F16, 6", "gemm_pp6_kernel<T_F16, 0",
            "attention": (("attention",), 2 * 3072 + 2 * 1024),
            "layernorm": (("layernorm_kernel",), 4 * 1024 + 2 * 1024),
            "refine_candidates": (("refine_candidates_kernel",), None)}
+TAIL_SPLIT = ("gemm_fc1", "gemm_fc2")                # the product's tail policy: K >= 2048 or N >= 4096 (vit.hip PG_DEFAULT_GEMM_TAIL_*)
 res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py, one launch = %d token rows; KiB as "
                "reported; hbm_bytes_per_launch_corrected = 2 x FETCH_SIZE (gfx950 under-report of wide coalesced reads, "
                "MI355X_MICROARCH.md) + WRITE_SIZE; algorithmic_bytes = activation rows in + out (+ weights once)" % rows}
@@ -59,6 +60,12 @@ for cls, (pats, bytes_per_row) in CLASSES.items():
         ms = [v for k, v in avg_ms.items() if pat in k]
         if ms:
             e["rocprof_avg_ms"] = ms[0]
+            # ... and of the small-tile launch that takes the rows beyond the persistent kernel's last whole round (gemm_tail.hip,
+            # same epilogue number): a GEMM of the model = the two launches together
+            epi = pat.split("<T_F16,")[1].strip().split(",")[0].split(">")[0].strip() if "<T_F16," in pat else None
+            tail = [v for k, v in avg_ms.items() if epi is not None and f"gemm_tail_kernel<T_F16, {epi}>" in k.replace(" >", ">")]
+            if tail and cls in TAIL_SPLIT:
+                e["rocprof_tail_avg_ms"] = tail[0]
             break
     if bytes_per_row:
         wbytes = {"gemm_qkv": 3072 * 1024 * 2, "gemm_fc1": 4096 * 1024 * 2, "gemm_fc2": 1024 * 4096 * 2, "gemm_out": 1024 * 1024 * 2}.get(cls, 0)
