@@ -118,11 +118,12 @@ def _free_port() -> int:
 
 def self_launch(args) -> int:
     """`--gpus N` without a launcher: start N workers of this very command, one per GPU, as accelerate / torchrun would."""
-    port = _free_port()
+    port = _free_port()                                         # kept in the environment for tools that read it; the ranks' control-plane
+    rdzv = os.path.join(tempfile.mkdtemp(prefix="pigeon_rdzv_"), "store")   # group rendezvouses through this FILE store (no port race)
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PIGEON_BENCH_LAUNCHER="self")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PIGEON_RDZV_FILE=rdzv, PIGEON_BENCH_LAUNCHER="self")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     try:

@@ -169,7 +169,13 @@ def init_from_env(backend: Optional[str] = None, set_device: bool = True, join_t
         os.environ.setdefault("MASTER_PORT", "29500")
         rank = int(os.environ.get("RANK", "0"))
         _await_all_ranks(rank, world, float(os.environ.get("PIGEON_JOIN_TIMEOUT_S", join_timeout_s)))
-        dist.init_process_group(backend=backend or "gloo")
+        rdzv = os.environ.get("PIGEON_RDZV_FILE")
+        if rdzv:
+            # a launcher that owns its ranks (bench.py self_launch) hands them a FILE store: no fixed TCP port to lose a race for
+            # between the launcher's "find a free port" and rank 0's bind (gloo's own pair connections use ephemeral ports)
+            dist.init_process_group(backend=backend or "gloo", init_method=f"file://{rdzv}", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend=backend or "gloo")
         comm = Communicator()
         comm._owns_group = True
         return comm
