@@ -301,11 +301,11 @@ int pg_op_gemm16_ld(int dtype, const void* A, int64_t lda, const void* W, int64_
  *                           (N/64, M, 2) fp32 = per-64-column (sum, sum of squares) of the new rows; ldx == ldc
  *   pg_op_rowstat_finalize  statpart -> rowstat (rstd, mean*rstd) over `slots` slices of a 1024-wide row
  *   pg_op_gemm16_ln         out 16-bit = epi(rowstat[m].rstd * acc - rowstat[m].mean_rstd * colsum[n] + bias[n]),
- *                           epi 6 = QKV form (columns < qcols scaled by qscale), 7 = QuickGELU form. */
+ *                           epi 6 = QKV form (columns < qcols scaled by qscale), 7 = QuickGELU form.
  * Memory contract of the fp32 residual epilogues (epi 2 of pg_op_gemm16, pg_op_gemm16_resid_stat): the last, partial row tile of the
  * persistent kernels READS (never writes) up to 383 rows past row M of X / out -- the row term of those loads rides in the SGPR
  * offset, which the buffer bounds check does not cover.  X must be followed by at least 384 * ldc * 4 readable bytes (inside
- * pg_vit_forward it is: the workspace's next buffer). */
+ * pg_vit_forward it is: the next buffer of the workspace). */
 int pg_op_rowstat_cast(const float* x, void* x16, int dtype, float* rowstat, int64_t rows, float eps, void* stream);
 int pg_op_gemm16_resid_stat(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* X,
                             int64_t ldc, void* x16, int64_t ldx, float* statpart, int M, int N, int K, int variant, void* stream);

@@ -214,6 +214,27 @@ class SuperGuessr(nn.Module):
             return ModelOutput(loss, loss_clf, 0, 0, 0, pred_LLH, geocell_preds, None, None, None,
                                geocell_topk, embedding)
 
+    @torch.no_grad()
+    def calibrate_certainty(self, pixel_values: Tensor, max_samples: int = 16) -> float:
+        """Measure what the 16-bit path's embedding error IS on this model -- once per set of weights -- and set the certainty bound
+        from it: up to `max_samples` samples go through the fast and the exact encoder, `margin_rel_tol` becomes 1.25 x the RMS
+        relative difference of their (panel-mean) embeddings.  Returns that RMS.  Needs pixels and a base model; the encoder is
+        (re)packed with the exact mode's split-weight copy if it did not have it."""
+        if self.base_model is None or pixel_values is None:
+            raise ValueError('calibrate_certainty needs pixel_values and a base model')
+        dev = self.cell_layer.weight.device
+        P = 4 if self.panorama else 1
+        px = pixel_values[:max_samples].reshape((-1, 3, 336, 336)).to(dev)
+        enc = self._encoder()
+        fast = enc.embed(px).reshape((-1, P, CLIP_EMBED_DIM)).mean(dim=1)
+        exact = enc.embed_precise(px).reshape((-1, P, CLIP_EMBED_DIM)).mean(dim=1)
+        rel2 = ((fast - exact).norm(dim=1) / exact.norm(dim=1).clamp_min(1e-30)) ** 2
+        self._cal_sumsq += float(rel2.sum())
+        self._cal_n += int(rel2.numel())
+        rms = (self._cal_sumsq / self._cal_n) ** 0.5
+        self.margin_rel_tol = max(1.25 * rms, 4 * self.margin_rel_tol_exact)
+        return rms
+
     def _certainty(self, o, head_in: Tensor, embedding: Tensor, pixel_values) -> Tensor:
         """Margin / bound / certain per sample; with exact_top1, re-encode the uncertain samples from their pixels in the
         encoder's exact mode and overwrite their rows of the head outputs `o` (and of the returned embedding)."""
