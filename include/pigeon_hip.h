@@ -160,8 +160,9 @@ int pg_vit_range_alarm_read(pg_vit* h, int64_t* rows, int reset);
  *   topk_idx DEVICE (B,k) int64 out
  *   argmax   DEVICE (B) int64 out (== topk_idx[:,0])
  *   pred_llh DEVICE (B,2) float64 out = centroids[argmax]
- * Limits: 1 <= k <= C <= 38400 (one row of C probabilities lives in LDS while its top k are picked; the reference's geocell
- * sets have 2 000 - 11 000 cells), P >= 1; anything else is PG_EINVAL.
+ * Limits: 1 <= k <= C, P >= 1; anything else is PG_EINVAL.  Up to C = 38 400 a row's probabilities live in LDS while its top k are
+ * picked (the reference's geocell sets have 2 000 - 11 000 cells); larger heads take the same kernel over a stream-ordered device
+ * scratch of B x C floats (hipMallocAsync / hipFreeAsync on `stream`), same results.
  * ------------------------------------------------------------------------------------------------ */
 int pg_head_forward(const float* emb, int B, int P, const float* W, const float* bias,
                     const double* centroids, int C, int k, float* logits,

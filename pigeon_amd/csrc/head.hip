@@ -95,12 +95,17 @@ __device__ __forceinline__ ValIdx block_argbest(ValIdx x, ValIdx* red /*[4]*/) {
     return r;
 }
 
-// one block per batch row; probs live in dynamic LDS (C floats)
+// one block per batch row; the row's C probabilities live in dynamic LDS (GLOBAL = false: C <= 38 400, every geocell set of the
+// reference) or, for larger heads, in a row of a device scratch matrix (GLOBAL = true, round 4: same arithmetic and selection order,
+// the k selection passes then stream the row from L2 / HBM instead of LDS)
+template <bool GLOBAL>
 __global__ __launch_bounds__(256) void head_row_kernel(const float* __restrict__ logits, int C, int k,
                                                        const double* __restrict__ centroids,
                                                        float* __restrict__ topk_val, int64_t* __restrict__ topk_idx,
-                                                       int64_t* __restrict__ argmax_out, double* __restrict__ pred_llh) {
-    extern __shared__ __attribute__((aligned(16))) float probs[];
+                                                       int64_t* __restrict__ argmax_out, double* __restrict__ pred_llh,
+                                                       float* __restrict__ scratch) {
+    extern __shared__ __attribute__((aligned(16))) float probs_lds[];
+    float* probs = GLOBAL ? scratch + (int64_t)blockIdx.x * C : probs_lds;
     __shared__ ValIdx red[4];
     __shared__ float redf[4];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -141,6 +146,7 @@ __global__ __launch_bounds__(256) void head_row_kernel(const float* __restrict__
             }
             probs[best.i] = -2.f;                      // retire (probabilities are >= 0)
         }
+        if (GLOBAL) __threadfence_block();             // the retirement is a global store: visible to the block's next pass
         __syncthreads();
     }
 }
@@ -156,17 +162,26 @@ extern "C" int pg_head_forward(const float* emb, int B, int P, const float* W, c
     }
     if (P < 1 || C < 1 || k < 1 || k > C) { pg_set_error("head: bad P=%d C=%d k=%d", P, C, k); return PG_EINVAL; }
     const size_t lds = (size_t)C * sizeof(float);
-    if (lds > 150 * 1024) { pg_set_error("head: C=%d exceeds the LDS-resident row limit (38400)", C); return PG_EINVAL; }
+    const bool big = lds > 150 * 1024;                     // > 38 400 geocells: probabilities in a stream-ordered device scratch
     dim3 g1((C + HT - 1) / HT, (B + HT - 1) / HT);
     hipLaunchKernelGGL(head_logits_kernel, g1, dim3(256), 0, s, emb, B, P, W, bias, C, logits);
     int rc = pg_check_launch("head_logits");
     if (rc) return rc;
+    if (big) {
+        float* scratch = nullptr;
+        PG_HIP(hipMallocAsync((void**)&scratch, (size_t)B * C * sizeof(float), s));
+        hipLaunchKernelGGL(head_row_kernel<true>, dim3(B), dim3(256), 0, s, logits, C, k, centroids, topk_val, topk_idx, argmax, pred_llh, scratch);
+        rc = pg_check_launch("head_row (large C)");
+        (void)hipFreeAsync(scratch, s);
+        return rc;
+    }
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        PG_HIP(hipFuncSetAttribute((const void*)head_row_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PG_HIP(hipFuncSetAttribute((const void*)head_row_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    hipLaunchKernelGGL(head_row_kernel, dim3(B), dim3(256), lds, s, logits, C, k, centroids, topk_val, topk_idx, argmax, pred_llh);
+    hipLaunchKernelGGL(head_row_kernel<false>, dim3(B), dim3(256), lds, s, logits, C, k, centroids, topk_val, topk_idx, argmax, pred_llh,
+                       (float*)nullptr);
     return pg_check_launch("head_row");
 }
 

@@ -65,3 +65,16 @@ def test_every_device_kernel_has_its_host_side(hip_lib):
         bad = [l.strip() for l in und.splitlines() if "_kernel" in l or "__device_stub__" in l]
         assert not bad, f"{lib}: kernels without a host side: {bad[:4]}"
         ctypes.CDLL(lib)
+
+
+def test_header_is_plain_c():
+    """include/pigeon_hip.h is what a cgo / JNI / ctypes binding reads: it must compile as C (no C++, no HIP types), on its own."""
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        import pytest
+        pytest.skip("no C compiler")
+    r = subprocess.run([cc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "pigeon_hip.h")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
