@@ -43,8 +43,62 @@ def vit_emul(sd, px, act=torch.bfloat16, wdt=torch.bfloat16, patch=torch.bfloat1
         h = h + lin(y, W[p+"mlp.fc2.weight"], W[p+"mlp.fc2.bias"])
     return h
 
+@torch.no_grad()
+def vit_budget(sd, px, on):
+    """The fast path with ONE family of 16-bit roundings switched on at a time (fp16): `on` = set of
+    {'w' weights, 'xn' LayerNorm output = A operand of QKV / fc1, 'q', 'k', 'v', 'p' softmax weights, 'o' attention output,
+    'g' QuickGELU output, 'patch' im2col pixels}.  `python tools/precision_sim.py --budget` prints the embedding error of each."""
+    H = torch.float16
+    r = lambda x, key: x.to(H).float() if key in on else x
+    N = px.shape[0]
+    W = sd
+    lin = lambda x, w, b, key: F.linear(r(x, key), r(w, 'w'), b)
+    x = F.unfold(px, 14, stride=14).transpose(1, 2)
+    pe = lin(x, W["embeddings.patch_embedding.weight"].reshape(1024, -1), None, 'patch')
+    h = torch.cat([W["embeddings.class_embedding"].expand(N, 1, -1), pe], 1) + W["embeddings.position_embedding.weight"][None]
+    h = F.layer_norm(h, (1024,), W["pre_layrnorm.weight"], W["pre_layrnorm.bias"], 1e-5)
+    for i in range(orc.num_layers(sd)):
+        p = f"encoder.layers.{i}."
+        y = F.layer_norm(h, (1024,), W[p+"layer_norm1.weight"], W[p+"layer_norm1.bias"], 1e-5)
+        q = r(lin(y, W[p+"self_attn.q_proj.weight"], W[p+"self_attn.q_proj.bias"], 'xn') * 0.125, 'q')
+        k = r(lin(y, W[p+"self_attn.k_proj.weight"], W[p+"self_attn.k_proj.bias"], 'xn'), 'k')
+        v = r(lin(y, W[p+"self_attn.v_proj.weight"], W[p+"self_attn.v_proj.bias"], 'xn'), 'v')
+        q, k, v = [t.view(N, 577, 16, 64).transpose(1, 2) for t in (q, k, v)]
+        s = q @ k.transpose(-1, -2)
+        e = torch.exp(s - s.max(-1, keepdim=True).values)
+        o = (r(e, 'p') @ v) / e.sum(-1, keepdim=True)
+        o = r(o.transpose(1, 2).reshape(N, 577, 1024), 'o')
+        h = h + lin(o, W[p+"self_attn.out_proj.weight"], W[p+"self_attn.out_proj.bias"], None)
+        y = F.layer_norm(h, (1024,), W[p+"layer_norm2.weight"], W[p+"layer_norm2.bias"], 1e-5)
+        y = lin(y, W[p+"mlp.fc1.weight"], W[p+"mlp.fc1.bias"], 'xn')
+        y = r(y * torch.sigmoid(1.702 * y), 'g')
+        h = h + lin(y, W[p+"mlp.fc2.weight"], W[p+"mlp.fc2.bias"], None)
+    return h.mean(1)
+
+
+def budget():
+    """Round 4: which rounding the embedding error comes from, on the default-init tower and on the spread one (24 layers, 2 images).
+    Measured here (8 cores, ~4 min):   default: all 2.69e-4 = weights 2.62e-4, everything else <= 4.4e-5 (patch), 3.4e-5 (xn) ...
+                                       spread:  all 7.08e-4 = weights 5.07e-4, xn 3.15e-4, k 2.70e-4, patch 2.67e-4, v 1.29e-4,
+                                                g 7.6e-5, q 6.5e-5, o 5.5e-5, p 2.1e-5
+    -> no single operand to split: an exact mode has to carry both halves of every GEMM operand (csrc/precise.hip).  Also tried on
+    the emulation: folding the COHERENT part of the weight-rounding error (mean A operand of a calibration batch x dW) into the
+    biases at load time -- 2.67e-4 -> 9.9e-5 on the default tower, whose images are collinear, 7.47e-4 -> 7.26e-4 on the spread
+    one: it exploits the degeneracy of the fixture, not built."""
+    keys = ['w', 'xn', 'q', 'k', 'v', 'p', 'o', 'g', 'patch']
+    for name, sd in (("default", synthetic.make_vit_weights(seed=0, layers=24)), ("spread", synthetic.make_vit_weights_spread(seed=31, layers=24))):
+        px = synthetic.make_pixels(2, seed=4242)
+        ref = orc.clip_embedding(sd, px)
+        print(name, "all fp16:", f"{orc.rel_err(vit_budget(sd, px, set(keys)), ref):.2e}", flush=True)
+        for k in keys:
+            print(f"   only {k:6s}: {orc.rel_err(vit_budget(sd, px, {k}), ref):.2e}", flush=True)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if "--budget" in sys.argv:
+        budget()
+        sys.exit(0)
     for (name, kw, n) in (("L2 jitter", dict(seed=11, layers=2, affine_jitter=True), 2),
                           ("L24 default", dict(seed=0, layers=24), 1),
                           ("L24 stress", dict(seed=5, layers=24, affine_jitter=True, scale=2.0), 1)):
