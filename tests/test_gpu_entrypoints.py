@@ -587,3 +587,32 @@ def test_evaluate_consumes_the_references_refiner_cache(env, golden_dir, tmp_pat
     assert np.array_equal(res["preds_geocells"], o["preds_geocell"].numpy())
     r = orc.proto_refiner_forward(bank, o["embedding"], o["preds_LLH"], o["topk"].indices, o["topk"].values, 40, 0.6, 100000)
     assert np.array_equal(res["preds"], r[1].numpy())
+
+
+def test_run_py_evaluate_exact_top1(env, monkeypatch, capsys):
+    """`run.py evaluate none --synthetic 16 --exact-top1`: the entry point with the exact mode on (PIGEON_EXACT_TOP1=1 through the
+    flag).  With an untrained head at its natural scale on a 2-layer tower most panoramas are inside the certainty band, so the
+    exact pass really runs; the result dict carries `geocell_certain`, and every geocell equals the oracle's fp32 argmax."""
+    import pigeon_amd.evaluate as ev
+    orc = env["orc"]
+    captured = {}
+    real = ev.evaluate_model
+
+    def spy(model, dataset, metrics, train_args, refiner, *a, **k):
+        captured.update(model=model, dataset=dataset)
+        return real(model, dataset, metrics, train_args, refiner, *a, **k)
+
+    monkeypatch.setattr(ev, "evaluate_model", spy)
+    monkeypatch.delenv("PIGEON_EXACT_TOP1", raising=False)
+    try:
+        results = _run_main(monkeypatch, ["evaluate", "none", "--synthetic", "16", "--layers", "2", "--geocells", "300", "--exact-top1"])
+    finally:
+        os.environ.pop("PIGEON_EXACT_TOP1", None)
+    model, ds = captured["model"], captured["dataset"]
+    assert model.exact_top1 is True and results["geocell_certain"].shape == (16,)
+    px = torch.stack([ds[i]["pixel_values"] for i in range(16)])
+    o = orc.super_guessr_forward(model.cell_layer.weight.data.cpu(), model.cell_layer.bias.data.cpu(), model.lla_geocells.data.cpu(),
+                                 50, vit_sd=model.base_model.state_dict(), pixel_values=px)
+    assert np.array_equal(results["preds_geocells"], o["preds_geocell"].numpy())
+    assert bool(results["geocell_certain"].all())                      # after the exact pass every top-1 is certain
+    assert model._cal_n > 0, "no panorama was re-encoded: the exact pass did not run"
