@@ -591,8 +591,8 @@ def test_evaluate_consumes_the_references_refiner_cache(env, golden_dir, tmp_pat
 
 def test_run_py_evaluate_exact_top1(env, monkeypatch, capsys):
     """`run.py evaluate none --synthetic 16 --exact-top1`: the entry point with the exact mode on (PIGEON_EXACT_TOP1=1 through the
-    flag).  With an untrained head at its natural scale on a 2-layer tower most panoramas are inside the certainty band, so the
-    exact pass really runs; the result dict carries `geocell_certain`, and every geocell equals the oracle's fp32 argmax."""
+    flag).  PIGEON_MARGIN_KAPPA = 1000 puts every panorama inside the certainty band, so the exact pass really runs on all 16;
+    the result dict carries `geocell_certain`, and every geocell equals the oracle's fp32 argmax."""
     import pigeon_amd.evaluate as ev
     orc = env["orc"]
     captured = {}
@@ -604,6 +604,7 @@ def test_run_py_evaluate_exact_top1(env, monkeypatch, capsys):
 
     monkeypatch.setattr(ev, "evaluate_model", spy)
     monkeypatch.delenv("PIGEON_EXACT_TOP1", raising=False)
+    monkeypatch.setenv("PIGEON_MARGIN_KAPPA", "1000")
     try:
         results = _run_main(monkeypatch, ["evaluate", "none", "--synthetic", "16", "--layers", "2", "--geocells", "300", "--exact-top1"])
     finally:
@@ -614,5 +615,5 @@ def test_run_py_evaluate_exact_top1(env, monkeypatch, capsys):
     o = orc.super_guessr_forward(model.cell_layer.weight.data.cpu(), model.cell_layer.bias.data.cpu(), model.lla_geocells.data.cpu(),
                                  50, vit_sd=model.base_model.state_dict(), pixel_values=px)
     assert np.array_equal(results["preds_geocells"], o["preds_geocell"].numpy())
-    assert bool(results["geocell_certain"].all())                      # after the exact pass every top-1 is certain
-    assert model._cal_n > 0, "no panorama was re-encoded: the exact pass did not run"
+    assert model._cal_n == 16, "the exact pass did not run on every panorama"
+    assert results["geocell_certain"].dtype == np.bool_
