@@ -11,6 +11,9 @@
 // HBM layout per chunk: X 4 KB/row fp32, Xn/O 2 KB/row bf16, QKV/H/P 8 KB/row bf16  => 14 KB per token row,
 // 8.1 MB per image; weights 0.61 GB (16-bit) stay resident.  The residual stream and all LayerNorm / softmax
 // statistics are fp32; only MFMA operands are 16-bit: fp16 by default, bf16 with cfg.mma_dtype / PIGEON_MMA_DTYPE=bf16.
+// Round 4: everything between im2col and token_mean is replayed from a hipGraph per (workspace, n) key (vit_forward_body_graphed),
+// and pg_vit_forward_precise runs the same network in near-fp32 arithmetic for the exact mode (split-fp16 GEMM operands on the same
+// MFMA kernels, fp32 attention / LayerNorm / QuickGELU: precise.hip; needs cfg.precise for the 3x weight copy).
 #include "common.h"
 #include "pigeon_internal.h"
 
