@@ -138,6 +138,31 @@ __device__ __forceinline__ void mma16(AccPP& acc, const Frag<T>& f) {
         }
 }
 
+// PG_PP_PHASES = 2 (round 4 experiment, tools/gemm_ab.py): a phase covers a whole k-step of 32 over all 128 rows of the wave -- 8 A
+// + 4 W fragments (48 registers instead of 32), 32 MFMAs -- so a K tile has 2 phases and 4 CU-wide barriers per wave group instead
+// of 4 and 8.  Same MFMA chain per accumulator over k: bit-identical.
+#ifndef PG_PP_PHASES
+#define PG_PP_PHASES 4
+#endif
+template <typename T> struct Frag2 { typename T::v8 a[8], b[4]; };
+template <typename T>
+__device__ __forceinline__ void load_frag2(Frag2<T>& f, const char* sa, const char* sb, int xo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f.a[i] = *(const typename T::v8*)(sa + i * 16 * ROWB + xo);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f.b[j] = *(const typename T::v8*)(sb + j * 16 * ROWB + xo);
+}
+template <typename T, bool ZERO>
+__device__ __forceinline__ void mma32(AccPP& acc, const Frag2<T>& f) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (ZERO) T::mfma16_init(acc[i][j], f.b[j], f.a[i]);
+            else T::mfma16_acc(acc[i][j], f.b[j], f.a[i]);
+        }
+}
+
 __device__ __forceinline__ void wait_lgkm0() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -205,6 +230,38 @@ __device__ __forceinline__ void ktile_pp(AccPP& acc, const char* cur, char* nxt,
                                          u32x4 (&xq)[4][8]) {
     constexpr int D3 = 8 - D0 - D1 - D2;
     static_assert(D3 >= 0, "DMA schedule");
+#if PG_PP_PHASES == 2
+    {
+        Frag2<T> f2;
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            load_frag2<T>(f2, cur + a_base, cur + b_base, xoff[ss]);
+            if (has_next) {
+                if (ss == 0) issue_dma<0, D0 + D1, 0>(c, nxt, wave, voffA, voffW, soff_next);
+                if (ss == 1) issue_dma<D0 + D1, D2 + D3, 0>(c, nxt, wave, voffA, voffW, soff_next);
+            }
+            if constexpr (XF == 1) {
+                if (xf && ss == 1) { fetch_xrows(xq[0], xc, 0); fetch_xrows(xq[1], xc, 1); }
+            }
+            if constexpr (XF == 2) {
+                if (xf && ss == 1) fetch_xrows_wide(xq[0], xc);
+            }
+            if (ss == 1 && has_next) {
+                if (XF == 1 && xf) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (XF == 2 && xf) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            wait_lgkm0();
+            raw_barrier();
+            __builtin_amdgcn_s_setprio(1);
+            if (ss == 0) mma32<T, ZERO>(acc, f2);
+            else mma32<T, false>(acc, f2);
+            __builtin_amdgcn_s_setprio(0);
+            raw_barrier();
+        }
+        return;
+    }
+#endif
     Frag<T> f;
     if constexpr ((ABL & 4) != 0) {                          // ablation: fragments read once per K tile (wrong results)
         load_frag<T, true>(f, cur + a_base, cur + b_base, xoff[0]);

@@ -14,18 +14,20 @@ def one():
     M = 512 * 577
     g = torch.Generator(device=dev).manual_seed(1)
     out = []
-    for name, (N, K, kind) in {"qkv": (3072, 1024, "qkv_ln"), "fc1": (4096, 1024, "gelu_ln"), "fc2": (1024, 4096, "resid_stat")}.items():
+    V = int(os.environ.get("GEMM_AB_VARIANT", "56"))          # 56: 384 x 256 tiles where they exist; 36: 256 x 256 everywhere
+    for name, (N, K, kind) in {"qkv": (3072, 1024, "qkv_ln"), "fc1": (4096, 1024, "gelu_ln"), "fc2": (1024, 4096, "resid_stat"),
+                               "out": (1024, 1024, "resid_stat")}.items():
         A = torch.randn((M, K), generator=g, device=dev).to(dt)
         W = (torch.randn((N, K), generator=g, device=dev) * 0.03).to(dt)
         bias = torch.randn(N, generator=g, device=dev) * 0.1
         cs = torch.randn(N, generator=g, device=dev) * 0.1
         rs = torch.rand((M, 2), generator=g, device=dev) + 0.5
-        X = torch.zeros((M, N), device=dev) if kind == "resid_stat" else None
+        X = torch.zeros((M + 384, N), device=dev)[:M] if kind == "resid_stat" else None   # + the slack the residual epilogue may read
 
         def run():
             if kind == "resid_stat":
-                return hip_ops.gemm16_resid_stat(A, W, bias, X, variant=56)
-            return hip_ops.gemm16_ln(A, W, bias, cs, rs, _lib.EPI_QKV_LN if kind == "qkv_ln" else _lib.EPI_GELU_LN, qscale=0.125, qcols=1024, variant=56)
+                return hip_ops.gemm16_resid_stat(A, W, bias, X, variant=V)
+            return hip_ops.gemm16_ln(A, W, bias, cs, rs, _lib.EPI_QKV_LN if kind == "qkv_ln" else _lib.EPI_GELU_LN, qscale=0.125, qcols=1024, variant=V)
         r = run()
         torch.cuda.synchronize()
         h = hashlib.sha256()
@@ -45,7 +47,7 @@ def one():
         ts.sort()
         out.append(f"{name} {ts[2]:.3f} ms ({h.hexdigest()[:10]})")
         del A, W, X
-    print(os.path.basename(os.environ.get("PIGEON_HIP_LIB", "libpigeon_hip.so")) + ": " + "  ".join(out), flush=True)
+    print(os.path.basename(os.environ.get("PIGEON_HIP_LIB", "libpigeon_hip.so")) + f" variant {V}: " + "  ".join(out), flush=True)
 
 
 if __name__ == "__main__":
