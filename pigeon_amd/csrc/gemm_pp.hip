@@ -262,6 +262,53 @@ __device__ __forceinline__ void ktile_pp(AccPP& acc, const char* cur, char* nxt,
         return;
     }
 #endif
+#if PG_PP_PHASES == 8
+    {   // eight phases per K tile: (k-step s, quarter q of the wave's 128 rows), 2 A fragments per phase, the 4 W fragments of a k-step
+        // read in its first quarter; 8 MFMAs per phase, 16 barriers per K tile and wave group
+        typename T::v8 fa[2], fb[4];
+#pragma unroll
+        for (int ph = 0; ph < 8; ++ph) {
+            const int ss = ph >> 2, q = ph & 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *(const typename T::v8*)(cur + a_base + (q * 2 + i) * 16 * ROWB + xoff[ss]);
+            if (q == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = *(const typename T::v8*)(cur + b_base + j * 16 * ROWB + xoff[ss]);
+            }
+            if (has_next) {
+                if (ph == 0) issue_dma<0, 2, 0>(c, nxt, wave, voffA, voffW, soff_next);
+                if (ph == 1) issue_dma<2, 2, 0>(c, nxt, wave, voffA, voffW, soff_next);
+                if (ph == 2) issue_dma<4, 2, 0>(c, nxt, wave, voffA, voffW, soff_next);
+                if (ph == 3) issue_dma<6, 2, 0>(c, nxt, wave, voffA, voffW, soff_next);
+            }
+            if constexpr (XF == 1) {
+                if (xf && ph == 5) fetch_xrows(xq[0], xc, 0);
+                if (xf && ph == 7) fetch_xrows(xq[1], xc, 1);
+            }
+            if constexpr (XF == 2) {
+                if (xf && ph == 7) fetch_xrows_wide(xq[0], xc);
+            }
+            if (ph == 7 && has_next) {
+                if (XF == 1 && xf) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (XF == 2 && xf) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            wait_lgkm0();
+            raw_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (ZERO && ss == 0) T::mfma16_init(acc[q * 2 + i][j], fb[j], fa[i]);
+                    else T::mfma16_acc(acc[q * 2 + i][j], fb[j], fa[i]);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            raw_barrier();
+        }
+        return;
+    }
+#endif
     Frag<T> f;
     if constexpr ((ABL & 4) != 0) {                          // ablation: fragments read once per K tile (wrong results)
         load_frag<T, true>(f, cur + a_base, cur + b_base, xoff[0]);
