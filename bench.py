@@ -713,6 +713,15 @@ def _worker(args, comm):
             refiner = ProtoRefiner(topk=args.topk, max_refinement=1000, temperature=1.6, bank=bank_t, device=str(dev)).eval()
         g = torch.Generator(device=dev).manual_seed(1234 + rank)
         pixel_batches = [torch.randn((args.panoramas, 12, 336, 336), generator=g, device=dev) for _ in range(nb)]   # resident in HBM
+    rccl_error = None
+    if not dry and world == 1 and comm.force_rccl:
+        # the forced 1-rank communicator is an early warning, not a dependency of the single-GPU line: if RCCL cannot come up on
+        # this box the step falls back to the identity gather and the line says why
+        try:
+            comm.gather_many([torch.zeros(4, device=dev)])
+        except Exception as e:  # noqa
+            rccl_error = repr(e)
+            comm.force_rccl = False
     pipe = PanoramaPipeline(model, refiner, comm)
     # sample ids as a sharded DataLoader deals them (batch i -> rank i % world, preprocessing/embed.py:68): interleaved, so the
     # gathered results really need restore_order
@@ -929,6 +938,9 @@ def _worker(args, comm):
                           "collective": "pg_allgather_many (C ABI, csrc/comm.hip): 5 buffers before refinement + 2 after, one grouped launch each",
                           "inside_timed_region": True, "both_gathers_us_per_step": gather_us,
                           "forced_at_one_rank": bool(world == 1)}
+    if rccl_error is not None:
+        result["rccl"] = {"error": rccl_error, "forced_at_one_rank": False,
+                          "note": "the 1-rank RCCL communicator could not be created; the step ran with the identity gather"}
     if refiner is not None and pipe.refine_events:
         ms = [a.elapsed_time(b_) for a, b_ in pipe.refine_events]
         rows = [float(s[..., 3].sum()) for s in refine_rows]
