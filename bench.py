@@ -753,7 +753,10 @@ def _worker(args, comm):
     if not dry and world == 1 and args.exact_steps > 0:
         # one-off, per set of weights: what the 16-bit path's embedding error is on THIS model (16 panoramas through the fast and the
         # exact encoder); the certainty bound of the default mode below is 4 x 1.25 x that instead of 4 x the contract's 1e-3
-        cal_rms = model.calibrate_certainty(pixel_batches[nb - 1][-16:])
+        try:
+            cal_rms = model.calibrate_certainty(pixel_batches[nb - 1][-16:])
+        except Exception as e:  # noqa  (the default mode does not depend on it: the bound stays at the contract's 1e-3)
+            print(f"[bench] certainty calibration failed: {e!r}", file=sys.stderr)
     for i in range(max(args.warmup, 1)):
         out = pipe.step(pixel_batches[i % nb], index)
     sync()
