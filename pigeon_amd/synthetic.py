@@ -121,7 +121,8 @@ def make_vit_weights_trained_like(seed: int = 21, layers: int = LAYERS) -> Dict[
 
 
 def make_vit_weights_spread(seed: int = 31, layers: int = LAYERS, q_bias_std: float = 3.5, k_gain: float = 4.0,
-                            v_gain: float = 4.0, heads_frac: float = 0.25) -> Dict[str, torch.Tensor]:
+                            v_gain: float = 4.0, heads_frac: float = 0.25,
+                            base: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
     """Random weights whose EMBEDDINGS spread the way a trained tower's do (round 4 fixture `pipeline24_spread`).
 
     A default-init tower maps every image to nearly the same token mean (pairwise cos-sim 0.94 .. 0.96): every per-token
@@ -137,7 +138,9 @@ def make_vit_weights_spread(seed: int = 31, layers: int = LAYERS, q_bias_std: fl
     also where 16-bit Q / K operands cost the most: tools/precision_sim.py predicts ~7e-4 relative embedding error for fp16
     operands on these weights (2.7e-4 default init).
     """
-    sd = make_vit_weights(seed=seed, layers=layers, affine_jitter=True)
+    # base: apply the attention modification to another state dict (e.g. make_vit_weights_trained_like: massive activations AND
+    # spread embeddings in one tower); default = the jittered HF-init tower the committed fixture uses
+    sd = make_vit_weights(seed=seed, layers=layers, affine_jitter=True) if base is None else {k: v.clone() for k, v in base.items()}
     g = torch.Generator().manual_seed(seed + 500)
     nh = max(1, int(HEADS * heads_frac))
     for i in range(layers):

@@ -342,3 +342,41 @@ def test_exact_mode_edges(env, tmp_path, capsys):
     assert e0.embedding.shape[0] == 0 and m.last_certain.numel() == 0
     e1 = m(pixel_values=px[:1], labels_clf=None)
     assert torch.equal(e1.embedding, want[:1])
+
+
+def test_trained_like_and_spread_tower_vs_reference_module(env, capsys):
+    """The two stress regimes in ONE 24-layer tower -- massive activations / rows with |mean| >> std (make_vit_weights_trained_like)
+    AND input-selected global attention (make_vit_weights_spread) -- against the reference's own module
+    (transformers.CLIPVisionModel, fp32, eager attention, stock PyTorch-ROCm on this GPU; never part of the product): fast path
+    within the 1e-3 contract with no fp16 range alarm, exact mode within EXACT_TOL.  No committed fixture: the checker is computed here."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    ops, syn = env["ops"], env["syn"]
+    sd = syn.make_vit_weights_spread(seed=31, layers=24, base=syn.make_vit_weights_trained_like(seed=21, layers=24))
+    cfg = CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=336,
+                           patch_size=14, projection_dim=768)
+    hf = CLIPVisionModel._from_config(cfg, attn_implementation="eager")
+    hf.load_state_dict(sd, strict=True)
+    hf = hf.to(DEV).eval()
+    torch.backends.cuda.matmul.allow_tf32 = False
+    px = syn.make_pixels(16, seed=2718).to(DEV)
+    with torch.no_grad():
+        hid = hf(pixel_values=px).last_hidden_state
+    ref = hid.mean(dim=1).cpu()
+    absmax = float(hid.abs().max())
+    ie = ref / ref.norm(dim=1, keepdim=True)
+    cs = (ie @ ie.t())[~torch.eye(16, dtype=torch.bool)]
+    del hf, hid
+    torch.cuda.empty_cache()
+    enc = ops.VitEncoder(sd, layers=24, precise=True)
+    fast = enc(px).cpu()
+    alarm = enc.range_alarm_read()
+    exact = enc.forward_precise(px).cpu()
+    e_fast, e_exact = _rel(fast, ref), _rel(exact, ref)
+    worst = float(((fast.double() - ref.double()).norm(dim=1) / ref.double().norm(dim=1)).max())
+    with capsys.disabled():
+        print(f"\ntrained-like + spread tower: |hidden| max {absmax:.0f}, image cos-sim mean {float(cs.mean()):.2f} max {float(cs.max()):.2f}; "
+              f"embedding rel err fast {e_fast:.2e} (worst image {worst:.2e}), exact {e_exact:.2e}; fp16 range alarm rows {alarm}")
+    enc.close()
+    assert alarm == 0
+    assert e_fast < 1e-3 and worst < 1.5e-3
+    assert e_exact < EXACT_TOL
