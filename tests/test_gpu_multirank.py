@@ -68,3 +68,22 @@ def test_rccl_allgather_many_with_two_or_more_ranks():
     if n < world:
         pytest.skip(f"needs {world} GPUs on one node, this box has {n}")
     mp.spawn(_worker, args=(world, _free_port()), nprocs=world, join=True)
+
+
+def test_bench_two_ranks_on_two_gpus():
+    """`python bench.py --gpus 2` on a node with >= 2 GPUs: the driver's scaling command at its smallest size, end to end over RCCL
+    (self-launch, NUMA pinning, both grouped all-gathers inside the timed region, restore order, per-rank step times, teardown)."""
+    import json
+    import subprocess
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"needs 2 GPUs on one node, this box has {torch.cuda.device_count()}")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--layers", "2",
+                        "--panoramas", "16", "--cells", "500", "--protos-per-cell", "10"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["rccl"]["nranks"] == 2 and len(r["per_rank_ms_per_step"]) == 2
+    assert r["gathered_results"]["complete_and_in_sample_order"] is True and r["gathered_results"]["panoramas"] == 32
+    assert r["config"]["images_per_step"] == 2 * 16 * 4 and r["scaling"] == "weak"
