@@ -185,15 +185,17 @@ def init_from_env(backend: Optional[str] = None, set_device: bool = True, join_t
 def _await_all_ranks(rank: int, world: int, timeout_s: float) -> None:
     """Bounded wait that NAMES who is missing, in front of torch's own rendezvous.  torch's env:// rendezvous just blocks (30
     minutes by default) when a rank never shows up -- on an 8-GPU launch the useful message is "rank(s) [5] did not join".
-    One node, one launcher (the contract of this path: one process per GPU of ONE node): every rank drops a file
-    `rank_<r>` into a directory named after the launcher's pid and MASTER_PORT and waits until all `world` files are there or
-    `timeout_s` is over.  Files are removed at exit.  Any filesystem trouble skips the check -- torch's rendezvous then does its
-    own waiting (this must never break a launch that would have worked)."""
+    One node (the contract of this path: one process per GPU of ONE node): every rank drops a file `rank_<r>` into a directory
+    named after MASTER_PORT (one rendezvous per port at a time) and waits until all `world` files are there or `timeout_s` is over.
+    Files are removed at exit; a stale file of a killed run only weakens the check.  The check must never break a launch that
+    would have worked: any filesystem trouble skips it, and it only RAISES when it has seen at least one other rank's file (proof
+    that the ranks share the directory) -- a rank that sees nobody (ranks in separate containers / TMPDIRs) prints a note and lets
+    torch's rendezvous do its own waiting."""
     import atexit
     import tempfile
     import time
     try:
-        d = os.path.join(tempfile.gettempdir(), f"pigeon_join_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}")
+        d = os.path.join(tempfile.gettempdir(), f"pigeon_join_{os.environ.get('MASTER_PORT', '0')}")
         os.makedirs(d, exist_ok=True)
         mine = os.path.join(d, f"rank_{rank}")
         with open(mine, "w") as f:
@@ -209,13 +211,20 @@ def _await_all_ranks(rank: int, world: int, timeout_s: float) -> None:
     except OSError:
         return
     t_end = time.time() + timeout_s
+    seen_other = False
     while True:
         missing = [r for r in range(world) if not os.path.exists(os.path.join(d, f"rank_{r}"))]
         if not missing:
             return
+        seen_other = seen_other or len(missing) < world - 1
         if time.time() > t_end:
+            if not seen_other:                                 # nobody else was ever visible: no proof of a shared directory
+                import sys
+                print(f"[pigeon_amd] rank {rank}: saw no other rank in {d} within {timeout_s:.0f} s; leaving the wait to torch's "
+                      f"rendezvous", file=sys.stderr)
+                return
             raise TimeoutError(f"rank {rank}: rank(s) {missing} of {world} did not join within {timeout_s:.0f} s "
-                               f"(launcher pid {os.getppid()}, MASTER_PORT {os.environ.get('MASTER_PORT')})")
+                               f"(MASTER_PORT {os.environ.get('MASTER_PORT')})")
         time.sleep(0.05)
 
 
