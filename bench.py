@@ -89,7 +89,11 @@ def parse(argv=None):
     ap.add_argument("--cpu-port-images", type=int, default=16, help="images through the oracle restatement (kind 'port') on the CPU (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="CPU-baseline worker processes x 16 threads (0 = hardware threads / 16)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)       # internal: run one CPU-baseline worker from a spec file
-    ap.add_argument("--exact-steps", type=int, default=3, help="steps of the exact-mode leg after the timed region (0 = skip)")
+    ap.add_argument("--fast", action="store_true",
+                    help="time the 16-bit fast mode (SuperGuessr(exact_top1=False): no certainty-driven exact re-encode) as the headline; "
+                         "its geocell argmax is NOT guaranteed to be the reference's -- A/B and kernel-profiling runs only")
+    ap.add_argument("--fast-steps", type=int, default=3, help="steps of the fast-mode leg after the timed region (0 = skip)")
+    ap.add_argument("--raster-gn", type=int, default=None, help="pg_tune_gemm_raster for this run (A/B of the 384x256 GEMM raster)")
     ap.add_argument("--weights", choices=["default", "spread"], default="default",
                     help="default: HF-init tower (seed 0), head centred on the mean embedding and scaled to sigma(logit) = 4 (BASELINE's synthetic "
                          "workload).  spread: synthetic.make_vit_weights_spread (input-selected global attention: embeddings spread like a trained "
@@ -409,10 +413,15 @@ def parity_report(args, dev, model, o, refined, hip):
         rep["refined_cell_equal_where_argmax_equal"] = f"{int((hip['refined_geocell'].cpu()[keep] == r_cell[keep]).sum())}/{int(keep.sum())}"
         same_ll = (hip["refined_LLH"].cpu()[keep] == r_llh[keep]).all(dim=1)
         rep["refined_lnglat_equal_where_argmax_equal"] = f"{int(same_ll.sum())}/{int(keep.sum())}"
+        # ... and UNCONDITIONALLY: panoramas whose refined cell or (lng, lat) differs from the reference chain's, whatever the reason
+        bad = (hip["refined_geocell"].cpu() != r_cell) | (hip["refined_LLH"].cpu() != r_llh).any(dim=1)
+        rep["refined_mismatch_unconditional"] = int(bad.sum())
+        rep["refined_mismatched"] = [hip["where"][i] for i in torch.nonzero(bad).flatten().tolist()][:16]
     return rep
 
 
-def gpu_module_parity(args, dev, vit_sd, model, pixel_batches, used, outs_default, certain_by_batch, outs_exact, cpu_sample_emb, per):
+def gpu_module_parity(args, dev, vit_sd, model, pixel_batches, used, outs_default, certain_by_batch, outs_other, other_name, cpu_sample_emb, per,
+                      bank_t=None):
     """Top-1 parity over EVERY panorama of the resident pixel batches (4 x 128 = 512), which the 16-CPU quota of these boxes puts out
     of the CPU oracle's reach: the reference's own module -- transformers.CLIPVisionModel, fp32, eager attention, stock
     PyTorch-ROCm -- runs on this GPU (never part of the product path), the oracle's head turns its embeddings into logits, and the
@@ -445,9 +454,29 @@ def gpu_module_parity(args, dev, vit_sd, model, pixel_batches, used, outs_defaul
     where = [f"batch {j} #{i}" for j in used for i in range(n_per)]
 
     def take(outs):
-        return {"embedding": torch.cat([outs[j]["embedding"] for j in used]), "preds_geocell": torch.cat([outs[j]["preds_geocell"] for j in used]),
-                "where": where}
-    rep = parity_report(args, dev, model, o, None, take(outs_default))
+        h = {"embedding": torch.cat([outs[j]["embedding"] for j in used]), "preds_geocell": torch.cat([outs[j]["preds_geocell"] for j in used]),
+             "where": where}
+        if "refined_geocell" in outs[used[0]]:
+            h["refined_geocell"] = torch.cat([outs[j]["refined_geocell"] for j in used])
+            h["refined_LLH"] = torch.cat([outs[j]["refined_LLH"] for j in used])
+        return h
+    refined = None
+    if bank_t is not None:
+        # the reference chain's refinement of ALL these panoramas: the oracle's restatement (bit-exact against the real reference on
+        # the fixtures) on the reference module's embeddings and the oracle head's candidates
+        class _B:
+            pass
+        hb = _B()
+        hb.proto_emb, hb.train_emb, hb.train_lnglat = _LazyRows(bank_t["proto_emb"]), _LazyRows(bank_t["train_emb"]), _LazyRows(bank_t["train_lnglat"])
+        for kk in ("cell_off", "proto_count", "member_off", "member_idx"):
+            setattr(hb, kk, bank_t[kk].cpu().numpy())
+        hb.proto_lnglat = bank_t["proto_lnglat"].cpu().numpy()
+        t1 = time.perf_counter()
+        _, r_llh, r_cell = orc.proto_refiner_forward(hb, o["embedding"], o["preds_LLH"], o["topk"].indices, o["topk"].values, args.topk, 1.6, 1000)
+        refined = (r_llh, r_cell, hb)
+    rep = parity_report(args, dev, model, o, refined, take(outs_default))
+    if refined is not None:
+        rep["reference_refine_seconds"] = time.perf_counter() - t1
     rep["from"] = "pixels through transformers.CLIPVisionModel fp32 (eager attention, stock PyTorch-ROCm) on this GPU vs this run's step outputs"
     rep["oracle"] = "the reference's module in fp32 on the GPU + the oracle's head; pinned to the CPU oracle on the bounded sample below"
     rep["reference_seconds"] = t_ref
@@ -455,9 +484,10 @@ def gpu_module_parity(args, dev, vit_sd, model, pixel_batches, used, outs_defaul
     rep["certain"] = f"{int(cert.sum())}/{cert.numel()}"
     rep["flips_among_certain"] = int(sum(1 for r in rep["flipped"] if bool(cert[where.index(r["panorama"])])))
     rep.pop("smallest_margins", None)
-    if outs_exact and all(j in outs_exact for j in used):
-        rx = parity_report(args, dev, model, o, None, take(outs_exact))
-        rep["exact_mode"] = {k: rx[k] for k in ("embedding_rel_err", "logit_abs_err_max", "flips", "flipped", "geocell_argmax_equal")}
+    if outs_other and all(j in outs_other for j in used):
+        rx = parity_report(args, dev, model, o, refined, take(outs_other))
+        rep[other_name] = {k: rx[k] for k in ("embedding_rel_err", "logit_abs_err_max", "flips", "flipped", "geocell_argmax_equal",
+                                              "refined_mismatch_unconditional", "refined_mismatched") if k in rx}
     if cpu_sample_emb is not None:
         sel = torch.cat([ref_emb[k * n_per:k * n_per + per] for k in range(len(used))])
         rep["vs_cpu_oracle_embedding_rel_err"] = orc.rel_err(sel, cpu_sample_emb)
@@ -685,6 +715,9 @@ def _worker(args, comm):
         from pigeon_amd.proto_refiner import ProtoRefiner
         from pigeon_amd.super_guessr import SuperGuessr
         _lib.require_gpu()
+        if args.raster_gn is not None:
+            from pigeon_amd import hip_ops
+            hip_ops.tune_gemm_raster(args.raster_gn)
         if local >= torch.cuda.device_count():
             raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but this box has {torch.cuda.device_count()} GPU(s)")
         torch.cuda.set_device(local)
@@ -702,7 +735,8 @@ def _worker(args, comm):
         geo_csv = os.path.join(tmp, f"geocells_{rank}.csv")
         synthetic.write_geocell_csv(geo_csv, synthetic.make_geocells(args.cells, seed=0))
         with contextlib.redirect_stdout(io.StringIO()):
-            model = SuperGuessr(base, panorama=True, freeze_base=True, num_candidates=args.topk, geocell_path=geo_csv)
+            model = SuperGuessr(base, panorama=True, freeze_base=True, num_candidates=args.topk, geocell_path=geo_csv,
+                                exact_top1=not args.fast, margin_autocalibrate=False)
         W, b = synthetic.make_head_weights(args.cells, seed=0)
         with torch.no_grad():
             model.cell_layer.weight.copy_(W)
@@ -749,13 +783,12 @@ def _worker(args, comm):
                 torch.distributed.broadcast_object_list(sc, src=0)
             model.cell_layer.weight.mul_(sc[0])
             model.cell_layer.bias.copy_(b.to(dev) - model.cell_layer.weight.data @ center)
-    cal_rms = None
-    if not dry and world == 1 and args.exact_steps > 0:
-        # one-off, per set of weights: what the 16-bit path's embedding error is on THIS model (16 panoramas through the fast and the
-        # exact encoder); the certainty bound of the default mode below is 4 x 1.25 x that instead of 4 x the contract's 1e-3
+    if not dry:
+        # one-off, per set of weights: what the 16-bit path's embedding error IS on this model -- 32 panoramas through the fast and the
+        # exact encoder: the systematic part of their difference and the RMS of the rest (pigeon_amd/certainty.py); frozen afterwards
         try:
-            cal_rms = model.calibrate_certainty(pixel_batches[nb - 1][-16:])
-        except Exception as e:  # noqa  (the default mode does not depend on it: the bound stays at the contract's 1e-3)
+            model.calibrate_certainty(pixel_batches[nb - 1][-32:])
+        except Exception as e:  # noqa  (nothing depends on it but the size of the re-encoded set: the threshold stays at the contract's 1e-3)
             print(f"[bench] certainty calibration failed: {e!r}", file=sys.stderr)
     for i in range(max(args.warmup, 1)):
         out = pipe.step(pixel_batches[i % nb], index)
@@ -774,7 +807,10 @@ def _worker(args, comm):
     refine_rows = []
     outs_by_batch = {}
     certain_by_batch = {}
+    info_by_step = []
 
+    # five time stamps per step on the launch stream (host clock in --dry-run): compute vs gather(-wait), per rank
+    pipe.split_marks = []
     # ---- timed region: exactly K steps between barrier + synchronize on both sides ----
     comm.barrier()
     sync()
@@ -783,7 +819,8 @@ def _worker(args, comm):
         out = pipe.step(pixel_batches[i % nb], index)
         outs_by_batch[i % nb] = out                               # references only; read after the timed region
         if not dry:
-            certain_by_batch[i % nb] = (model.last_certain, model.last_margin, model.last_bound)
+            info_by_step.append(pipe.last_info)                    # device tensors; read after the timed region
+            certain_by_batch[i % nb] = (pipe.last_info["certain"], model.last_margin, model.last_bound)
         if refiner is not None and not dry:
             refine_rows.append(refiner.last_scratch)             # device tensor kept; summed after the timed region
     sync()
@@ -816,6 +853,16 @@ def _worker(args, comm):
                                  "(this rank, right after the timed region): where `kernels` / `roofline` are measured"}
         enc.graph(True)
     rank_ms = [x / args.steps * 1e3 for x in comm.all_values(dt)]
+    # per rank: mean compute ms (encoder + head + certainty + exact re-encode + refinement) and mean gather ms (both grouped
+    # all-gathers INCLUDING the wait for the slowest rank) per step: a rank that re-encodes more than the others shows up as compute
+    # there and as gather-wait everywhere else
+    sp = [PanoramaPipeline.split_ms(m) for m in (pipe.split_marks or []) if len(m) == 5]
+    pipe.split_marks = None
+    my_compute = float(np.mean([c for c, _ in sp])) if sp else 0.0
+    my_gather = float(np.mean([g for _, g in sp])) if sp else 0.0
+    rank_compute, rank_gather = comm.all_values(my_compute), comm.all_values(my_gather)
+    my_re = float(np.mean([int(inf["reencoded"].numel()) for inf in info_by_step if inf is not None])) if info_by_step else 0.0
+    rank_reenc = comm.all_values(my_re)
     dt = comm.max_over_ranks(dt)
 
     # ---- what every rank (rank 0 in particular) holds after the last step: the whole batch, restorable to sample order ----
@@ -863,6 +910,11 @@ def _worker(args, comm):
         "metric": "images/sec end-to-end (ViT+head+refine), 4x336x336",
         "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": step_ms, "per_rank_ms_per_step": [round(x, 3) for x in rank_ms],
+        "per_rank_split_ms": {"compute": [round(x, 3) for x in rank_compute], "gather_incl_wait": [round(x, 3) for x in rank_gather],
+                              "reencoded_panoramas_per_step": [round(x, 2) for x in rank_reenc],
+                              "what": "stream time stamps around the two grouped all-gathers of every timed step: compute = encoder + head + "
+                                      "certainty + exact re-encode + refinement; gather = both collectives including the wait for the "
+                                      "slowest rank"},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32-stub" if dry else enc.mma_dtype, "data": "synthetic",
         "config": {"workload": "BASELINE configs[3]: SuperGuessr 4-panorama ViT-L/14-336 + 10k-geocell head + ProtoRefiner "
@@ -910,13 +962,7 @@ def _worker(args, comm):
         result["ungraphed_evented"] = ungraphed
     cf = [c[0].float().mean().item() for c in certain_by_batch.values() if c[0] is not None]
     if cf:
-        result["certain_frac"] = float(np.mean(cf))
-        result["certainty_rule"] = (f"top-1 certain when logit(top1) - logit(top2) > {model.margin_kappa:g} x {model.margin_rel_tol:.3g} x |emb| "
-                                    "|W[top1] - W[top2]| / sqrt(1024) (pg_head_margin).  The middle factor is the model's relative embedding "
-                                    "error, " + (f"calibrated before the timed region on 16 panoramas through the fast and the exact encoder (RMS "
-                                                 f"{cal_rms:.3g}, x 1.25)" if cal_rms is not None else "the contract's tolerance 1e-3 (uncalibrated)") +
-                                    "; the margin change is Gaussian in those units (reference fixtures: max over 128 panoramas 2.8 sigma), "
-                                    "4 is the z-score")
+        result["certain_frac"] = float(np.mean(cf))               # after the exact re-encode (product mode) / as flagged (--fast)
     if pinned:
         result["config"]["rank0_cores"] = f"{len(pinned)} cores next to GPU {local} (sched_setaffinity)"
     result["roofline"] = {"bound": "mfma", "kernel": f"gemm16 {dom}: M={chunk_rows} rows x {GEMM_FLOPS[dom]} FLOP/row per launch",
@@ -1005,42 +1051,57 @@ def _worker(args, comm):
             oc.append({"error": repr(e)})
         result["other_configs"] = oc
 
-    # ---- exact mode: the same step with SuperGuessr(exact_top1): panoramas whose top-1 margin is inside the 16-bit path's error
-    # band are re-encoded from their pixels in near-fp32 arithmetic (pg_vit_forward_precise) -- its cost, stated next to `value` ----
-    exact_outs = {}
+    # ---- the two modes next to each other.  The timed region ran the PRODUCT configuration: exact_top1 (every discrete output --
+    # geocell argmax, refined cell and point -- is the fp32 reference's; samples inside the 16-bit path's error band are re-encoded by
+    # pg_vit_forward_precise), unless --fast.  The other mode runs here for --fast-steps steps on the same resident batches. ----
+    other_outs = {}
     cpu_sample_emb, cpu_per = None, 0
-    if world == 1 and args.exact_steps > 0:
+    headline_exact = bool(model.exact_top1)
+    n_re = [int(inf["reencoded"].numel()) for inf in info_by_step if inf is not None]
+    cert_all = [inf["certain"] for inf in info_by_step if inf is not None]
+    result["certainty"] = {
+        "mode": "exact_top1 (product default)" if headline_exact else "fast (--fast): certainty reported, nothing re-encoded",
+        "rule": model.certainty.describe(), "calibration": model.certainty.stats,
+        "reencoded_panoramas_per_step": n_re, "panoramas_per_step": args.panoramas,
+        "uncertain_after_step": [int((~c).sum()) for c in cert_all],
+        "boundary_checked": bool(info_by_step and info_by_step[-1] is not None and info_by_step[-1].get("boundary_checked"))}
+    if world == 1 and args.fast_steps > 0:
         try:
-            base.enable_precise(True)                             # repacks the encoder with the split-weight copy (one-off)
-            model.exact_top1 = True
+            model.exact_top1 = not headline_exact
+            if model.exact_top1:
+                base.enable_precise(True)
             pipe.refine_events = None
-            pipe.step(pixel_batches[0], index)                    # warm-up: weight packing, exact-mode workspace
+            pipe.step(pixel_batches[0], index)                    # warm-up of the other mode (workspaces, weight copies)
             torch.cuda.synchronize()
-            n_re = []
+            n_re_o = []
             te = time.perf_counter()
-            for i in range(args.exact_steps):
-                exact_outs[i % nb] = pipe.step(pixel_batches[i % nb], index)
-                n_re.append(model.last_reencoded)
+            for i in range(args.fast_steps):
+                other_outs[i % nb] = pipe.step(pixel_batches[i % nb], index)
+                n_re_o.append(pipe.last_info["reencoded"])
             torch.cuda.synchronize()
-            te = (time.perf_counter() - te) / args.exact_steps
-            for i in range(args.exact_steps, nb):                 # the parity sample below wants every resident batch (untimed)
-                exact_outs[i] = pipe.step(pixel_batches[i], index)
+            te = (time.perf_counter() - te) / args.fast_steps
+            for i in range(nb):                                    # the parity legs below want every resident batch (untimed)
+                if i not in other_outs:
+                    other_outs[i] = pipe.step(pixel_batches[i], index)
             torch.cuda.synchronize()
-            n_re = [int(x.numel()) for x in n_re]
-            result["exact_mode"] = {
-                "value": args.panoramas * 4 / te, "unit": "images/s", "ms_per_step": te * 1e3, "steps": args.exact_steps,
-                "cost_vs_default": te * 1e3 / step_ms, "reencoded_panoramas_per_step": n_re, "panoramas_per_step": args.panoramas,
-                "margin_rel_tol_calibrated": model.margin_rel_tol, "margin_kappa": model.margin_kappa,
-                "fast_vs_exact_embedding_rms": (model._cal_sumsq / max(1, model._cal_n)) ** 0.5, "calibration_samples": model._cal_n,
-                "what": "PIGEON_EXACT_TOP1=1 / SuperGuessr(exact_top1=True): after the fast pass, panoramas that are not certain (see "
-                        "certainty_rule) are re-encoded FROM THE PIXELS by pg_vit_forward_precise (split-fp16 GEMM operands on the same "
-                        "MFMA kernels, fp32 attention / LayerNorm / QuickGELU: ~1e-6 relative vs 2.7e-4) and their head outputs recomputed; "
-                        "refinement then runs on the corrected candidates.  Synchronises once per step (the uncertain set is data dependent)"}
-            model.exact_top1 = False
+            leg = {"value": args.panoramas * 4 / te, "unit": "images/s", "ms_per_step": te * 1e3, "steps": args.fast_steps,
+                   "mfma_frac_end_to_end": args.panoramas * 4 / te * FLOP_PER_IMAGE / PEAK_MFMA,
+                   "reencoded_panoramas_per_step": [int(x.numel()) for x in n_re_o]}
+            if headline_exact:
+                leg["what"] = ("SuperGuessr(exact_top1=False) / PIGEON_EXACT_TOP1=0: the 16-bit path alone -- embeddings within 1e-3, discrete "
+                               "outputs NOT guaranteed (see the parity legs' `fast_mode` entries); timed after the timed region")
+                result["fast_mode"] = leg
+                result["exact_cost_vs_fast"] = step_ms / (te * 1e3)
+            else:
+                leg["what"] = "SuperGuessr(exact_top1=True), the product default, timed after the timed region (the headline of this run is --fast)"
+                result["exact_mode"] = leg
+                result["exact_cost_vs_fast"] = te * 1e3 / step_ms
+            model.exact_top1 = headline_exact
         except Exception as e:  # noqa
             import traceback
-            result["exact_mode"] = {"error": repr(e), "trace": traceback.format_exc()[-600:]}
-            model.exact_top1 = False
+            result["fast_mode" if headline_exact else "exact_mode"] = {"error": repr(e), "trace": traceback.format_exc()[-600:]}
+            model.exact_top1 = headline_exact
+    other_name = "fast_mode" if headline_exact else "exact_mode"
 
     if world == 1 and args.cpu_images > 0:
         try:
@@ -1065,10 +1126,11 @@ def _worker(args, comm):
             cert = hip["certain"]
             rep["certain"] = f"{int(cert.sum())}/{cert.numel()}"
             rep["flips_among_certain"] = int(sum(1 for r in rep["flipped"] if bool(cert[hip["where"].index(r["panorama"])])))
-            if exact_outs and all(j in exact_outs for j in used):
-                rx = parity_report(args, dev, model, o, refined, take(exact_outs))
-                rep["exact_mode"] = {k: rx[k] for k in ("embedding_rel_err", "logit_abs_err_max", "flips", "flipped", "geocell_argmax_equal",
-                                                         "refined_cell_equal_where_argmax_equal", "refined_lnglat_equal_where_argmax_equal") if k in rx}
+            if other_outs and all(j in other_outs for j in used):
+                rx = parity_report(args, dev, model, o, refined, take(other_outs))
+                rep[other_name] = {k: rx[k] for k in ("embedding_rel_err", "logit_abs_err_max", "flips", "flipped", "geocell_argmax_equal",
+                                                      "refined_mismatch_unconditional", "refined_cell_equal_where_argmax_equal",
+                                                      "refined_lnglat_equal_where_argmax_equal") if k in rx}
             result["parity_vs_oracle_sample"] = rep
             cpu_sample_emb, cpu_per = o["embedding"], per
         except Exception as e:  # noqa
@@ -1078,7 +1140,8 @@ def _worker(args, comm):
         try:
             used = sorted(outs_by_batch)
             result["parity_vs_reference_module_gpu_fp32"] = gpu_module_parity(
-                args, dev, vit_sd, model, pixel_batches, used, outs_by_batch, certain_by_batch, exact_outs, cpu_sample_emb, cpu_per)
+                args, dev, vit_sd, model, pixel_batches, used, outs_by_batch, certain_by_batch, other_outs, other_name, cpu_sample_emb, cpu_per,
+                bank_t if refiner is not None else None)
         except Exception as e:  # noqa
             import traceback
             result["parity_vs_reference_module_gpu_fp32"] = {"error": repr(e), "trace": traceback.format_exc()[-600:]}

@@ -37,7 +37,8 @@ extern "C" {
 #define PG_DTYPE_F16     2
 #define PG_DTYPE_F64     3
 
-#define PG_ABI_VERSION   2   /* 2: pg_vit_cfg.precise, pg_vit_forward_precise, pg_head_margin (round 4) */
+#define PG_ABI_VERSION   3   /* 2: pg_vit_cfg.precise, pg_vit_forward_precise, pg_head_margin (round 4); 3: pg_head_certainty, pg_refine_forward_ex,
+                              * pg_refine_certainty, pg_tune_gemm_raster (round 5) */
 
 const char* pg_last_error(void);
 int pg_abi_version(void);
@@ -139,6 +140,10 @@ int pg_tune_gemm_tail_rows(int rows);
 /* ... and only for GEMMs with K >= min_k or N >= min_n (env PIGEON_GEMM_TAIL_MIN_K / PIGEON_GEMM_TAIL_MIN_N; defaults 2048 / 4096:
  * of the model's four GEMMs the split pays for fc2 and fc1 only).  (0, 0) = every shape.  Timing only, never results. */
 int pg_tune_gemm_tail_shape(int min_k, int min_n);
+/* Raster of the 384 x 256 persistent GEMM (QKV, fc1, fc2; also env PIGEON_GEMM_RASTER_GN): N tiles per group an XCD's round walks
+ * before it moves to the next row panels.  0 = default (4: 8 x 4 super-tiles, 2 MB of weights resident per XCD), -1 = all N tiles
+ * (each activation panel crosses the fabric once, the weight panels are re-streamed per XCD), 1..64 = explicit.  Timing only. */
+int pg_tune_gemm_raster(int gn);
 int pg_vit_saturation_check(pg_vit* h, int on);
 int pg_vit_saturation_read(pg_vit* h, int64_t* count, int reset);
 /* Always-on range alarm of the fp16 operand path (no scan, no cost worth naming): the kernel that turns the residual GEMMs' row
@@ -178,6 +183,19 @@ int pg_head_forward(const float* emb, int B, int P, const float* W, const float*
 int pg_head_margin(const float* logits, int B, int C, const float* emb, int P, const float* W, float* margin, float* sens,
                    int64_t* top2, void* stream);
 
+/* Certainty of the top-1 against EVERY cell (round 5; supersedes pg_head_margin's top-1 / top-2 pair).  The embedding this path
+ * feeds the head differs from the reference's fp32 one by  |e| (beta + r):  beta a calibrated systematic part (relative to |e|,
+ * may be NULL), r of relative RMS norm eps in an unknown direction.  Per row,
+ *   tol  DEVICE (B) fp32 out = min over cells c != top1 of (logit(top1) - logit(c) - |e| g.beta) / (|e| |g| / 32),  g = W[top1] - W[c]:
+ *        the largest eps, in standard deviations of the margin change, that the reference's argmax (models/super_guessr.py:454) survives;
+ *        the cells are the kx listed in topk_idx (as pg_head_forward wrote them, descending) and, bounded with |g| <= |W[top1]| +
+ *        *wnorm_max and the list's last logit, every cell not listed.  The host calls a row certain when tol > kappa * eps.
+ *   code DEVICE (B) int32 out: the list position j >= 1 that sets tol, -1 = the cells beyond the list, -2 = bad index in the list
+ *   margin, sens DEVICE (B) fp32 out, may be NULL: pg_head_margin's pair (top-1 against top-2), for reports
+ *   wnorm_max DEVICE (1) fp32: the largest row norm of W.   Limits: 1 <= kx <= C; kx == C: nothing beyond the list. */
+int pg_head_certainty(const float* logits, int B, int C, const float* emb, int P, const float* W, const int64_t* topk_idx, int kx,
+                      const float* beta, const float* wnorm_max, float* tol, int32_t* code, float* margin, float* sens, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * ProtoRefiner prototype-distance refinement over a CSR prototype bank.
  * Replaces: models/proto_refiner.py:154-222 (the per-sample / per-candidate Python loop), :233-255
@@ -212,6 +230,34 @@ int pg_refine_forward(const pg_bank* bank, const float* q, int B, int P, const d
                       const int64_t* cand, const float* cand_prob, int k, int topk,
                       float temperature, double max_refine_km, float* scratch,
                       float* out_llh, int64_t* out_cell, int32_t* out_choice, void* stream);
+
+/* pg_refine_forward with n_eval >= topk candidates evaluated per query (topk <= n_eval <= k): the selection is pg_refine_forward's,
+ * over the first topk only; the candidates beyond take no part in it and exist for pg_refine_certainty (could one of them enter the
+ * set and win?).  scratch12: DEVICE >= B*n_eval*12 floats; per (query, candidate) on return
+ *   [0] score = -distance to the nearest prototype (-100000: empty cell)  [1] lng  [2] lat  [3] bank rows streamed
+ *   [4] distance of the runner-up prototype (+inf: none)   [5] / [6] bank rows of the nearest / runner-up prototype
+ *   [7] / [8] distance of the farthest / second farthest member of the chosen cluster (-1: none)
+ *   [9] / [10] their training-bank rows   [11] member count of the chosen prototype      ([5] [6] [9] [10] [11]: int32 bit patterns, -1 = none)
+ * out_refined DEVICE (B) int32, may be NULL: the candidate picked BEFORE the haversine veto (out_choice: after it). */
+int pg_refine_forward_ex(const pg_bank* bank, const float* q, int B, int P, const double* init_llh,
+                         const int64_t* cand, const float* cand_prob, int k, int topk, int n_eval,
+                         float temperature, double max_refine_km, float* scratch12,
+                         float* out_llh, int64_t* out_cell, int32_t* out_choice, int32_t* out_refined, void* stream);
+
+/* Certainty of the refined cell and point (round 5; reference models/proto_refiner.py:176-222).  Same error model and units as
+ * pg_head_certainty; the decisions of a row are: the winning candidate r against every other candidate of the set
+ * (s_j = log p_j - d_j / T; gradient W[c_r] - W[c_j] - (u_r - u_j) / T with u_j the unit vector from candidate j's nearest prototype to
+ * the query), every evaluated candidate outside the set (it must get into the set AND -- unless it pushes r out -- win), the cells
+ * beyond the evaluated ones (getting in counts; only when n_eval > topk, i.e. when the caller supplied candidates past the set), and
+ * for the refined and the finally chosen candidate the nearest-prototype and farthest-member picks.  The haversine veto compares
+ * two discrete points and has no margin.   W (C,1024) = the head's weights (the candidates' log-probabilities move with the
+ * embedding through them), wnorm_max as above, refined / choice as pg_refine_forward_ex wrote them.
+ *   tol DEVICE (B) fp32 out;  code DEVICE (B) int32 out: 1000 + j / 2000 + j / 2999 / 3000 + w / 4000 + w (see csrc/certainty.hip), -9 = the
+ *   winning product underflows in fp32 (uncertain), 0 = nothing can change the row.   Limits: topk <= 64, n_eval <= min(k, 96). */
+int pg_refine_certainty(const pg_bank* bank, const float* q, int B, int P, const int64_t* cand, const float* cand_prob, int k,
+                        int topk, int n_eval, const float* scratch12, const float* W, int C, const float* beta,
+                        const float* wnorm_max, float temperature, const int32_t* refined, const int32_t* choice,
+                        float* tol, int32_t* code, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * CLIP image preprocessing (the step in front of the encoder): uint8 RGB -> pixel_values.

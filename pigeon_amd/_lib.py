@@ -55,6 +55,7 @@ SIGNATURES = {
     "pg_tune_gemm_stagger": (_I, [_F]),
     "pg_tune_gemm_tail_rows": (_I, [_I]),
     "pg_tune_gemm_tail_shape": (_I, [_I, _I]),
+    "pg_tune_gemm_raster": (_I, [_I]),
     "pg_vit_saturation_check": (_I, [_P, _I]),
     "pg_vit_saturation_read": (_I, [_P, C.POINTER(_I64), _I]),
     "pg_vit_range_alarm_read": (_I, [_P, C.POINTER(_I64), _I]),
@@ -76,7 +77,10 @@ SIGNATURES = {
     "pg_smooth_labels": (_I, [_P, _I, _I, _D, _P, _P]),
     "pg_head_forward": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "pg_head_margin": (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
+    "pg_head_certainty": (_I, [_P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "pg_refine_forward": (_I, [C.POINTER(Bank), _P, _I, _I, _P, _P, _P, _I, _I, _F, _D, _P, _P, _P, _P, _P]),
+    "pg_refine_forward_ex": (_I, [C.POINTER(Bank), _P, _I, _I, _P, _P, _P, _I, _I, _I, _F, _D, _P, _P, _P, _P, _P, _P]),
+    "pg_refine_certainty": (_I, [C.POINTER(Bank), _P, _I, _I, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _F, _P, _P, _P, _P, _P]),
     "pg_op_gemm16": (_I, [_I, _P, _I64, _P, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _P, _I, _P]),
     "pg_op_gemm16_ld": (_I, [_I, _P, _I64, _P, _I64, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _P, _I, _P]),
     "pg_op_rowstat_cast": (_I, [_P, _P, _I, _P, _I64, _F, _P]),

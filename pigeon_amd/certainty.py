@@ -1,0 +1,86 @@
+"""The error model behind "is this discrete output certain to be the reference's?" (round 5; kernels: csrc/certainty.hip).
+
+The reference is fp32 end to end (models/super_guessr.py:447-459, models/proto_refiner.py:154-222).  This path's embedding of a
+sample differs from the reference's by
+
+    e_fast - e_ref  =  |e| * (beta + r)
+
+`beta` is the SYSTEMATIC part -- the same vector for every image of a given set of weights, relative to |e| (the 16-bit rounding of the
+weights is identical for every token of every image and survives the 577-token mean) -- and `r` the rest: relative RMS norm
+`rel_tol`, direction unknown.  Both are MEASURED once per set of weights by sending a few samples through the fast and the exact
+encoder (`SuperGuessr.calibrate_certainty`); the numbers never enter an output -- they only decide which samples are sent through
+the exact encoder.  A decision with margin m and gradient g then survives when
+
+    (m - |e| g.beta) / (|e| |g| / 32)  >  kappa * rel_tol
+
+(left side: what pg_head_certainty / pg_refine_certainty return per sample, the minimum over the sample's decisions; kappa: a z-score).
+The exact tier's own floor is `rel_tol_exact` (the reference's CPU result itself moves by ~1e-6 with the thread partition).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+
+class Certainty:
+    def __init__(self, kappa: float = 3.6, rel_tol: float = 1e-3, rel_tol_exact: float = 2e-5):
+        self.kappa = float(kappa)
+        self.rel_tol = float(rel_tol)                 # uncalibrated default: the contract's embedding tolerance
+        self.rel_tol_exact = float(rel_tol_exact)
+        self.drift: Optional[torch.Tensor] = None     # (1024,) fp32 on the model's device, or None
+        self.calibrated = False
+        self.stats = {}
+
+    def threshold(self, exact: bool = False) -> float:
+        return self.kappa * (self.rel_tol_exact if exact else self.rel_tol)
+
+    def drift_on(self, device) -> Optional[torch.Tensor]:
+        if self.drift is None:
+            return None
+        if self.drift.device != device:
+            self.drift = self.drift.to(device)
+        return self.drift
+
+    @torch.no_grad()
+    def calibrate(self, fast: torch.Tensor, exact: torch.Tensor, safety: float = 1.1, use_drift: bool = True) -> dict:
+        """fast, exact: (n,1024) embeddings of the same n samples (panel means for panoramas).  Sets `rel_tol` (and `drift` when a
+        systematic part explains a worthwhile share of the error), freezes them, returns the measured statistics.
+
+        The systematic part is fitted on the even samples and the residual measured on the ODD ones (out of sample, so that
+        `rel_tol` is not flattered by the fit); the vector finally kept is the mean over all samples."""
+        rel = (fast.float() - exact.float()) / exact.float().norm(dim=1, keepdim=True).clamp_min(1e-30)
+        n = int(rel.shape[0])
+        if n == 0:
+            raise ValueError('calibrate: no samples')
+        total = float(rel.norm(dim=1).pow(2).mean().sqrt())
+        st = {'samples': n, 'fast_vs_exact_rms': total, 'drift_norm': 0.0, 'residual_rms': total, 'drift_used': False}
+        drift = None
+        if use_drift and n >= 8:
+            fit, held = rel[0::2], rel[1::2]
+            beta_half = fit.mean(dim=0)
+            resid = float((held - beta_half).norm(dim=1).pow(2).mean().sqrt())
+            st['residual_rms'] = resid
+            st['drift_norm'] = float(rel.mean(dim=0).norm())
+            if resid < 0.9 * total:
+                drift = rel.mean(dim=0).contiguous()
+                st['drift_used'] = True
+        eps = st['residual_rms'] if drift is not None else total
+        self.rel_tol = max(safety * eps, 4.0 * self.rel_tol_exact)
+        self.drift = drift
+        self.calibrated = True
+        st['rel_tol'] = self.rel_tol
+        st['kappa'] = self.kappa
+        self.stats = st
+        return st
+
+    def describe(self) -> str:
+        s = self.stats
+        how = (f"calibrated on {s.get('samples')} samples through the fast and the exact encoder: total relative error RMS "
+               f"{s.get('fast_vs_exact_rms', 0):.3g}, systematic part |beta| {s.get('drift_norm', 0):.3g} "
+               f"({'used' if s.get('drift_used') else 'not used'}), residual RMS (out of sample) {s.get('residual_rms', 0):.3g}"
+               if self.calibrated else "uncalibrated: the contract's embedding tolerance")
+        return (f"a sample is certain when every discrete decision downstream of its embedding (top-1 cell against every other cell; "
+                f"with a refiner: winning candidate, candidate-set boundary, nearest prototype, farthest member) keeps "
+                f"(margin - |e| grad.beta) / (|e| |grad| / 32) > kappa x rel_tol = {self.kappa:g} x {self.rel_tol:.3g} "
+                f"(pg_head_certainty / pg_refine_certainty); {how}")

@@ -52,7 +52,7 @@ class HipCLIPVisionModel(torch.nn.Module):
         self._enc_device = None
         self._max_chunk = max_chunk
         # exact mode (`embed_precise`): the encoder additionally packs the split-fp16 weight copy (3x the 16-bit weight memory)
-        self._precise = os.environ.get("PIGEON_EXACT_TOP1", "0") not in ("", "0")
+        self._precise = False                             # SuperGuessr(exact_top1) / enable_precise(True) switch it on
         self._dummy = torch.nn.Parameter(torch.zeros(1), requires_grad=False)   # lets .to()/is_cuda work
 
     # ---- nn.Module protocol over the plain weight dict ----

@@ -80,6 +80,19 @@ int pg_num_cus() {
 #define PG_DEFAULT_GEMM_TAIL_MIN_K 2048
 #define PG_DEFAULT_GEMM_TAIL_MIN_N 4096
 static int g_tail_rows = -1, g_tail_min_k = -1, g_tail_min_n = -1;
+// every pg_tune_* call bumps the epoch: the knobs are baked into captured launches, so a hipGraph of an older epoch is re-captured
+static unsigned long long g_tune_epoch = 1;
+unsigned long long pg_tune_epoch() { return g_tune_epoch; }
+static int g_raster_gn = -2;
+int pg_gemm_raster_gn() {
+    if (g_raster_gn == -2) { const char* e = getenv("PIGEON_GEMM_RASTER_GN"); g_raster_gn = e ? atoi(e) : 0; if (g_raster_gn < -1) g_raster_gn = 0; }
+    return g_raster_gn;
+}
+extern "C" int pg_tune_gemm_raster(int gn) {
+    if (gn < -1 || gn > 64) { pg_set_error("tune_gemm_raster: gn must be -1 (all N tiles), 0 (default) or 1..64"); return PG_EINVAL; }
+    g_raster_gn = gn; ++g_tune_epoch;
+    return PG_OK;
+}
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     const int v = e ? atoi(e) : dflt;
@@ -90,12 +103,12 @@ int pg_gemm_tail_min_k() { if (g_tail_min_k < 0) g_tail_min_k = env_int("PIGEON_
 int pg_gemm_tail_min_n() { if (g_tail_min_n < 0) g_tail_min_n = env_int("PIGEON_GEMM_TAIL_MIN_N", PG_DEFAULT_GEMM_TAIL_MIN_N); return g_tail_min_n; }
 extern "C" int pg_tune_gemm_tail_rows(int rows) {
     if (rows < 0 || rows > (1 << 20)) { pg_set_error("tune_gemm_tail_rows: rows must be in [0, 2^20]"); return PG_EINVAL; }
-    g_tail_rows = rows;
+    g_tail_rows = rows; ++g_tune_epoch;
     return PG_OK;
 }
 extern "C" int pg_tune_gemm_tail_shape(int min_k, int min_n) {
     if (min_k < 0 || min_n < 0) { pg_set_error("tune_gemm_tail_shape: negative threshold"); return PG_EINVAL; }
-    g_tail_min_k = min_k; g_tail_min_n = min_n;
+    g_tail_min_k = min_k; g_tail_min_n = min_n; ++g_tune_epoch;
     return PG_OK;
 }
 static float g_stagger = -1.f;
@@ -109,7 +122,7 @@ float pg_gemm_stagger_fraction() {
 }
 extern "C" int pg_tune_gemm_stagger(float fraction) {
     if (!(fraction >= 0.f && fraction <= 4.f)) { pg_set_error("tune_gemm_stagger: fraction must be in [0, 4]"); return PG_EINVAL; }
-    g_stagger = fraction;
+    g_stagger = fraction; ++g_tune_epoch;
     return PG_OK;
 }
 
@@ -163,7 +176,7 @@ struct pg_vit {
     // key (the first runs eagerly: it also sets the kernels' LDS attributes, which is not a stream operation), on an internal
     // stream (torch's current stream is usually the legacy default stream, which cannot be captured), launched on the caller's.
     // Off while profiling events / the saturation scan / the multi-stream mode are on, and with env PIGEON_VIT_GRAPH=0.
-    struct GraphEntry { const void* ws; int n; int seen; hipGraph_t graph; hipGraphExec_t exec; unsigned long long last_use; };
+    struct GraphEntry { const void* ws; int n; int seen; hipGraph_t graph; hipGraphExec_t exec; unsigned long long last_use, epoch; hipEvent_t done; };
     std::vector<GraphEntry> graphs;
     bool use_graph = true;
     hipStream_t capture_stream = nullptr;
@@ -555,14 +568,17 @@ static int vit_forward_body(pg_vit* h, int n, char* ws, hipStream_t s) {
     return PG_OK;
 }
 
+// An exec may still be running on the caller's stream when its entry is evicted or found stale: wait for the event recorded behind
+// its last launch before destroying it.
 static void graph_entry_free(pg_vit::GraphEntry& e) {
+    if (e.done) { (void)hipEventSynchronize(e.done); (void)hipEventDestroy(e.done); }
     if (e.exec) (void)hipGraphExecDestroy(e.exec);
     if (e.graph) (void)hipGraphDestroy(e.graph);
-    e.exec = nullptr; e.graph = nullptr;
+    e.exec = nullptr; e.graph = nullptr; e.done = nullptr;
 }
 // Run the body through its captured graph if there is one for (ws, n); capture it at the second sight of the key; else eagerly.
 static int vit_forward_body_graphed(pg_vit* h, int n, char* ws, hipStream_t s) {
-    const bool ok = h->use_graph && !h->prof && !h->sat_check;
+    const bool ok = h->use_graph && !h->prof && !h->sat_check && h->streams == 1;
     if (!ok) return vit_forward_body(h, n, ws, s);
     pg_vit::GraphEntry* ent = nullptr;
     for (auto& e : h->graphs) if (e.ws == ws && e.n == n) { ent = &e; break; }
@@ -573,12 +589,17 @@ static int vit_forward_body_graphed(pg_vit* h, int n, char* ws, hipStream_t s) {
             graph_entry_free(h->graphs[lru]);
             h->graphs.erase(h->graphs.begin() + lru);
         }
-        h->graphs.push_back({ws, n, 0, nullptr, nullptr, 0});
+        h->graphs.push_back({ws, n, 0, nullptr, nullptr, 0, pg_tune_epoch(), nullptr});
         ent = &h->graphs.back();
     }
     ent->last_use = ++h->graph_clock;
+    if (ent->exec && ent->epoch != pg_tune_epoch()) {         // a pg_tune_* call since the capture: the baked-in knobs are stale
+        graph_entry_free(*ent);
+        ent->seen = 1;                                         // kernel attributes are set already: capture right away
+    }
     if (ent->exec) {
         PG_HIP(hipGraphLaunch(ent->exec, s));
+        if (ent->done) (void)hipEventRecord(ent->done, s);
         ++h->graph_replays;
         return PG_OK;
     }
@@ -598,9 +619,11 @@ static int vit_forward_body_graphed(pg_vit* h, int n, char* ws, hipStream_t s) {
     hipGraphExec_t exec = nullptr;
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     if (e != hipSuccess || !exec) { (void)hipGetLastError(); (void)hipGraphDestroy(graph); h->use_graph = false; return vit_forward_body(h, n, ws, s); }
-    ent->graph = graph; ent->exec = exec;
+    ent->graph = graph; ent->exec = exec; ent->epoch = pg_tune_epoch();
+    if (!ent->done) (void)hipEventCreateWithFlags(&ent->done, hipEventDisableTiming);
     ++h->graph_captures;
     PG_HIP(hipGraphLaunch(exec, s));
+    if (ent->done) (void)hipEventRecord(ent->done, s);
     ++h->graph_replays;
     return PG_OK;
 }
@@ -761,12 +784,16 @@ extern "C" int pg_vit_range_alarm_read(pg_vit* h, int64_t* rows, int reset) {
     if (!h || !rows) { pg_set_error("range_alarm_read: null argument"); return PG_EINVAL; }
     *rows = 0;
     if (!h->range_alarm) return PG_OK;                       // bf16 operands, or the separate-LayerNorm chain: no alarm
+    int cur = 0;
+    PG_HIP(hipGetDevice(&cur));
     PG_HIP(hipSetDevice(h->device));                         // the counter lives on the handle's device, whatever is current
-    PG_HIP(hipDeviceSynchronize());
+    hipError_t e = hipDeviceSynchronize();
     unsigned long long v = 0;
-    PG_HIP(hipMemcpy(&v, h->range_alarm, sizeof(v), hipMemcpyDeviceToHost));
+    if (e == hipSuccess) e = hipMemcpy(&v, h->range_alarm, sizeof(v), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && reset) e = hipMemset(h->range_alarm, 0, sizeof(v));
+    (void)hipSetDevice(cur);                                 // ... and the caller's current device is put back
+    if (e != hipSuccess) { pg_set_error("range_alarm_read: %s", hipGetErrorString(e)); return PG_EHIP; }
     *rows = (int64_t)v;
-    if (reset) PG_HIP(hipMemset(h->range_alarm, 0, sizeof(v)));
     return PG_OK;
 }
 
@@ -785,12 +812,16 @@ extern "C" int pg_vit_saturation_read(pg_vit* h, int64_t* count, int reset) {
     if (!h || !count) { pg_set_error("saturation_read: null argument"); return PG_EINVAL; }
     *count = 0;
     if (!h->sat_counter) return PG_OK;
+    int cur = 0;
+    PG_HIP(hipGetDevice(&cur));
     PG_HIP(hipSetDevice(h->device));
-    PG_HIP(hipDeviceSynchronize());
+    hipError_t e = hipDeviceSynchronize();
     unsigned long long v = 0;
-    PG_HIP(hipMemcpy(&v, h->sat_counter, sizeof(v), hipMemcpyDeviceToHost));
+    if (e == hipSuccess) e = hipMemcpy(&v, h->sat_counter, sizeof(v), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && reset) e = hipMemset(h->sat_counter, 0, sizeof(v));
+    (void)hipSetDevice(cur);
+    if (e != hipSuccess) { pg_set_error("saturation_read: %s", hipGetErrorString(e)); return PG_EHIP; }
     *count = (int64_t)v;
-    if (reset) PG_HIP(hipMemset(h->sat_counter, 0, sizeof(v)));
     return PG_OK;
 }
 

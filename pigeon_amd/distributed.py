@@ -185,20 +185,40 @@ def init_from_env(backend: Optional[str] = None, set_device: bool = True, join_t
 def _await_all_ranks(rank: int, world: int, timeout_s: float) -> None:
     """Bounded wait that NAMES who is missing, in front of torch's own rendezvous.  torch's env:// rendezvous just blocks (30
     minutes by default) when a rank never shows up -- on an 8-GPU launch the useful message is "rank(s) [5] did not join".
-    One node (the contract of this path: one process per GPU of ONE node): every rank drops a file `rank_<r>` into a directory
-    named after MASTER_PORT (one rendezvous per port at a time) and waits until all `world` files are there or `timeout_s` is over.
-    Files are removed at exit; a stale file of a killed run only weakens the check.  The check must never break a launch that
+    ONE NODE ONLY (the contract of this path: one process per GPU of one node): the check runs when WORLD_SIZE equals
+    LOCAL_WORLD_SIZE (or LOCAL_WORLD_SIZE is unset); on a multi-node launch the ranks of the other nodes can never show up in this
+    node's /tmp, so it is skipped.  Every rank drops a file `rank_<r>` into a per-user directory named after MASTER_PORT (mode 0700,
+    owned by this uid, not a symlink; the file is created with O_EXCL | O_NOFOLLOW, so nothing a stranger planted there is followed
+    or truncated) and waits until all `world` files are there or `timeout_s` is over.  Files are removed at exit and on SIGTERM (what
+    torchrun and bench.py's launcher send); a stale file of a killed run only weakens the check.  It must never break a launch that
     would have worked: any filesystem trouble skips it, and it only RAISES when it has seen at least one other rank's file (proof
     that the ranks share the directory) -- a rank that sees nobody (ranks in separate containers / TMPDIRs) prints a note and lets
     torch's rendezvous do its own waiting."""
     import atexit
+    import signal
     import tempfile
     import time
+    local_world = os.environ.get("LOCAL_WORLD_SIZE")
+    if local_world is not None and local_world.isdigit() and int(local_world) != world:
+        return                                                 # multi-node: the other nodes' ranks are not visible here
     try:
-        d = os.path.join(tempfile.gettempdir(), f"pigeon_join_{os.environ.get('MASTER_PORT', '0')}")
-        os.makedirs(d, exist_ok=True)
+        uid = os.getuid()
+        d = os.path.join(tempfile.gettempdir(), f"pigeon_join_{uid}_{os.environ.get('MASTER_PORT', '0')}")
+        try:
+            os.mkdir(d, 0o700)
+        except FileExistsError:
+            pass
+        st = os.lstat(d)
+        import stat as _stat
+        if not _stat.S_ISDIR(st.st_mode) or st.st_uid != uid or (st.st_mode & 0o077):
+            return                                             # not ours / a symlink / open to others: do not touch it
         mine = os.path.join(d, f"rank_{rank}")
-        with open(mine, "w") as f:
+        try:
+            os.unlink(mine)                                    # a stale file of an earlier run of this user on this port
+        except FileNotFoundError:
+            pass
+        fd = os.open(mine, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+        with os.fdopen(fd, "w") as f:
             f.write(str(os.getpid()))
 
         def _cleanup():
@@ -208,6 +228,16 @@ def _await_all_ranks(rank: int, world: int, timeout_s: float) -> None:
             except OSError:
                 pass
         atexit.register(_cleanup)
+        try:                                                   # SIGTERM skips atexit: remove the file, then die as before
+            prev = signal.getsignal(signal.SIGTERM)
+            if prev in (signal.SIG_DFL, None):
+                def _on_term(signum, frame):
+                    _cleanup()
+                    signal.signal(signal.SIGTERM, signal.SIG_DFL)
+                    os.kill(os.getpid(), signal.SIGTERM)
+                signal.signal(signal.SIGTERM, _on_term)
+        except (ValueError, OSError):                          # not the main thread
+            pass
     except OSError:
         return
     t_end = time.time() + timeout_s

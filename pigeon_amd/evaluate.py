@@ -61,6 +61,46 @@ def compute_geoguessr_metrics(results) -> Dict[str, float]:
     return eval_dict
 
 
+@torch.no_grad()
+def certain_forward(model: SuperGuessr, refiner: Optional[ProtoRefiner], pixel_values=None, embedding=None, labels=None,
+                    labels_clf=None, **_unused):
+    """`model(**data)` followed by `refiner(...)` with the reference's outputs guaranteed (round 5): one fast pass, the tolerance of
+    every discrete decision downstream of the embedding -- the top-1 cell (pg_head_certainty) and, with a refiner, the winning
+    candidate, the candidate-set boundary, the nearest prototype and the farthest member (pg_refine_certainty) -- and ONE exact
+    re-encode (pg_vit_forward_precise) of the union of the samples that are not certain, after which their head outputs are
+    recomputed.  One host synchronisation (the uncertain set is data dependent).  The refinement itself is left to the caller (it runs
+    on the corrected embeddings / candidates: `evaluate_model` right away, `PanoramaPipeline.step` after its all-gather).
+    Returns (outputs as `model.forward` returns them, info) with info = dict(certain (B,) bool: every output of the sample is the
+    reference's; reencoded (n,) int64; head_tol, refine_tol (B,) f32 or None; boundary_checked)."""
+    st = model.encode_head(pixel_values, embedding)
+    info = dict(head_tol=st['tol'], refine_tol=None, refine_code=None, boundary_checked=None)
+    can_fix = model.exact_top1 and st['pixel_values'] is not None
+    flag = ~st['certain']
+    k = model.num_candidates
+    W = model.cell_layer.weight.data
+    if refiner is not None:
+        _, _, rtol, rcode, checked = refiner.forward_certain(st['embedding'], st['preds_LLH'], st['topk_indices'], st['topk_values'],
+                                                            W, model.wnorm_max(), model.certainty.drift_on(W.device))
+        info.update(refine_tol=rtol, refine_code=rcode, boundary_checked=checked)
+        flag = flag | ~(rtol > model.certainty.threshold())
+    if can_fix:
+        idx = torch.nonzero(flag).flatten()                                       # the step's one host synchronisation
+        model.reencode_rows(st, idx)
+        if refiner is not None and idx.numel():
+            # the re-encoded samples, judged again at the exact tier's floor (no systematic part there)
+            _, _, rt2, rc2, _ = refiner.forward_certain(st['embedding'][idx], st['preds_LLH'][idx], st['topk_indices'][idx],
+                                                        st['topk_values'][idx], W, model.wnorm_max(), None)
+            info['refine_tol'][idx], info['refine_code'][idx] = rt2, rc2
+            flag[idx] = ~st['certain'][idx] | ~(rt2 > model.certainty.threshold(exact=True))
+        elif idx.numel():
+            flag[idx] = ~st['certain'][idx]
+    info['certain'] = ~flag
+    info['reencoded'] = st['reencoded']
+    out = model.package(st, labels, labels_clf)
+    model.last_certain = info['certain']
+    return out, info
+
+
 def evaluate_model(model: SuperGuessr, dataset, metrics: Optional[Callable] = None, train_args=None,
                    refiner: Optional[ProtoRefiner] = None, yfcc: bool = False, writer=None, step: int = 0,
                    batch_size: Optional[int] = None, num_workers: int = 0):
@@ -84,7 +124,8 @@ def evaluate_model(model: SuperGuessr, dataset, metrics: Optional[Callable] = No
     n_seen = 0
     with torch.no_grad():
         for data in eval_data:
-            outputs = model(**data)                                               # :80
+            # :80 `model(**data)` -- through certain_forward, which also looks at what the refiner will consume
+            outputs, _info = certain_forward(model, refiner, **data)
             if outputs.loss_clf is not None:
                 combined_loss += float(outputs.loss_clf) * len(data)              # :81-82 (`len(data)` as the reference)
             if refiner is not None:                                               # :98-103
@@ -98,15 +139,14 @@ def evaluate_model(model: SuperGuessr, dataset, metrics: Optional[Callable] = No
             top5 = outputs.top5_geocells
             combined_top5_cells.append(top5.indices.cpu().detach().numpy())
             combined_top5_probs.append(top5.values.cpu().detach().numpy())
-            if getattr(model, 'last_certain', None) is not None:                  # round 4: certainty of each geocell top-1
-                combined_certain.append(model.last_certain.cpu().numpy())
+            combined_certain.append(_info['certain'].cpu().numpy())            # every output of the sample is the reference's
             n_seen += outputs.preds_geocell.shape[0]
     preds = np.concatenate(combined_preds, axis=0)
     preds_geocells = np.concatenate(combined_geocell_preds, axis=0)
     top5_geocells = np.concatenate(combined_top5_cells, axis=0)
     results = dict(preds=preds, preds_geocells=preds_geocells, top5_geocells=top5_geocells,
                    top5_probs=np.concatenate(combined_top5_probs, axis=0), loss_clf=combined_loss / max(n_seen, 1))
-    if combined_certain:        # beyond the reference's keys: which geocell predictions are certain to be the fp32 argmax
+    if combined_certain:        # beyond the reference's keys: which samples' outputs are certain to be the fp32 reference's
         results['geocell_certain'] = np.concatenate(combined_certain, axis=0)
     if metrics is not None:                                                       # :122-140
         labels_lla, labels_cell = dataset['labels'], dataset['labels_clf']
@@ -215,15 +255,50 @@ class PanoramaPipeline:
         self.model, self.refiner = model, refiner
         self.comm = comm or Communicator()
         self.refine_events = None        # set to a list to collect (start, end) stream events around the refinement launches
+        self.last_info = None            # certain_forward's info of the last step (certain, reencoded, tolerances)
+        self.split_marks = None          # set to a list to collect five time stamps per step (see split_ms): compute vs gather(-wait)
+
+    def _mark(self, marks, device):
+        """A time stamp on the device's stream (a HIP event) or, for host tensors, the host clock."""
+        if marks is None:
+            return
+        if device.type == 'cuda':
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append(ev)
+        else:
+            import time
+            marks.append(time.perf_counter())
+
+    @staticmethod
+    def split_ms(marks):
+        """(compute ms, gather ms) of one step's five marks: [start, before gather 1, after it, before gather 2, end].  On the
+        device the gather spans include the time this rank WAITS for the slowest rank to arrive at the collective."""
+        if isinstance(marks[0], float):
+            d = [(b - a) * 1e3 for a, b in zip(marks[:-1], marks[1:])]
+        else:
+            d = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
+        return d[0] + d[2], d[1] + d[3]
 
     @torch.no_grad()
     def step(self, pixel_values: torch.Tensor, index: Optional[torch.Tensor] = None):
-        out = self.model(pixel_values=pixel_values, labels_clf=None)
+        marks = [] if self.split_marks is not None else None
+        self._mark(marks, pixel_values.device)
+        if hasattr(self.model, 'encode_head'):
+            # fast pass, tolerance of every decision the head AND the refinement below will take, one exact re-encode of the
+            # samples that are not certain (model.exact_top1; off: the certainty is still reported)
+            out, self.last_info = certain_forward(self.model, self.refiner, pixel_values=pixel_values)
+        else:
+            out, self.last_info = self.model(pixel_values=pixel_values, labels_clf=None), None     # stub models (bench.py --dry-run)
         B = out.preds_geocell.shape[0]
         if index is None:
             index = torch.arange(B, device=out.embedding.device) + self.comm.rank * B
+        self._mark(marks, pixel_values.device)
+        # The gather BEFORE the refinement is what `north_star` / the reference's accelerator.gather ask for, not a data dependency of
+        # this step: every rank refines exactly the rows it produced (its own slice below), against its own replica of the bank.
         emb, topi, topv, llh, idx = self.comm.gather_many([out.embedding, out.top5_geocells.indices,
                                                            out.top5_geocells.values, out.preds_LLH, index.to(out.embedding.device)])
+        self._mark(marks, pixel_values.device)
         res = dict(embedding=emb, index=idx, preds_geocell=topi[:, 0], preds_LLH=llh,
                    topk_indices=topi, topk_values=topv)
         if self.refiner is not None:
@@ -237,5 +312,11 @@ class PanoramaPipeline:
             if self.refine_events is not None:
                 ev[1].record()
                 self.refine_events.append(ev)
+            self._mark(marks, pixel_values.device)
             res['refined_LLH'], res['refined_geocell'] = self.comm.gather_many([ref_llh, ref_cell])
+        else:
+            self._mark(marks, pixel_values.device)
+        self._mark(marks, pixel_values.device)
+        if marks is not None:
+            self.split_marks.append(marks)
         return res

@@ -471,6 +471,30 @@ def head_margin(logits: torch.Tensor, emb: torch.Tensor, W: torch.Tensor):
     return margin, sens, top2
 
 
+def head_certainty(logits: torch.Tensor, emb: torch.Tensor, W: torch.Tensor, topk_idx: torch.Tensor,
+                   drift: Optional[torch.Tensor], wnorm_max: torch.Tensor):
+    """pg_head_certainty: tolerance of the top-1 against every cell.  logits (B,C) as written by head_forward, emb (B,P,1024) or
+    (B,1024), topk_idx (B,kx) int64 from the same head_forward call, drift (1024,) fp32 or None, wnorm_max (1,) fp32 = the largest
+    row norm of W.  Returns (tol (B,) f32, code (B,) i32, margin (B,) f32, sens (B,) f32)."""
+    _dev(logits, torch.float32); _dev(emb, torch.float32); _dev(W, torch.float32); _dev(topk_idx, torch.int64)
+    _dev(wnorm_max, torch.float32)
+    B, Cn = logits.shape
+    P = emb.shape[1] if emb.dim() == 3 else 1
+    _shape(emb, "emb", *((B, P, HIDDEN) if emb.dim() == 3 else (B, HIDDEN)))
+    _shape(W, "W", Cn, HIDDEN); _shape(topk_idx, "topk_idx", B, None); _shape(wnorm_max, "wnorm_max", 1)
+    kx = topk_idx.shape[1]
+    if drift is not None:
+        _dev(drift, torch.float32); _shape(drift, "drift", HIDDEN)
+    dev = logits.device
+    tol = torch.empty((B,), dtype=torch.float32, device=dev)
+    code = torch.empty((B,), dtype=torch.int32, device=dev)
+    margin = torch.empty((B,), dtype=torch.float32, device=dev)
+    sens = torch.empty((B,), dtype=torch.float32, device=dev)
+    check(load().pg_head_certainty(_p(logits), B, Cn, _p(emb), P, _p(W), _p(topk_idx), kx, _p(drift), _p(wnorm_max), _p(tol), _p(code),
+                                   _p(margin), _p(sens), _stream()), "pg_head_certainty")
+    return tol, code, margin, sens
+
+
 # ----------------------------------------------------------------------------------------- exact-mode building blocks
 def x3_split(x: torch.Tensor, gelu: bool = False) -> torch.Tensor:
     """fp32 (rows,cols) -> fp16 triple (rows, 3 cols) = [hi | lo | hi 2^-8]; gelu: through QuickGELU first."""
@@ -561,3 +585,63 @@ def refine_forward(bank: DeviceBank, q: torch.Tensor, init_llh: torch.Tensor, ca
     if return_scratch:
         return out_llh, out_cell, out_choice, scratch
     return out_llh, out_cell, out_choice
+
+
+def refine_forward_ex(bank: DeviceBank, q: torch.Tensor, init_llh: torch.Tensor, cand: torch.Tensor,
+                      cand_prob: Optional[torch.Tensor], topk: int, n_eval: int, temperature: float, max_refine_km: float):
+    """pg_refine_forward_ex: refine_forward's selection over the first `topk` candidates, with `n_eval` >= topk candidates evaluated and
+    the 12-float records pg_refine_certainty needs.  Returns (preds_LLH, preds_geocell, choice, refined, scratch12 (B,n_eval,12))."""
+    _dev(q, torch.float32); _dev(init_llh, torch.float64); _dev(cand, torch.int64)
+    if cand_prob is not None:
+        _dev(cand_prob, torch.float32)
+    if q.dim() not in (2, 3) or cand.dim() != 2:
+        raise _lib.PigeonHipError(f"refine: q must be (B,{HIDDEN}) or (B,P,{HIDDEN}) and cand (B,k), got {tuple(q.shape)} / {tuple(cand.shape)}")
+    B = q.shape[0]
+    P = q.shape[1] if q.dim() == 3 else 1
+    k = cand.shape[1]
+    _shape(q, "q", *((B, P, HIDDEN) if q.dim() == 3 else (B, HIDDEN)))
+    _shape(init_llh, "init_llh", B, 2); _shape(cand, "cand", B, k)
+    if cand_prob is not None:
+        _shape(cand_prob, "cand_prob", B, k)
+    if not 1 <= int(topk) <= int(n_eval) <= k:
+        raise _lib.PigeonHipError(f"refine_ex: topk = {topk}, n_eval = {n_eval} of k = {k} candidates")
+    dev = q.device
+    scratch = torch.empty((B, n_eval, 12), dtype=torch.float32, device=dev)
+    out_llh = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    out_cell = torch.empty((B,), dtype=torch.int64, device=dev)
+    out_choice = torch.empty((B,), dtype=torch.int32, device=dev)
+    out_refined = torch.empty((B,), dtype=torch.int32, device=dev)
+    check(load().pg_refine_forward_ex(C.byref(bank.struct), _p(q), B, P, _p(init_llh), _p(cand), _p(cand_prob), k, int(topk), int(n_eval),
+                                      float(temperature), float(max_refine_km), _p(scratch), _p(out_llh), _p(out_cell),
+                                      _p(out_choice), _p(out_refined), _stream()), "pg_refine_forward_ex")
+    return out_llh, out_cell, out_choice, out_refined, scratch
+
+
+def refine_certainty(bank: DeviceBank, q: torch.Tensor, cand: torch.Tensor, cand_prob: Optional[torch.Tensor], topk: int,
+                     scratch12: torch.Tensor, W: torch.Tensor, drift: Optional[torch.Tensor], wnorm_max: torch.Tensor,
+                     temperature: float, refined: torch.Tensor, choice: torch.Tensor):
+    """pg_refine_certainty over the records refine_forward_ex left.  Returns (tol (B,) f32, code (B,) i32)."""
+    _dev(q, torch.float32); _dev(cand, torch.int64); _dev(scratch12, torch.float32); _dev(W, torch.float32)
+    _dev(wnorm_max, torch.float32); _dev(refined, torch.int32); _dev(choice, torch.int32)
+    B = q.shape[0]
+    P = q.shape[1] if q.dim() == 3 else 1
+    k = cand.shape[1]
+    n_eval = scratch12.shape[1]
+    _shape(q, "q", *((B, P, HIDDEN) if q.dim() == 3 else (B, HIDDEN)))
+    _shape(cand, "cand", B, k); _shape(scratch12, "scratch12", B, n_eval, 12); _shape(W, "W", None, HIDDEN)
+    _shape(refined, "refined", B); _shape(choice, "choice", B); _shape(wnorm_max, "wnorm_max", 1)
+    if cand_prob is not None:
+        _dev(cand_prob, torch.float32); _shape(cand_prob, "cand_prob", B, k)
+    if drift is not None:
+        _dev(drift, torch.float32); _shape(drift, "drift", HIDDEN)
+    tol = torch.empty((B,), dtype=torch.float32, device=q.device)
+    code = torch.empty((B,), dtype=torch.int32, device=q.device)
+    check(load().pg_refine_certainty(C.byref(bank.struct), _p(q), B, P, _p(cand), _p(cand_prob), k, int(topk), int(n_eval), _p(scratch12),
+                                     _p(W), W.shape[0], _p(drift), _p(wnorm_max), float(temperature), _p(refined), _p(choice), _p(tol),
+                                     _p(code), _stream()), "pg_refine_certainty")
+    return tol, code
+
+
+def tune_gemm_raster(gn: int) -> None:
+    """pg_tune_gemm_raster: N tiles per raster group of the 384 x 256 GEMM (0 default, -1 all).  Timing only."""
+    check(load().pg_tune_gemm_raster(int(gn)), "pg_tune_gemm_raster")

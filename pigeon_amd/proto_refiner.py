@@ -283,3 +283,33 @@ class ProtoRefiner(nn.Module):
                 print(f'Changed geocell predictions of {perc_changed * 100:.1f} % of guesses.')
         loss = 0 if self.training else None
         return loss, preds_LLH, preds_geocell
+
+    # candidates evaluated beyond `topk` by the certainty pass (could one of them enter the set and win?)
+    EXTRA_EVAL = 4
+
+    @torch.no_grad()
+    def forward_certain(self, embedding: Tensor, initial_preds: Tensor, candidate_cells: Tensor, candidate_probs: Tensor,
+                        head_weight: Tensor, wnorm_max: Tensor, drift: Tensor = None):
+        """`forward` plus the TOLERANCE of its discrete outputs against an embedding error (round 5; error model:
+        pigeon_amd/certainty.py, kernels: pg_refine_forward_ex + pg_refine_certainty).  `candidate_cells` / `candidate_probs` may hold
+        more than `topk` candidates (SuperGuessr computes `num_candidates + 4`): up to 4 of those beyond `topk` are evaluated too --
+        never selected -- so that the pass can tell whether a cell just outside the set could get in and win; with none beyond
+        `topk` that question stays open (`boundary_checked` False).  `head_weight` (C,1024) is the geocell head's weight matrix: the
+        candidates' probabilities move with the embedding through it.
+        Returns (preds_LLH (B,2) f32, preds_geocell (B,) i64, tol (B,) f32, code (B,) i32, boundary_checked)."""
+        assert self.topk <= candidate_cells.size(1)
+        dev = embedding.device
+        if dev.type != 'cuda':
+            raise RuntimeError('pigeon_amd.ProtoRefiner runs on the GPU only (no CPU fallback)')
+        q = embedding.to(dev, torch.float32).contiguous()
+        init = initial_preds.to(dev, torch.float64).contiguous()
+        cand = candidate_cells.to(dev, torch.int64).contiguous()
+        probs = None if candidate_probs is None else candidate_probs.to(dev, torch.float32).contiguous()
+        n_eval = min(cand.shape[1], self.topk + self.EXTRA_EVAL)
+        bank = self._device_bank(dev)
+        T = self._temperature_value()
+        llh, cell, choice, refined, scratch = hip_ops.refine_forward_ex(bank, q, init, cand, probs, self.topk, n_eval, T,
+                                                                       float(self.max_refinement))
+        tol, code = hip_ops.refine_certainty(bank, q, cand, probs, self.topk, scratch, head_weight, drift, wnorm_max, T, refined, choice)
+        self.last_scratch = scratch[:, :self.topk, :4]
+        return llh, cell, tol, code, n_eval > self.topk

@@ -67,7 +67,13 @@ def predict_panorama(views: Sequence, model, refiner=None, preprocess: Optional[
     px = preprocess(list(views))                                   # (4,3,336,336), CLIP-normalised
     px = px.reshape(1, 12, px.shape[-2], px.shape[-1])             # one panorama, panels along the channel axis (:386-393)
     with torch.no_grad():
-        pred_llh, topk, embedding = model(pixel_values=px)         # serving tuple, [lng, lat] order (:455, :462-466)
+        if hasattr(model, "encode_head"):
+            # pigeon_amd.SuperGuessr: the same call with the certainty of every discrete output (top-1 cell AND what the refiner below
+            # will pick) checked, and the panorama re-encoded in the exact mode if it is not certain (exact_top1, the default)
+            from .evaluate import certain_forward
+            (pred_llh, topk, embedding), info = certain_forward(model, refiner, pixel_values=px)
+        else:
+            pred_llh, topk, embedding = model(pixel_values=px)     # serving tuple, [lng, lat] order (:455, :462-466)
         if refiner is not None:
             _, pred_llh, _ = refiner(embedding=embedding, initial_preds=pred_llh, candidate_cells=topk.indices,
                                      candidate_probs=topk.values)
@@ -125,8 +131,9 @@ def main(argv=None):
     ap.add_argument("--protos", default=None)
     ap.add_argument("--dataset", default=None)
     ap.add_argument("--layers", type=int, default=24)
-    ap.add_argument("--exact-top1", action="store_true", help="re-encode panoramas whose top-1 margin is inside the 16-bit path's error "
-                                                                  "band in the encoder's exact mode (the reference's fp32 argmax)")
+    ap.add_argument("--no-exact-top1", dest="exact_top1", action="store_false",
+                    help="switch the exact mode off (default on: panoramas whose discrete outputs are inside the 16-bit path's error band "
+                         "are re-encoded in the encoder's exact mode, so that the answer is the reference's fp32 one)")
     ap.add_argument("--host", default="127.0.0.1")
     ap.add_argument("--port", type=int, default=5000)
     args = ap.parse_args(argv)

@@ -17,10 +17,15 @@ from torch import nn, Tensor
 from torch.nn.parameter import Parameter
 
 from . import hip_ops
+from .certainty import Certainty
 from .geo_utils import haversine_matrix, smooth_labels
 from .clip_embedder import HipCLIPVisionModel
 from .config import CLIP_EMBED_DIM, GEOCELL_PATH, GEOCELL_PATH_YFCC
 from .utils import ModelOutput, TopK, resolve_name
+
+
+# candidates the head computes beyond `num_candidates`: never exposed, they tell the certainty pass how far the next cells are
+EXTRA_CANDIDATES = 4
 
 
 class SuperGuessr(nn.Module):
@@ -36,32 +41,33 @@ class SuperGuessr(nn.Module):
         One extra keyword, `geocell_path`, overrides config.GEOCELL_PATH(_YFCC) (the reference hard-wires the
         path through its config module, :87-88).
 
-        Certainty of the top-1 (round 4).  The reference's `torch.argmax(geocell_probs)` (:454) is fp32 end to end; this path's
-        embeddings carry the rounding of 16-bit MFMA operands (2.7e-4 relative on default-init weights, 6e-4 on the high-gain
-        `pipeline24_spread` tower), so a panorama whose top-1 / top-2 logit margin is smaller than that error moves the logits may
-        come out with the runner-up cell.  After every forward the model exposes, per sample (ModelOutput keeps its 12 fields):
-          .last_margin   (B,) fp32  logit(top-1) - logit(top-2)
-          .last_bound    (B,) fp32  margin_kappa * rel_tol * |emb| |W[top1] - W[top2]| / sqrt(1024): the margin change a relative
-                                    embedding error of `rel_tol` in a random direction causes, times a safety factor
-          .last_certain  (B,) bool  margin > bound: the reference's argmax is this cell
-          .last_reencoded (n,) int64  the samples the exact mode re-encoded (empty when it is off)
-        Extra keywords: `exact_top1` (default: env PIGEON_EXACT_TOP1=1) -- samples that are not certain are re-encoded FROM THE
-        PIXELS in the encoder's exact mode (pg_vit_forward_precise: split-fp16 GEMM operands, fp32 attention; ~1e-6 relative, ~5x
-        the time per image) and their head outputs recomputed, so that their top-1 is the fp32 one; `margin_rel_tol` (default
-        1e-3 = the embedding tolerance of the contract, 1.5-4x the measured error; in exact mode it is re-calibrated on the fly to
-        1.25 x the RMS difference between the fast and the exact embeddings of the re-encoded samples, `margin_autocalibrate`)
-        and `margin_kappa` (default 4: a z-score, the margin change being Gaussian in units of rel_tol * sens).
+        The geocell argmax is the reference's, bit for bit (round 5: on by default).  The reference's `torch.argmax(geocell_probs)`
+        (:454) is fp32 end to end; this path's embeddings carry the rounding of 16-bit MFMA operands (2.7e-4 relative on default-init
+        weights, 7e-4 on a high-gain tower), so a sample whose margins are smaller than what that error moves could come out with a
+        runner-up.  Every forward therefore measures, per sample, the TOLERANCE of its top-1 against every other cell
+        (pg_head_certainty; error model and calibration: pigeon_amd/certainty.py) and -- `exact_top1`, default True, env
+        PIGEON_EXACT_TOP1=0 switches it off -- re-encodes the samples that are not certain FROM THEIR PIXELS in the encoder's exact mode
+        (pg_vit_forward_precise: split-fp16 GEMM operands, fp32 attention; ~2e-6 relative) and recomputes their head outputs.
+        After every forward (ModelOutput keeps its 12 fields):
+          .last_tol      (B,) fp32  the tolerance (see certainty.py), compared with .certainty.threshold()
+          .last_certain  (B,) bool  the top-1 is the reference's (after the re-encode: judged at the exact tier's floor)
+          .last_margin   (B,) fp32  logit(top-1) - logit(top-2);  .last_bound (B,) fp32 the margin change the threshold stands for
+          .last_reencoded (n,) int64  the samples the exact tier re-encoded (empty when it is off)
+        With a ProtoRefiner, `pigeon_amd.evaluate.certain_forward` extends the same guarantee to the refined cell and point.
+        Extra keywords: `exact_top1`, `margin_kappa` (z-score, default 3.6), `margin_rel_tol` (default 1e-3 = the contract's embedding
+        tolerance until `calibrate_certainty` -- called explicitly, or by the first forward that sees >= 8 samples with pixels --
+        replaces it by the measured error of THIS set of weights), `margin_rel_tol_exact` (2e-5).
         """
         super(SuperGuessr, self).__init__()
         geocell_path = kwargs.pop('geocell_path', None)
         exact_top1 = kwargs.pop('exact_top1', None)
-        self.exact_top1 = (os.environ.get('PIGEON_EXACT_TOP1', '0') not in ('', '0')) if exact_top1 is None else bool(exact_top1)
-        self.margin_rel_tol = float(kwargs.pop('margin_rel_tol', os.environ.get('PIGEON_MARGIN_REL_TOL', 1e-3)))
-        self.margin_rel_tol_exact = float(kwargs.pop('margin_rel_tol_exact', 2e-5))
-        self.margin_kappa = float(kwargs.pop('margin_kappa', os.environ.get('PIGEON_MARGIN_KAPPA', 4.0)))
+        self.exact_top1 = (os.environ.get('PIGEON_EXACT_TOP1', '1') not in ('', '0')) if exact_top1 is None else bool(exact_top1)
+        self.certainty = Certainty(kappa=float(kwargs.pop('margin_kappa', os.environ.get('PIGEON_MARGIN_KAPPA', 3.6))),
+                                   rel_tol=float(kwargs.pop('margin_rel_tol', os.environ.get('PIGEON_MARGIN_REL_TOL', 1e-3))),
+                                   rel_tol_exact=float(kwargs.pop('margin_rel_tol_exact', 2e-5)))
         self.margin_autocalibrate = bool(kwargs.pop('margin_autocalibrate', True))
-        self._cal_sumsq, self._cal_n = 0.0, 0
-        self.last_margin = self.last_bound = self.last_certain = self.last_reencoded = None
+        self.last_margin = self.last_bound = self.last_certain = self.last_reencoded = self.last_tol = None
+        self.last_state = None
         if len(kwargs) > 0:
             print(f'Not using keyword arguments: {list(kwargs.keys())}')
         if hierarchical or multi_task or heading:
@@ -92,7 +98,31 @@ class SuperGuessr(nn.Module):
         self._freeze_params()
         self.loss_fnc = nn.CrossEntropyLoss()
         self._hip_base = None
+        self._wnorm = None                                   # (key, device tensor): largest row norm of cell_layer.weight
+        if self.exact_top1 and isinstance(self.base_model, HipCLIPVisionModel):
+            self.base_model.enable_precise(True)             # pack the split-weight copy with the first build, not inside a request
         print(f'Initialized SuperGuessr classification model with {self.num_cells} geocells.')
+
+    # legacy names of the certainty parameters (round 4)
+    @property
+    def margin_kappa(self) -> float:
+        return self.certainty.kappa
+
+    @margin_kappa.setter
+    def margin_kappa(self, v: float):
+        self.certainty.kappa = float(v)
+
+    @property
+    def margin_rel_tol(self) -> float:
+        return self.certainty.rel_tol
+
+    @margin_rel_tol.setter
+    def margin_rel_tol(self, v: float):
+        self.certainty.rel_tol = float(v)
+
+    @property
+    def margin_rel_tol_exact(self) -> float:
+        return self.certainty.rel_tol_exact
 
     def _set_hidden_size(self):
         if self.base_model is not None:
@@ -129,6 +159,7 @@ class SuperGuessr(nn.Module):
         self._hip_base = None
         if isinstance(self.base_model, HipCLIPVisionModel):
             self.base_model._weights_changed()
+        self.certainty = Certainty(self.certainty.kappa, 1e-3, self.certainty.rel_tol_exact)     # other weights: the measured error is void
 
     def state_dict(self, *args, **kwargs):
         sd = super().state_dict(*args, **kwargs)
@@ -143,6 +174,8 @@ class SuperGuessr(nn.Module):
             return self.base_model
         if self._hip_base is None:                       # e.g. a transformers CLIPVisionModel: pack its weights once
             self._hip_base = HipCLIPVisionModel(self.base_model.state_dict())
+            if self.exact_top1:
+                self._hip_base.enable_precise(True)
             self._hip_base.to(self.cell_layer.weight.device)
         return self._hip_base
 
@@ -159,6 +192,117 @@ class SuperGuessr(nn.Module):
             return one_hot
         return tensor
 
+    def wnorm_max(self) -> Tensor:
+        """(1,) fp32 on the head's device: the largest row norm of cell_layer.weight (bounds |W[a] - W[c]| for the cells the certainty
+        pass does not visit one by one); recomputed when the weight tensor changes (in-place edits bump its version)."""
+        W = self.cell_layer.weight
+        key = (W.data_ptr(), W._version, str(W.device))
+        if self._wnorm is None or self._wnorm[0] != key:
+            self._wnorm = (key, W.data.float().norm(dim=1).max().reshape(1).contiguous())
+        return self._wnorm[1]
+
+    def _panels(self) -> int:
+        return 4 if self.panorama else 1
+
+    def _head_rows(self, layer_input: Tensor) -> Tensor:
+        if self.panorama:
+            head_in = layer_input if layer_input.dim() == 3 else layer_input[:, None, :]   # mean over panels :437
+        elif layer_input.dim() == 3 and layer_input.size(1) == 4:
+            head_in = layer_input[:, 0].contiguous()                            # :440-441
+        else:
+            head_in = layer_input
+        return head_in.contiguous()
+
+    def _head_with_tol(self, head_in: Tensor, exact: bool) -> dict:
+        """cell_layer + softmax + top-(k + extra) + argmax + centroid gather (:447-459), and the tolerance of the top-1."""
+        W = self.cell_layer.weight.data
+        kx = min(self.num_cells, self.num_candidates + EXTRA_CANDIDATES)
+        o = hip_ops.head_forward(head_in, W, self.cell_layer.bias.data, self.lla_geocells.data, kx)
+        drift = None if exact else self.certainty.drift_on(W.device)
+        o['tol'], o['code'], o['margin'], o['sens'] = hip_ops.head_certainty(o['logits'], head_in, W, o['topk_indices'], drift,
+                                                                             self.wnorm_max())
+        return o
+
+    @torch.no_grad()
+    def encode_head(self, pixel_values: Tensor = None, embedding: Tensor = None) -> dict:
+        """Fast pass: ViT + token mean (:395-398), head, tolerance of the top-1.  No re-encode.  Returns the step's STATE: a dict
+        with `embedding` (as ModelOutput carries it), `head_in`, the head outputs over k + extra candidates (`topk_values`,
+        `topk_indices`, `logits`, `preds_geocell`, `preds_LLH`), `tol`, `certain`, `exact` (rows on the exact tier: none yet) and
+        `pixel_values` (the reshaped device pixels, or None).  `reencode_rows` patches it in place; `package` turns it into the
+        reference's outputs."""
+        dev = self.cell_layer.weight.device
+        px = None
+        if self.panorama and pixel_values is not None:                          # :386-388
+            num_samples = pixel_values.size(0)
+            pixel_values = pixel_values.reshape((num_samples * 4, 3, 336, 336))
+        if self.base_model is not None and pixel_values is not None:
+            if pixel_values.dim() > 4:
+                pixel_values = pixel_values.squeeze(1)                          # :392-393
+            px = pixel_values.to(dev)
+            if (self.exact_top1 and self.margin_autocalibrate and not self.certainty.calibrated
+                    and px.shape[0] >= 8 * self._panels()):
+                self._calibrate(px)
+            embedding = self._encoder().embed(px)                               # :395-398 (ViT + token mean)
+            if self.panorama:
+                embedding = embedding.reshape((num_samples, 4, embedding.shape[-1]))   # :404-405 (explicit width: B = 0 stays legal)
+        else:
+            embedding = embedding.to(dev, torch.float32).contiguous()
+        head_in = self._head_rows(embedding)
+        st = self._head_with_tol(head_in, exact=False)
+        st['embedding'], st['head_in'], st['pixel_values'] = embedding, head_in, px
+        st['certain'] = st['tol'] > self.certainty.threshold()
+        st['exact'] = torch.zeros_like(st['certain'])
+        st['reencoded'] = torch.empty((0,), dtype=torch.int64, device=dev)
+        return st
+
+    @torch.no_grad()
+    def reencode_rows(self, st: dict, idx: Tensor) -> None:
+        """Exact tier for the samples `idx` of a state: their pixels go through pg_vit_forward_precise, their rows of the embedding
+        and of every head output are replaced, their tolerance is judged at the exact tier's floor."""
+        if idx.numel() == 0:
+            return
+        if st['pixel_values'] is None:
+            raise ValueError('reencode_rows needs the pixels (the state was built from embeddings)')
+        P = self._panels()
+        px = st['pixel_values'].reshape((-1, P, 3, 336, 336))[idx].reshape((-1, 3, 336, 336))
+        emb_x = self._encoder().embed_precise(px)
+        if self.panorama:
+            emb_x = emb_x.reshape((idx.numel(), P, emb_x.shape[-1]))
+        st['embedding'][idx] = emb_x
+        hin = self._head_rows(emb_x)
+        st['head_in'][idx] = hin
+        o2 = self._head_with_tol(hin, exact=True)
+        for k in ('logits', 'topk_values', 'topk_indices', 'preds_geocell', 'preds_LLH', 'tol', 'code', 'margin', 'sens'):
+            st[k][idx] = o2[k]
+        st['certain'][idx] = o2['tol'] > self.certainty.threshold(exact=True)
+        st['exact'][idx] = True
+        st['reencoded'] = idx
+
+    def _publish(self, st: dict) -> None:
+        thr = torch.where(st['exact'], self.certainty.threshold(True), self.certainty.threshold(False))
+        self.last_tol, self.last_margin, self.last_certain = st['tol'], st['margin'], st['certain']
+        self.last_bound = st['sens'] * thr
+        self.last_reencoded = st['reencoded']
+        self.last_state = st
+
+    def package(self, st: dict, labels: Tensor = None, labels_clf: Tensor = None):
+        """State -> the reference's outputs (:459-483)."""
+        self._publish(st)
+        k = self.num_candidates
+        geocell_topk = TopK(st['topk_values'][:, :k], st['topk_indices'][:, :k])
+        if not self.training and self.serving:                              # :462-466
+            return st['preds_LLH'], geocell_topk, st['embedding']
+        dev = st['logits'].device
+        loss_clf = None
+        if labels_clf is not None:                                          # :456, :474 (logged only)
+            label_probs = self._to_one_hot(labels_clf.to(dev))
+            if self.should_smooth_labels and labels is not None:            # :469-471 soft labels by distance
+                distances = haversine_matrix(labels.to(dev), self.lla_geocells.data.t())
+                label_probs = smooth_labels(distances)
+            loss_clf = self.loss_fnc(st['logits'], label_probs)
+        return ModelOutput(loss_clf, loss_clf, 0, 0, 0, st['preds_LLH'], st['preds_geocell'], None, None, None,
+                           geocell_topk, st['embedding'])
+
     def forward(self, pixel_values: Tensor = None, embedding: Tensor = None, heading: Tensor = None,
                 labels: Tensor = None, labels_clf: Tensor = None, labels_multi_task: Tensor = None,
                 labels_climate: Tensor = None, labels_month: Tensor = None, index: Tensor = None):
@@ -170,127 +314,39 @@ class SuperGuessr(nn.Module):
         self._assert_requirements(pixel_values, embedding, heading)
         if not self.cell_layer.weight.is_cuda:
             raise RuntimeError('pigeon_amd.SuperGuessr runs on the GPU only: call .to("cuda") first (no CPU fallback)')
-        dev = self.cell_layer.weight.device
         with torch.no_grad():
-            if self.panorama and pixel_values is not None:                      # :386-388
-                num_samples = pixel_values.size(0)
-                pixel_values = pixel_values.reshape((num_samples * 4, 3, 336, 336))
-            if self.base_model is not None and pixel_values is not None:
-                if pixel_values.dim() > 4:
-                    pixel_values = pixel_values.squeeze(1)                      # :392-393
-                embedding = self._encoder().embed(pixel_values.to(dev))         # :395-398 (ViT + token mean)
-                if self.panorama:
-                    embedding = embedding.reshape((num_samples, 4, embedding.shape[-1]))   # :404-405 (explicit width: B = 0 stays legal)
-            else:
-                embedding = embedding.to(dev, torch.float32).contiguous()
-
-            layer_input = embedding
-            if self.panorama:
-                head_in = layer_input if layer_input.dim() == 3 else layer_input[:, None, :]   # mean over panels :437
-            elif layer_input.dim() == 3 and layer_input.size(1) == 4:
-                head_in = layer_input[:, 0].contiguous()                        # :440-441
-            else:
-                head_in = layer_input
-            head_in = head_in.contiguous()
-            o = hip_ops.head_forward(head_in, self.cell_layer.weight.data, self.cell_layer.bias.data,
-                                     self.lla_geocells.data, self.num_candidates)          # :447-459
-            embedding = self._certainty(o, head_in, embedding, pixel_values)
-            logits = o['logits']
-            geocell_preds = o['preds_geocell']
-            pred_LLH = o['preds_LLH']
-            geocell_topk = TopK(o['topk_values'], o['topk_indices'])
-
-            if not self.training and self.serving:                              # :462-466
-                return pred_LLH, geocell_topk, embedding
-
-            loss_clf = None
-            if labels_clf is not None:                                          # :456, :474 (logged only)
-                label_probs = self._to_one_hot(labels_clf.to(dev))
-                if self.should_smooth_labels and labels is not None:            # :469-471 soft labels by distance
-                    distances = haversine_matrix(labels.to(dev), self.lla_geocells.data.t())
-                    label_probs = smooth_labels(distances)
-                loss_clf = self.loss_fnc(logits, label_probs)
-            loss = loss_clf
-            return ModelOutput(loss, loss_clf, 0, 0, 0, pred_LLH, geocell_preds, None, None, None,
-                               geocell_topk, embedding)
+            st = self.encode_head(pixel_values, embedding)
+            if self.exact_top1 and st['pixel_values'] is not None:
+                # the one host synchronisation of the step: which samples are inside the error band is data dependent
+                self.reencode_rows(st, torch.nonzero(~st['certain']).flatten())
+            return self.package(st, labels, labels_clf)
 
     @torch.no_grad()
-    def calibrate_certainty(self, pixel_values: Tensor, max_samples: int = 16) -> float:
-        """Measure what the 16-bit path's embedding error IS on this model -- once per set of weights -- and set the certainty bound
-        from it: up to `max_samples` samples go through the fast and the exact encoder, `margin_rel_tol` becomes 1.25 x the RMS
-        relative difference of their (panel-mean) embeddings.  Returns that RMS.  Needs pixels and a base model; the encoder is
-        (re)packed with the exact mode's split-weight copy if it did not have it."""
-        if self.base_model is None or pixel_values is None:
-            raise ValueError('calibrate_certainty needs pixel_values and a base model')
-        dev = self.cell_layer.weight.device
-        P = 4 if self.panorama else 1
-        px = pixel_values[:max_samples].reshape((-1, 3, 336, 336)).to(dev)
+    def _calibrate(self, px: Tensor, max_samples: int = 32) -> dict:
+        P = self._panels()
+        n = min(max_samples, px.shape[0] // P)
+        px = px[:n * P]
         enc = self._encoder()
         fast = enc.embed(px).reshape((-1, P, CLIP_EMBED_DIM)).mean(dim=1)
         exact = enc.embed_precise(px).reshape((-1, P, CLIP_EMBED_DIM)).mean(dim=1)
-        rel2 = ((fast - exact).norm(dim=1) / exact.norm(dim=1).clamp_min(1e-30)) ** 2
-        self._cal_sumsq += float(rel2.sum())
-        self._cal_n += int(rel2.numel())
-        rms = (self._cal_sumsq / self._cal_n) ** 0.5
-        self.margin_rel_tol = max(1.25 * rms, 4 * self.margin_rel_tol_exact)
-        return rms
+        return self.certainty.calibrate(fast, exact)
 
-    def _certainty(self, o, head_in: Tensor, embedding: Tensor, pixel_values) -> Tensor:
-        """Margin / bound / certain per sample; with exact_top1, re-encode the uncertain samples from their pixels in the
-        encoder's exact mode and overwrite their rows of the head outputs `o` (and of the returned embedding)."""
-        W = self.cell_layer.weight.data
-        margin, sens, _ = hip_ops.head_margin(o['logits'], head_in, W)
-        bound = sens * (self.margin_kappa * self.margin_rel_tol)
-        certain = margin > bound
-        self.last_reencoded = torch.empty((0,), dtype=torch.int64, device=margin.device)
-        if self.exact_top1 and pixel_values is not None and self.base_model is not None and not bool(certain.all()):
-            idx = torch.nonzero(~certain).flatten()
-            P = 4 if self.panorama else 1
-            px = pixel_values.reshape((-1, P, 3, 336, 336))[idx.to(pixel_values.device)].reshape((-1, 3, 336, 336))
-            emb_x = self._encoder().embed_precise(px.to(W.device))
-            emb_x = emb_x.reshape((idx.numel(), P, emb_x.shape[-1])) if self.panorama else emb_x
-            # what the 16-bit path's embedding error IS on this model: the exact re-encode of the uncertain samples measures it
-            # (panel-mean embeddings, relative L2).  1.25 x its running RMS replaces the conservative default of `margin_rel_tol`
-            # once 8 samples have been seen -- the margin change it explains is Gaussian in those units (observed max over 128
-            # panoramas: 2.8 x the RMS), so kappa is a z-score
-            fast_mean = head_in[idx].reshape(idx.numel(), -1, head_in.shape[-1]).mean(dim=1) if head_in.dim() == 3 else head_in[idx]
-            exact_mean = emb_x.mean(dim=1) if emb_x.dim() == 3 else emb_x
-            rel2 = ((fast_mean - exact_mean).norm(dim=1) / exact_mean.norm(dim=1).clamp_min(1e-30)) ** 2
-            self._cal_sumsq += float(rel2.sum())
-            self._cal_n += int(rel2.numel())
-            if self.margin_autocalibrate and self._cal_n >= 8:
-                self.margin_rel_tol = max(1.25 * (self._cal_sumsq / self._cal_n) ** 0.5, 4 * self.margin_rel_tol_exact)
-            embedding = embedding.clone()
-            embedding[idx] = emb_x
-            if self.panorama:
-                hin = emb_x
-            elif emb_x.dim() == 3 and emb_x.size(1) == 4:
-                hin = emb_x[:, 0].contiguous()
-            else:
-                hin = emb_x
-            o2 = hip_ops.head_forward(hin.contiguous(), W, self.cell_layer.bias.data, self.lla_geocells.data, self.num_candidates)
-            for k in ('logits', 'topk_values', 'topk_indices', 'preds_geocell', 'preds_LLH'):
-                o[k][idx] = o2[k]
-            m2, s2, _ = hip_ops.head_margin(o2['logits'], hin.contiguous(), W)
-            b2 = s2 * (self.margin_kappa * self.margin_rel_tol_exact)
-            margin[idx], bound[idx], certain[idx] = m2, b2, m2 > b2
-            self.last_reencoded = idx
-        self.last_margin, self.last_bound, self.last_certain = margin, bound, certain
-        return embedding
+    @torch.no_grad()
+    def calibrate_certainty(self, pixel_values: Tensor, max_samples: int = 32) -> float:
+        """Measure what the 16-bit path's embedding error IS on this model -- once per set of weights -- and set the certainty
+        threshold from it: up to `max_samples` samples go through the fast and the exact encoder (`Certainty.calibrate`: the
+        systematic part of their difference and the RMS of the rest).  Frozen afterwards: which samples a later forward re-encodes
+        does not depend on what earlier batches held.  Returns the total RMS relative difference.  Needs pixels and a base model."""
+        if self.base_model is None or pixel_values is None:
+            raise ValueError('calibrate_certainty needs pixel_values and a base model')
+        dev = self.cell_layer.weight.device
+        px = pixel_values.reshape((-1, 3, 336, 336)).to(dev)
+        return self._calibrate(px, max_samples)['fast_vs_exact_rms']
 
     def __str__(self):
-        rep = 'SuperGuessr(\n'
-        rep += f'\tbase_model\t= {self.base_model is not None}\n'
-        rep += f'\tpanorama\t= {self.panorama}\n'
-        rep += f'\thierarchical\t= {self.hierarchical}\n'
-        rep += f'\tmulti-task\t= {self.multi_task}\n'
-        rep += f'\tyfcc\t\t= {self.yfcc}\n'
-        rep += f'\tembedding_size\t= {self.hidden_size}\n'
-        rep += f'\tinput_dim\t= {self.input_dim}\n'
-        rep += f'\tnum_geocells\t= {self.num_cells}\n'
-        rep += f'\tlabel_smoothing\t= {self.should_smooth_labels}\n'
-        rep += f'\tuses_headings\t= {self.heading}\n'
-        rep += f'\tfreeze_base\t= {self.freeze_base}\n'
-        rep += f'\tserving\t\t= {self.serving}\n'
-        rep += ')'
-        return rep
+        shown = (('base_model', self.base_model is not None), ('panorama', self.panorama), ('hierarchical', self.hierarchical),
+                 ('multi-task', self.multi_task), ('yfcc', self.yfcc), ('embedding_size', self.hidden_size), ('input_dim', self.input_dim),
+                 ('num_geocells', self.num_cells), ('label_smoothing', self.should_smooth_labels), ('uses_headings', self.heading),
+                 ('freeze_base', self.freeze_base), ('serving', self.serving))
+        width = max(len(k) for k, _ in shown) + 1
+        return 'SuperGuessr(\n' + ''.join(f'\t{k.ljust(width)}= {v}\n' for k, v in shown) + ')'

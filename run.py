@@ -46,9 +46,11 @@ argp.add_argument('--synthetic', type=int, default=0, help='use N seeded synthet
 argp.add_argument('--layers', type=int, default=24, help='encoder layers for a "random" model')
 argp.add_argument('--out-dir', default='data/landmark_embeddings')
 argp.add_argument('--geocells', type=int, default=10000, help='synthetic geocell count')
-argp.add_argument('--exact-top1', action='store_true', default=False,
-                  help='evaluate: re-encode panoramas whose geocell top-1 margin is inside the error band of the 16-bit path in the '
-                       "encoder's exact mode, so that the argmax is the reference's fp32 one (same as PIGEON_EXACT_TOP1=1)")
+argp.add_argument('--exact-top1', dest='exact_top1', action='store_true', default=None,
+                  help="(default) re-encode the panoramas whose discrete outputs are inside the 16-bit path's error band in the "
+                       "encoder's exact mode, so that geocell argmax and refined point are the reference's fp32 ones (PIGEON_EXACT_TOP1=1)")
+argp.add_argument('--no-exact-top1', dest='exact_top1', action='store_false',
+                  help="the 16-bit path alone (PIGEON_EXACT_TOP1=0): embeddings within 1e-3, discrete outputs not guaranteed")
 
 
 class _SyntheticImages(torch.utils.data.Dataset):
@@ -84,8 +86,8 @@ def _vision_model(args):
 
 def main():
     args = argp.parse_args()
-    if args.exact_top1:
-        os.environ['PIGEON_EXACT_TOP1'] = '1'          # read by SuperGuessr / HipCLIPVisionModel at construction
+    if args.exact_top1 is not None:
+        os.environ['PIGEON_EXACT_TOP1'] = '1' if args.exact_top1 else '0'     # read by SuperGuessr / HipCLIPVisionModel at construction
     mode = 'classification' if args.classification else 'regression'
     logger.warning(f'Task: {args.function.capitalize()} Pigeon("{args.name}") via geospatial {mode}.')
     if args.function in ('pretrain', 'finetune'):

@@ -1,0 +1,345 @@
+"""The certainty kernels (csrc/certainty.hip, round 5) and the extended refinement records they read (pg_refine_forward_ex), against
+float64 restatements written out here from the formulas of pigeon_amd/certainty.py (run with -m gpu on an MI355X).
+
+  * pg_refine_forward_ex == pg_refine_forward on the selection, and its extra record fields == brute force (runner-up prototype,
+    the two farthest members);
+  * pg_head_certainty == min over the listed cells (and the bound for the cells beyond the list) of
+    (m - |e| g.beta) / (|e| |g| / 32), with and without a systematic part beta;
+  * pg_refine_certainty == the same minimum over the refiner's decisions (winner against the set, set boundary, nearest prototype,
+    farthest member), veto included;
+  * what the numbers MEAN: a perturbation of the embedding smaller than the tolerance never changes an output, one slightly larger
+    in the worst direction does.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def env():
+    from pigeon_amd import _lib, hip_ops, synthetic
+    from pigeon_amd.proto_refiner import HostBank
+    _lib.require_gpu()
+    return dict(lib=_lib, ops=hip_ops, syn=synthetic, HostBank=HostBank)
+
+
+def _bank(env, cells=60, ppc=9, seed=5):
+    syn = env["syn"]
+    hb = syn.make_bank(cells, ppc, seed=seed, empty_frac=0.1, max_members=6)
+    return hb, env["ops"].DeviceBank(hb, device=DEV)
+
+
+def _queries(hb, B, k, seed, P=4):
+    rng = np.random.default_rng(seed)
+    C = hb.cell_off.shape[0] - 1
+    q = np.empty((B, P, 1024), dtype=np.float32)
+    cand = np.stack([rng.permutation(C)[:k] for _ in range(B)]).astype(np.int64)
+    for i in range(B):
+        c = cand[i, rng.integers(0, 3)]
+        s, e = hb.cell_off[c], hb.cell_off[c + 1]
+        base = hb.proto_emb[rng.integers(s, e)] if e > s else np.zeros(1024, np.float32)
+        q[i] = base[None] + 0.7 * rng.standard_normal((P, 1024)).astype(np.float32)
+    logit = np.sort(rng.normal(0, 1.2, (B, k)), axis=1)[:, ::-1]
+    prob = np.exp(logit - 6.0)
+    prob = (prob / (prob.sum(1, keepdims=True) * 1.3)).astype(np.float32)          # a head's top-k: descending, summing to < 1
+    init = np.stack([rng.uniform(-180, 180, B), rng.uniform(-80, 80, B)], axis=1)
+    return torch.from_numpy(q), torch.from_numpy(cand), torch.from_numpy(prob), torch.from_numpy(init)
+
+
+def test_refine_forward_ex_records(env):
+    ops = env["ops"]
+    hb, db = _bank(env)
+    B, k, topk, n_eval = 40, 12, 5, 9
+    q, cand, prob, init = _queries(hb, B, k, seed=1)
+    args = (db, q.to(DEV), init.to(DEV), cand.to(DEV), prob.to(DEV))
+    llh0, cell0, ch0, sc0 = ops.refine_forward(*args, topk, 1.6, 1000.0, return_scratch=True)
+    llh, cell, ch, refined, sc = ops.refine_forward_ex(*args, topk, n_eval, 1.6, 1000.0)
+    assert torch.equal(llh, llh0) and torch.equal(cell, cell0) and torch.equal(ch, ch0)
+    assert torch.equal(sc[:, :topk, :4], sc0)
+    assert ((refined == ch) | (ch == 0)).all()                    # a veto falls back to candidate 0 (probabilities descend)
+    sc = sc.cpu()
+    qm = q.mean(dim=1).double()
+    ints = sc[..., [5, 6, 9, 10, 11]].contiguous().view(torch.int32)
+    for b in range(B):
+        for j in range(n_eval):
+            c = int(cand[b, j]); s, e = int(hb.cell_off[c]), int(hb.cell_off[c + 1])
+            r = sc[b, j]
+            p1, p2, t1, t2, cnt = [int(x) for x in ints[b, j]]
+            if e == s:
+                assert r[0] == -100000.0 and p1 == -1 and p2 == -1 and t1 == -1
+                continue
+            d = (torch.from_numpy(hb.proto_emb[s:e]).double() - qm[b]).norm(dim=1)
+            order = torch.argsort(d, stable=True)
+            assert p1 == s + int(order[0]) and abs(float(-r[0]) - float(d[order[0]])) < 1e-4 * float(d[order[0]])
+            if e - s > 1:
+                assert p2 == s + int(order[1]) and abs(float(r[4]) - float(d[order[1]])) < 1e-4 * float(d[order[1]])
+            else:
+                assert p2 == -1 and torch.isinf(r[4])
+            assert cnt == int(hb.proto_count[p1])
+            if cnt > 1:
+                mem = hb.member_idx[int(hb.member_off[p1]):int(hb.member_off[p1 + 1])]
+                dm = (torch.from_numpy(hb.train_emb[mem]).double() - qm[b]).norm(dim=1)
+                o2 = torch.argsort(-dm, stable=True)
+                assert t1 == int(mem[int(o2[0])]) and abs(float(r[7]) - float(dm[o2[0]])) < 1e-4 * float(dm[o2[0]])
+                assert t2 == int(mem[int(o2[1])]) and abs(float(r[8]) - float(dm[o2[1]])) < 1e-4 * float(dm[o2[1]])
+            else:
+                assert t1 == -1 and t2 == -1 and r[7] == -1 and r[8] == -1
+
+
+def _tol(m, g, beta, en):
+    g2 = float(g @ g)
+    if not np.isfinite(m) and m > 0:
+        return np.inf
+    if g2 == 0:
+        return np.inf
+    return (m - en * float(g @ beta)) / (en * np.sqrt(g2) / 32.0)
+
+
+def _head_tol_restated(logits, e, W, idx, beta, wmax):
+    C = W.shape[0]
+    en = np.linalg.norm(e)
+    c0 = idx[0]
+    best, code = np.inf, 0
+    for j in range(1, len(idx)):
+        t = _tol(logits[c0] - logits[idx[j]], W[c0] - W[idx[j]], beta, en)
+        if t < best:
+            best, code = t, j
+    if len(idx) < C:
+        gmax = np.linalg.norm(W[c0]) + wmax
+        t = (logits[c0] - logits[idx[-1]] - en * gmax * np.linalg.norm(beta)) / (en * gmax / 32.0)
+        if t < best:
+            best, code = t, -1
+    return best, code
+
+
+@pytest.mark.parametrize("with_drift", [False, True])
+def test_head_certainty_vs_restatement(env, with_drift):
+    ops, syn = env["ops"], env["syn"]
+    g = torch.Generator().manual_seed(8)
+    B, C, kx = 37, 3001, 9
+    emb = torch.randn((B, 4, 1024), generator=g)
+    W, b = syn.make_head_weights(C, seed=4)
+    W = W * 8
+    cent = torch.from_numpy(syn.make_geocells(C, seed=1))
+    beta = (2e-4 * torch.randn((1024,), generator=g) / 32).float() if with_drift else None
+    o = ops.head_forward(emb.to(DEV), W.to(DEV), b.to(DEV), cent.to(DEV), kx)
+    wmax = W.norm(dim=1).max().reshape(1)
+    tol, code, margin, sens = ops.head_certainty(o["logits"], emb.to(DEV), W.to(DEV), o["topk_indices"],
+                                                 None if beta is None else beta.to(DEV), wmax.to(DEV))
+    lg, idx = o["logits"].cpu().double().numpy(), o["topk_indices"].cpu().numpy()
+    pe = emb.mean(dim=1).double().numpy()
+    Wd = W.double().numpy()
+    bz = np.zeros(1024) if beta is None else beta.double().numpy()
+    for i in range(B):
+        t, c = _head_tol_restated(lg[i], pe[i], Wd, idx[i], bz, float(wmax))
+        assert abs(float(tol[i]) - t) <= 2e-3 * abs(t) + 1e-6, (i, float(tol[i]), t)
+        assert int(code[i]) == c
+    # the legacy pair (top-1 against top-2) rides along
+    t2 = torch.topk(o["logits"].cpu(), 2, dim=-1)
+    assert torch.equal(margin.cpu(), t2.values[:, 0] - t2.values[:, 1])
+    want = emb.mean(dim=1).norm(dim=1) * (W[t2.indices[:, 0]] - W[t2.indices[:, 1]]).norm(dim=1) / 32.0
+    assert torch.allclose(sens.cpu(), want, rtol=1e-5)
+    # the whole head listed: nothing beyond the list; one geocell: nothing to be uncertain about
+    Cs = 7
+    o7 = ops.head_forward(emb.to(DEV), W[:Cs].contiguous().to(DEV), b[:Cs].to(DEV), cent[:Cs].to(DEV), Cs)
+    t7, c7, _, _ = ops.head_certainty(o7["logits"], emb.to(DEV), W[:Cs].contiguous().to(DEV), o7["topk_indices"], None, wmax.to(DEV))
+    assert (c7 >= 1).all() and torch.isfinite(t7).all()
+    o1 = ops.head_forward(emb.to(DEV), W[:1].contiguous().to(DEV), b[:1].to(DEV), cent[:1].to(DEV), 1)
+    t1, c1, m1, s1 = ops.head_certainty(o1["logits"], emb.to(DEV), W[:1].contiguous().to(DEV), o1["topk_indices"], None, wmax.to(DEV))
+    assert torch.isinf(t1).all() and torch.isinf(m1).all() and (s1 == 0).all()
+
+
+def test_head_tolerance_means_what_it_says(env):
+    """Move the embedding against the gradient of the tightest decision: 0.9 x the tolerance keeps the argmax, 1.1 x flips it
+    (the tolerance is in units of |e| |g| / 32 per unit relative error: a step of relative size t / 32 along -g / |g| closes the margin)."""
+    ops, syn = env["ops"], env["syn"]
+    g = torch.Generator().manual_seed(9)
+    B, C, kx = 16, 500, 9
+    emb = torch.randn((B, 1, 1024), generator=g)
+    W, b = syn.make_head_weights(C, seed=5)
+    W = W * 8
+    cent = torch.from_numpy(syn.make_geocells(C, seed=1))
+    wmax = W.norm(dim=1).max().reshape(1).to(DEV)
+
+    def run(e):
+        o = ops.head_forward(e.to(DEV), W.to(DEV), b.to(DEV), cent.to(DEV), kx)
+        return o, ops.head_certainty(o["logits"], e.to(DEV), W.to(DEV), o["topk_indices"], None, wmax)
+    o, (tol, code, _, _) = run(emb)
+    idx = o["topk_indices"].cpu()
+    moved = 0
+    for i in range(B):
+        j = int(code[i])
+        if j < 1:
+            continue
+        gvec = (W[idx[i, 0]] - W[idx[i, j]]).double()
+        en = float(emb[i, 0].double().norm())
+        step = float(tol[i]) / 32.0 * en * gvec / gvec.norm()
+        for f, same in ((0.9, True), (1.1, False)):
+            e2 = emb.clone()
+            e2[i, 0] = (emb[i, 0].double() - f * step).float()
+            o2, _ = run(e2)
+            assert (int(o2["preds_geocell"][i]) == int(o["preds_geocell"][i])) == same, (i, f)
+        moved += 1
+    assert moved >= 8
+
+
+def _refine_tol_restated(rec, ints, L, cand, topk, n_eval, C, W, bankp, bankt, e, beta, wmax, T, r, ch, fin_r):
+    en = np.linalg.norm(e)
+    S = L + rec[:, 0] / T
+    if not (fin_r >= 1e-30) and ints[r, 0] >= 0:
+        return 0.0, -9
+    if ints[r, 0] < 0:
+        return np.inf, 0
+
+    def pair_s(a, j):
+        pa, pj = ints[a, 0], ints[j, 0]
+        da, dj = -rec[a, 0], -rec[j, 0]
+        ia = (1.0 / T) / da if (pa >= 0 and da > 0) else 0.0
+        ij = (1.0 / T) / dj if (pj >= 0 and dj > 0) else 0.0
+        g = W[cand[a]] - W[cand[j]] + (ia * bankp[pa] if pa >= 0 else 0) - (ij * bankp[pj] if pj >= 0 else 0) + (ij - ia) * e
+        return _tol(S[a] - S[j], g, beta, en)
+    best, code = np.inf, 0
+    for j in range(topk):
+        if j == r:
+            continue
+        t = pair_s(r, j)
+        if t < best:
+            best, code = t, 1000 + j
+    for j in range(topk, n_eval):
+        t_in = _tol(L[topk - 1] - L[j], W[cand[topk - 1]] - W[cand[j]], beta, en)
+        t = t_in if r == topk - 1 else max(t_in, pair_s(r, j))
+        if t < best:
+            best, code = t, 2000 + j
+    if n_eval > topk and n_eval < C:
+        gmax = np.linalg.norm(W[cand[topk - 1]]) + wmax
+        t = (L[topk - 1] - L[n_eval - 1] - en * gmax * np.linalg.norm(beta)) / (en * gmax / 32.0)
+        if t < best:
+            best, code = t, 2999
+    for which, x in enumerate((r, ch)):
+        if which == 1 and ch == r:
+            break
+        p1, p2, t1, t2 = ints[x, 0], ints[x, 1], ints[x, 2], ints[x, 3]
+        if p1 >= 0 and p2 >= 0:
+            d1, d2 = -rec[x, 0], rec[x, 4]
+            g = (e - bankp[p2]) / d2 - (e - bankp[p1]) / d1
+            t = _tol(d2 - d1, g, beta, en)
+            if t < best:
+                best, code = t, 3000 + which
+        if t1 >= 0 and t2 >= 0:
+            f1, f2 = rec[x, 7], rec[x, 8]
+            g = (e - bankt[t1]) / f1 - (e - bankt[t2]) / f2
+            t = _tol(f1 - f2, g, beta, en)
+            if t < best:
+                best, code = t, 4000 + which
+    return best, code
+
+
+@pytest.mark.parametrize("topk,k,T,max_km,with_drift", [(5, 9, 1.6, 1000.0, False), (5, 9, 1.6, 1000.0, True), (8, 8, 0.6, 1e5, False),
+                                                         (3, 12, 1.0, 50.0, True)])
+def test_refine_certainty_vs_restatement(env, topk, k, T, max_km, with_drift):
+    ops, syn = env["ops"], env["syn"]
+    hb, db = _bank(env)
+    C = hb.cell_off.shape[0] - 1
+    B = 48
+    q, cand, prob, init = _queries(hb, B, k, seed=3)
+    g = torch.Generator().manual_seed(2)
+    W = torch.randn((C, 1024), generator=g) * 0.3
+    beta = (3e-4 * torch.randn((1024,), generator=g) / 32).float() if with_drift else None
+    wmax = W.norm(dim=1).max().reshape(1)
+    n_eval = min(k, topk + 4)
+    llh, cell, ch, refined, sc = ops.refine_forward_ex(db, q.to(DEV), init.to(DEV), cand.to(DEV), prob.to(DEV), topk, n_eval, T, max_km)
+    tol, code = ops.refine_certainty(db, q.to(DEV), cand.to(DEV), prob.to(DEV), topk, sc, W.to(DEV),
+                                     None if beta is None else beta.to(DEV), wmax.to(DEV), T, refined, ch)
+    sc = sc.cpu()
+    ints = sc[..., [5, 6, 9, 10]].contiguous().view(torch.int32).numpy()
+    rec = sc.double().numpy()
+    qm = q.mean(dim=1).double().numpy()
+    bz = np.zeros(1024) if beta is None else beta.double().numpy()
+    Wd = W.double().numpy()
+    bp, bt = hb.proto_emb.astype(np.float64), hb.train_emb.astype(np.float64)
+    seen = set()
+    for b in range(B):
+        L = np.log(prob[b, :n_eval].float().numpy()).astype(np.float64)               # fp32 log as the kernel takes it
+        r, c = int(refined[b]), int(ch[b])
+        ex = np.exp((sc[b, :topk, 0] / T).float().numpy()).astype(np.float32)
+        fin_r = float(prob[b, r]) * float(ex[r] / ex.sum(dtype=np.float32))
+        t, cd = _refine_tol_restated(rec[b], ints[b], L, cand[b].numpy(), topk, n_eval, C, Wd, bp, bt, qm[b], bz, float(wmax), T, r, c, fin_r)
+        got = float(tol[b])
+        assert (np.isinf(t) and np.isinf(got)) or abs(got - t) <= 5e-3 * abs(t) + 1e-5, (b, got, t, int(code[b]), cd)
+        if np.isfinite(t) and abs(t) > 1e-3:
+            assert int(code[b]) == cd, (b, int(code[b]), cd, got, t)
+        seen.add(cd // 1000)
+    assert 1 in seen                                              # winner-against-the-set decisions set some tolerances
+    # without candidates beyond the set the boundary question stays open: no 2xxx code
+    if n_eval == topk:
+        assert not ((code >= 2000) & (code < 3000)).any()
+
+
+def test_certain_forward_end_to_end_small(env, tmp_path):
+    """pigeon_amd.evaluate.certain_forward on a 2-layer tower: with everything forced uncertain every sample is re-encoded and the
+    outputs equal the exact encoder's chain; with nothing uncertain they are the fast path's; the info dict is consistent."""
+    import os
+    from pigeon_amd.clip_embedder import HipCLIPVisionModel
+    from pigeon_amd.evaluate import certain_forward
+    from pigeon_amd.proto_refiner import ProtoRefiner
+    from pigeon_amd.super_guessr import SuperGuessr
+    ops, syn = env["ops"], env["syn"]
+    C = 60
+    gp = os.path.join(str(tmp_path), "g.csv")
+    syn.write_geocell_csv(gp, syn.make_geocells(C, seed=0))
+    sd = syn.make_vit_weights(seed=11, layers=2, affine_jitter=True)
+    vit = HipCLIPVisionModel(sd, layers=2).to(DEV)
+    W, b = syn.make_head_weights(C, seed=1)
+    hb, _ = _bank(env, cells=C)
+    px = syn.make_pixels(4 * 6, seed=3, panorama=True).to(DEV)                      # 6 panoramas
+
+    def build(kappa):
+        m = SuperGuessr(vit, panorama=True, freeze_base=True, num_candidates=5, geocell_path=gp, exact_top1=True, margin_kappa=kappa,
+                        margin_autocalibrate=False)
+        with torch.no_grad():
+            m.cell_layer.weight.copy_(W * 64); m.cell_layer.bias.copy_(b)
+        return m.to(DEV).eval()
+    ref = ProtoRefiner(topk=5, max_refinement=1000, temperature=1.6, bank=hb, device=DEV).eval()
+    m_all = build(1e9)                                            # exact_top1: the tower packs its split-weight copy now
+    enc = vit._encoder(torch.device(DEV))
+    out, info = certain_forward(m_all, ref, pixel_values=px)
+    assert info["reencoded"].tolist() == list(range(6)) and info["boundary_checked"] is True
+    want = enc.forward_precise(px.reshape(-1, 3, 336, 336)).reshape(6, 4, 1024)
+    assert torch.equal(out.embedding, want)
+    ho = ops.head_forward(want.contiguous(), m_all.cell_layer.weight.data, m_all.cell_layer.bias.data, m_all.lla_geocells.data, 5)
+    assert torch.equal(out.preds_geocell, ho["preds_geocell"]) and torch.equal(out.top5_geocells.indices, ho["topk_indices"])
+    assert out.top5_geocells.indices.shape == (6, 5)              # the extra candidates never leave the model
+    m_none = build(0.0)
+    out0, info0 = certain_forward(m_none, ref, pixel_values=px)
+    assert info0["reencoded"].numel() == 0 and torch.equal(out0.embedding, enc.forward(px.reshape(-1, 3, 336, 336)).reshape(6, 4, 1024))
+    assert bool(info0["certain"].all()) or bool((info0["head_tol"] <= 0).any() | (info0["refine_tol"] <= 0).any())
+    # embeddings in, no pixels: certainty is reported, nothing can be re-encoded
+    m_emb = build(1e9)
+    m_emb.base_model = None
+    out_e, info_e = certain_forward(m_emb, ref, embedding=want)
+    assert info_e["reencoded"].numel() == 0 and not bool(info_e["certain"].any())
+    assert torch.equal(out_e.preds_geocell, out.preds_geocell)
+
+
+def test_hipcc_builds_a_kernel_source_on_this_box(capsys):
+    """The library the tests load was cross-compiled in the authoring container; this compiles one of its sources AGAIN, here, with
+    the GPU box's own hipcc (same image) and prints the command -- "built for gfx950 by hipcc" is then visible in the GPU test log."""
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    from pigeon_amd import build
+    cc = build.hipcc()
+    if shutil.which(cc) is None and not os.path.exists(cc):
+        pytest.skip("no hipcc on this box")
+    src = os.path.join(build.CSRC, "certainty.hip")
+    obj = os.path.join(tempfile.mkdtemp(prefix="pigeon_hipcc_"), "certainty.o")
+    cmd = [cc] + build.FLAGS + ["-I", build.CSRC, "-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    with capsys.disabled():
+        print("\n[hipcc on the GPU box] " + " ".join(cmd) + f" -> rc {r.returncode}, {os.path.getsize(obj) if os.path.exists(obj) else 0} bytes")
+    assert r.returncode == 0 and os.path.getsize(obj) > 10000, r.stderr[-400:]

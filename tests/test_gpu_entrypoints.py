@@ -615,5 +615,5 @@ def test_run_py_evaluate_exact_top1(env, monkeypatch, capsys):
     o = orc.super_guessr_forward(model.cell_layer.weight.data.cpu(), model.cell_layer.bias.data.cpu(), model.lla_geocells.data.cpu(),
                                  50, vit_sd=model.base_model.state_dict(), pixel_values=px)
     assert np.array_equal(results["preds_geocells"], o["preds_geocell"].numpy())
-    assert model._cal_n == 16, "the exact pass did not run on every panorama"
+    assert model.last_reencoded.numel() == 16, "the exact pass did not run on every panorama"
     assert results["geocell_certain"].dtype == np.bool_

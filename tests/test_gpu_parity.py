@@ -852,10 +852,13 @@ def test_serve_predict_panorama(env, vit2, tmp_path):
     llh, topk, emb = model(pixel_values=px)
     assert {k: got[k] for k in ("lat", "lng")} == {"lat": float(llh[0, 1]), "lng": float(llh[0, 0])}
     # round 4: the certainty of the geocell top-1 rides along (extra keys; the extension reads lat / lng only)
-    assert isinstance(got["geocell_certain"], bool) and got["geocell_margin"] >= 0 and got["reencoded_exact"] is False
+    assert isinstance(got["geocell_certain"], bool) and got["geocell_margin"] >= 0 and isinstance(got["reencoded_exact"], bool)
     ref = env["orc"].super_guessr_forward(W, b, model.lla_geocells.data.cpu(), 5, embedding=emb.cpu())
     assert torch.equal(topk.indices.cpu(), ref["topk"].indices)
     refiner = ProtoRefiner(topk=5, bank=env["syn"].make_bank(C, 20, seed=4, empty_frac=0.05)).eval()
     got_r = serve.predict_panorama(views, model, refiner)
+    # the explicit chain: the model call with the refiner's decisions included in the certainty pass, then the refinement
+    from pigeon_amd.evaluate import certain_forward
+    (llh, topk, emb), _ = certain_forward(model, refiner, pixel_values=px)
     _, want, _ = refiner(embedding=emb, initial_preds=llh, candidate_cells=topk.indices, candidate_probs=topk.values)
     assert {k: got_r[k] for k in ("lat", "lng")} == {"lat": float(want[0, 1]), "lng": float(want[0, 0])}

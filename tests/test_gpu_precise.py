@@ -8,9 +8,8 @@ margin is inside that band may flip.  What is tested here:
     the persistent MFMA kernel), fp32 attention, LayerNorm -> triple, QuickGELU -> triple;
   * pg_vit_forward_precise against the reference-generated goldens (vit2, vit24, pipeline24_spread) at a tolerance 100x tighter
     than the fast path's (EXACT_TOL);
-  * pg_head_margin against torch;
-  * SuperGuessr(exact_top1=True) from the PIXELS against the REAL reference's 128-panorama fixtures: default mode lists its flips,
-    exact mode must have none, and every re-encoded panorama is reported.
+  * pg_head_margin against torch (the certainty kernels that superseded it: tests/test_gpu_certainty.py);
+  * the exact mode at the edges of its inputs.  The end-to-end contract on the REAL reference's fixtures: tests/test_gpu_top1.py.
 """
 import os
 
@@ -163,98 +162,6 @@ def test_precise_encoder_vs_reference_golden(env, golden_dir, name, capsys):
     enc.close()
 
 
-def _spread_model(env, tmp_path, exact):
-    from pigeon_amd.clip_embedder import HipCLIPVisionModel
-    from pigeon_amd.super_guessr import SuperGuessr
-    syn = env["syn"]
-    C = 10000
-    p = os.path.join(str(tmp_path), f"geocells_{C}.csv")
-    syn.write_geocell_csv(p, syn.make_geocells(C, seed=0))
-    return SuperGuessr, HipCLIPVisionModel, p
-
-
-def _top1_run(env, golden_dir, tmp_path, fixture, capsys):
-    """Default mode and exact mode of SuperGuessr from the pixels against a 128-panorama REAL-reference fixture."""
-    from pigeon_amd.clip_embedder import HipCLIPVisionModel
-    from pigeon_amd.super_guessr import SuperGuessr
-    syn, ops = env["syn"], env["ops"]
-    g = np.load(os.path.join(golden_dir, f"{fixture}.npz"))
-    wseed, layers, NP, pseed, C = [int(x) for x in g["meta"][:5]]
-    gp = os.path.join(str(tmp_path), f"geocells_{C}.csv")
-    syn.write_geocell_csv(gp, syn.make_geocells(C, seed=0))
-    sd = syn.make_vit_weights_spread(seed=wseed, layers=layers) if fixture == "pipeline24_spread" else syn.make_vit_weights(seed=wseed, layers=layers)
-    vit = HipCLIPVisionModel(sd, layers=layers).to(DEV)
-    W0, b0 = syn.make_head_weights(C, seed=0)
-    if "head_scale" in g.files:
-        W, b = W0 * float(g["head_scale"]), torch.from_numpy(g["head_bias"])
-    else:
-        W, b = W0, b0                                              # the head at its natural scale
-    px = syn.make_pixels(4 * NP, seed=pseed, panorama=True).to(DEV)
-    ref_emb = torch.from_numpy(g["embedding"])
-    ref_cells, ref8, cells8 = g["preds_geocell"], g["top8_logits"], g["top8_cells"]
-    sigma = g["logit_sigma"] if "logit_sigma" in g.files else np.full(NP, 4.0)
-    lines, res = [], {}
-    for mode in ("default", "exact"):
-        model = SuperGuessr(vit, panorama=True, freeze_base=True, num_candidates=50, geocell_path=gp, exact_top1=(mode == "exact"))
-        with torch.no_grad():
-            model.cell_layer.weight.copy_(W); model.cell_layer.bias.copy_(b)
-        model.to(DEV).eval()
-        out = model(pixel_values=px, labels_clf=None)
-        emb = out.embedding.cpu()
-        hip_cells = out.preds_geocell.cpu().numpy()
-        logits = ops.head_forward(out.embedding.contiguous(), model.cell_layer.weight.data, model.cell_layer.bias.data,
-                                  model.lla_geocells.data, 50)["logits"].cpu().numpy()
-        hip8 = np.take_along_axis(logits, cells8, axis=1)
-        err = np.abs(hip8 - ref8).max(axis=1)
-        dmargin = np.abs((hip8[:, 0] - hip8[:, 1]) - (ref8[:, 0] - ref8[:, 1]))
-        sens = (model.last_bound / (model.margin_kappa * (model.margin_rel_tol if mode == "default" else 1.0))).cpu().numpy()
-        certain = model.last_certain.cpu().numpy()
-        re = model.last_reencoded.cpu().numpy()
-        flips = np.nonzero(hip_cells != ref_cells)[0]
-        res[mode] = dict(flips=flips, certain=certain, re=re, emb_err=_rel(emb, ref_emb), err=err, dmargin=dmargin, sens=sens,
-                         margin=model.last_margin.cpu().numpy())
-        lines.append(f"{fixture} [{mode}]: embedding rel err {res[mode]['emb_err']:.2e}; logit error max {err.max():.5f} = "
-                     f"{(err / sigma).max():.2e} sigma(logit); flips {len(flips)}/{NP} {[int(i) for i in flips]}; "
-                     f"certain {int(certain.sum())}/{NP} (certain_frac {certain.mean():.3f}); re-encoded {len(re)} {[int(i) for i in re]}")
-        if mode == "default":
-            # calibration of the certainty bound: the margin change actually observed, in units of sens = |e| |w1 - w2| / 32
-            ratio = dmargin / np.maximum(sens, 1e-30)
-            lines.append(f"   margin change / sens: max {ratio.max():.2e}, median {np.median(ratio):.2e}  (bound = kappa {model.margin_kappa:g} x "
-                         f"rel_tol {model.margin_rel_tol:g} = {model.margin_kappa * model.margin_rel_tol:.1e}); reference margin / sigma: min "
-                         f"{(g['logit_margin'] / sigma).min():.2e}, median {np.median(g['logit_margin'] / sigma):.2e}; "
-                         f"panoramas below 3 x the logit error: {int((g['logit_margin'] < 3 * err.max()).sum())}")
-        for i in flips:
-            lines.append(f"   flip at panorama {int(i)}: reference margin {g['logit_margin'][i]:.6f} = {g['logit_margin'][i] / sigma[i]:.2e} sigma, "
-                         f"certain = {bool(certain[i])}")
-    with capsys.disabled():
-        print("\n" + "\n".join(lines))
-    _report(lines, f"{fixture}_exact_report.txt")
-    d, x = res["default"], res["exact"]
-    assert d["emb_err"] < 1e-3
-    # the certainty signal is sound: no flip among the panoramas the default mode calls certain ...
-    assert not [int(i) for i in d["flips"] if d["certain"][i]], "a panorama flagged certain flipped"
-    # ... the exact mode re-encoded exactly the uncertain ones, and agrees with the fp32 reference everywhere
-    assert set(x["re"].tolist()) == set(np.nonzero(~d["certain"])[0].tolist())
-    assert len(x["flips"]) == 0, f"exact mode: top-1 differs from the reference at {x['flips']}"
-    assert x["certain"].all(), "a re-encoded panorama is still inside the (1e-5-scale) error band of the exact mode"
-    if len(x["re"]):
-        pe = out.embedding.cpu()[x["re"]]
-        assert _rel(pe, ref_emb[x["re"]]) < EXACT_TOL
-    return res
-
-
-def test_exact_top1_pipeline24_wide(env, golden_dir, tmp_path, capsys):
-    """The 128-panorama default-init fixture (collinear embeddings, head centred and scaled to sigma = 4)."""
-    _top1_run(env, golden_dir, tmp_path, "pipeline24_wide", capsys)
-
-
-def test_exact_top1_pipeline24_spread(env, golden_dir, tmp_path, capsys):
-    """The 128-panorama SPREAD fixture (trained-like embeddings, cos-sim ~0.7; head at its natural scale)."""
-    g = np.load(os.path.join(golden_dir, "pipeline24_spread.npz"))
-    assert g["image_cos_sim"][2] <= 0.8, "the fixture's embeddings must spread (pairwise cos-sim <= 0.8)"
-    _top1_run(env, golden_dir, tmp_path, "pipeline24_spread", capsys)
-
-
 def test_encoder_graph_replay_bit_identical(env, capsys):
     """pg_vit_forward replays the encoder body from a captured hipGraph from the second forward of a (workspace, n) key on:
     same kernels, same order -> the same bits as the eager launches; profiling switches the replay off for the call."""
@@ -305,17 +212,22 @@ def test_exact_mode_edges(env, tmp_path, capsys):
         return m.to(DEV).eval()
     px = syn.make_pixels(12, seed=3).to(DEV)
     # single images, everything uncertain (kappa huge) -> every sample re-encoded: embeddings == the exact encoder's, bit for bit
-    m = model(panorama=False, exact_top1=True, margin_kappa=1e9)
+    m = model(panorama=False, exact_top1=True, margin_kappa=1e9, margin_autocalibrate=False)
     out = m(pixel_values=px, labels_clf=None)
     assert m.last_reencoded.numel() == 12
     want = vit._encoder(torch.device(DEV)).forward_precise(px)
     assert torch.equal(out.embedding, want)
     # ... nothing uncertain (kappa 0): the fast path's outputs, no exact pass
-    m0 = model(panorama=False, exact_top1=True, margin_kappa=0.0)
+    m0 = model(panorama=False, exact_top1=True, margin_kappa=0.0, margin_autocalibrate=False)
     out0 = m0(pixel_values=px, labels_clf=None)
     assert m0.last_reencoded.numel() == 0 and torch.equal(out0.embedding, vit.embed(px)) and bool(m0.last_certain.all())
+    # the exact mode is the product default; PIGEON_EXACT_TOP1=0 / exact_top1=False is the opt-out, which still reports certainty
+    assert model(panorama=False).exact_top1 is True
+    mf = model(panorama=False, exact_top1=False, margin_kappa=1e9)
+    outf = mf(pixel_values=px, labels_clf=None)
+    assert mf.last_reencoded.numel() == 0 and torch.equal(outf.embedding, vit.embed(px)) and not bool(mf.last_certain.any())
     # panoramas with fp16 pixels (what pg_prep_forward hands over) + the serving tuple
-    mp = model(panorama=True, serving=True, exact_top1=True, margin_kappa=1e9)
+    mp = model(panorama=True, serving=True, exact_top1=True, margin_kappa=1e9, margin_autocalibrate=False)
     px16 = px.half().reshape(3, 12, 336, 336)
     llh, topk, emb = mp(pixel_values=px16)
     assert emb.shape == (3, 4, 1024) and mp.last_reencoded.tolist() == [0, 1, 2]
@@ -323,10 +235,16 @@ def test_exact_mode_edges(env, tmp_path, capsys):
     # exactness claim on the panorama path: agrees with the oracle's embedding of the SAME (fp16-rounded) pixels to 1e-5
     ref = env["orc"].clip_embedding(sd, px.half().float().cpu())
     assert _rel(emb.reshape(12, 1024).cpu(), ref) < EXACT_TOL
-    # auto-calibration: after >= 8 re-encoded samples the bound follows the measured fast-vs-exact difference
-    assert m._cal_n == 12 and 1e-5 < m.margin_rel_tol < 1e-3
-    rms = (m._cal_sumsq / m._cal_n) ** 0.5
-    assert abs(m.margin_rel_tol - 1.25 * rms) < 1e-12 and 1e-4 < rms < 5e-4
+    # calibration: explicit, or by the first forward that sees >= 8 samples; frozen afterwards (later batches do not move it)
+    assert not m.certainty.calibrated and m.margin_rel_tol == 1e-3
+    mc = model(panorama=False, exact_top1=True)
+    mc(pixel_values=px, labels_clf=None)
+    st = dict(mc.certainty.stats)
+    assert mc.certainty.calibrated and st["samples"] == 12 and 1e-5 < mc.margin_rel_tol < 1e-3 and 1e-4 < st["fast_vs_exact_rms"] < 5e-4
+    mc(pixel_values=px.flip(0).contiguous(), labels_clf=None)
+    assert mc.certainty.stats == st
+    rms = mc.calibrate_certainty(px[:8])
+    assert mc.certainty.stats["samples"] == 8 and abs(rms - mc.certainty.stats["fast_vs_exact_rms"]) < 1e-12
     # bf16 operands on the fast path: the exact pass is unaffected
     vb = HipCLIPVisionModel(sd, layers=2).to(DEV)
     vb.enable_precise(True)
