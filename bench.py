@@ -639,32 +639,75 @@ def secondary_baseline(dev, vit_sd, layers):
 
 
 # ------------------------------------------------------------------------------------------------------ dry-run stubs
+def _cause_counts(causes):
+    """certain_forward's `cause` codes of the timed steps -> {cause: panoramas}, summed over the steps."""
+    names = {1: "head top-1", 2: "refiner: candidate-set boundary", 3: "refiner: nearest prototype", 4: "refiner: farthest member"}
+    out = {}
+    for c in causes:
+        for v in c[c != 0].tolist():
+            key = "head top-1" if v == 1 else ("refiner: winning candidate" if 1000 <= v < 2000 else
+                                               names.get(v // 1000, "refiner: fp32 underflow" if v == -9 else f"code {v}"))
+            out[key] = out.get(key, 0) + 1
+    return out
+
+
 def _dry_stubs(args):
-    """CPU stand-ins with the call surface PanoramaPipeline uses (pigeon_amd.SuperGuessr / ProtoRefiner on this path).  They
-    exist so that the launch / shard / gather / restore-order / timing / JSON control flow can be exercised without a GPU
-    (tests/test_bench_dry_run.py); nothing here is a fallback of the product: the real run never constructs them."""
+    """CPU stand-ins with the call surface PanoramaPipeline / certain_forward use (pigeon_amd.SuperGuessr / ProtoRefiner on this
+    path).  They exist so that the launch / shard / gather / restore-order / timing / JSON control flow -- INCLUDING the exact mode's
+    data-dependent part: rank r finds r panoramas uncertain per step and pays 2 ms per re-encoded panorama, so the ranks reach the
+    all-gather at different times -- can be exercised without a GPU (tests/test_bench_dry_run.py); nothing here is a fallback of the
+    product: the real run never constructs them."""
     import torch
+    from pigeon_amd.certainty import Certainty
     from pigeon_amd.utils import ModelOutput, TopK
     g = torch.Generator().manual_seed(5)
     P = torch.randn((3, 1024), generator=g)
     W = torch.randn((args.cells, 1024), generator=g) * 0.05
     cen = torch.rand((args.cells, 2), generator=g, dtype=torch.float64) * 100
     k = args.topk
+    rank = int(os.environ.get("RANK", "0"))
 
     class Model:
         cell_layer = torch.nn.Linear(1024, args.cells)
         lla_geocells = torch.nn.Parameter(cen, requires_grad=False)
+        exact_top1 = not args.fast
+        num_candidates = k
+        certainty = Certainty()
+        last_margin = last_bound = last_certain = None
 
-        def __call__(self, pixel_values=None, labels_clf=None):
+        def wstats(self, exact=False):
+            return torch.stack([W.norm(dim=1).max(), torch.zeros(())])
+
+        def encode_head(self, pixel_values=None, embedding=None):
             B = pixel_values.shape[0]
             emb = pixel_values.reshape(B, 4, 3, -1).float().mean(dim=-1) @ P                    # (B,4,1024)
             probs = torch.softmax(emb.mean(dim=1) @ W.t(), dim=-1)
-            top = torch.topk(probs, k, dim=-1)
+            top = torch.topk(probs, k + min(4, max(0, args.cells - k)), dim=-1)           # k > cells raises, as the real head does
             cells = top.indices[:, 0].contiguous()
-            return ModelOutput(None, None, 0, 0, 0, cen[cells], cells, None, None, None, TopK(top.values, top.indices), emb)
+            certain = torch.ones(B, dtype=torch.bool)
+            certain[:min(rank, B)] = False                                                      # rank r: r uncertain panoramas per step
+            return dict(embedding=emb, head_in=emb, pixel_values=pixel_values, topk_values=top.values, topk_indices=top.indices,
+                        preds_geocell=cells, preds_LLH=cen[cells], tol=certain.float(), certain=certain, exact=torch.zeros_like(certain),
+                        reencoded=torch.empty((0,), dtype=torch.int64), margin=certain.float(), sens=certain.float())
+
+        def reencode_rows(self, st, idx):
+            if idx.numel():
+                time.sleep(2e-3 * idx.numel())                                                  # the exact tier's cost, per panorama
+                st["certain"][idx] = True
+                st["exact"][idx] = True
+                st["reencoded"] = idx
+
+        def package(self, st, labels=None, labels_clf=None):
+            return ModelOutput(None, None, 0, 0, 0, st["preds_LLH"], st["preds_geocell"], None, None, None,
+                               TopK(st["topk_values"][:, :k], st["topk_indices"][:, :k]), st["embedding"])
 
     class Refiner:
         last_scratch = None
+
+        def forward_certain(self, emb, initial_preds, candidate_cells, candidate_probs, head_weight, wstats, drift=None):
+            B = emb.shape[0]
+            return ((initial_preds + 0.25).float(), candidate_cells[:, min(1, k - 1)].contiguous(), torch.full((B,), 1e9),
+                    torch.zeros(B, dtype=torch.int32), True)
 
         def __call__(self, emb, initial_preds=None, candidate_cells=None, candidate_probs=None, quiet=False):
             return None, (initial_preds + 0.25).float(), candidate_cells[:, min(1, k - 1)].contiguous()
@@ -818,8 +861,8 @@ def _worker(args, comm):
     for i in range(args.steps):
         out = pipe.step(pixel_batches[i % nb], index)
         outs_by_batch[i % nb] = out                               # references only; read after the timed region
+        info_by_step.append(pipe.last_info)                        # device tensors; read after the timed region
         if not dry:
-            info_by_step.append(pipe.last_info)                    # device tensors; read after the timed region
             certain_by_batch[i % nb] = (pipe.last_info["certain"], model.last_margin, model.last_bound)
         if refiner is not None and not dry:
             refine_rows.append(refiner.last_scratch)             # device tensor kept; summed after the timed region
@@ -1064,6 +1107,7 @@ def _worker(args, comm):
         "rule": model.certainty.describe(), "calibration": model.certainty.stats,
         "reencoded_panoramas_per_step": n_re, "panoramas_per_step": args.panoramas,
         "uncertain_after_step": [int((~c).sum()) for c in cert_all],
+        "uncertain_by_cause": _cause_counts([inf["cause"] for inf in info_by_step if inf is not None]),
         "boundary_checked": bool(info_by_step and info_by_step[-1] is not None and info_by_step[-1].get("boundary_checked"))}
     if world == 1 and args.fast_steps > 0:
         try:

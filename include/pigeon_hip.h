@@ -188,13 +188,15 @@ int pg_head_margin(const float* logits, int B, int C, const float* emb, int P, c
  * may be NULL), r of relative RMS norm eps in an unknown direction.  Per row,
  *   tol  DEVICE (B) fp32 out = min over cells c != top1 of (logit(top1) - logit(c) - |e| g.beta) / (|e| |g| / 32),  g = W[top1] - W[c]:
  *        the largest eps, in standard deviations of the margin change, that the reference's argmax (models/super_guessr.py:454) survives;
- *        the cells are the kx listed in topk_idx (as pg_head_forward wrote them, descending) and, bounded with |g| <= |W[top1]| +
- *        *wnorm_max and the list's last logit, every cell not listed.  The host calls a row certain when tol > kappa * eps.
+ *        the cells are the kx listed in topk_idx (as pg_head_forward wrote them, descending) and -- bounded with the list's last logit,
+ *        |g| <= |W[top1]| + wstats[0] and g.beta <= W[top1].beta + wstats[1] -- every cell not listed.  The host calls a row certain
+ *        when tol > kappa * eps.
  *   code DEVICE (B) int32 out: the list position j >= 1 that sets tol, -1 = the cells beyond the list, -2 = bad index in the list
  *   margin, sens DEVICE (B) fp32 out, may be NULL: pg_head_margin's pair (top-1 against top-2), for reports
- *   wnorm_max DEVICE (1) fp32: the largest row norm of W.   Limits: 1 <= kx <= C; kx == C: nothing beyond the list. */
+ *   wstats DEVICE (2) fp32: [0] the largest row norm of W, [1] max over cells of |W[c].beta| (0 without beta).
+ *   Limits: 1 <= kx <= C; kx == C: nothing beyond the list. */
 int pg_head_certainty(const float* logits, int B, int C, const float* emb, int P, const float* W, const int64_t* topk_idx, int kx,
-                      const float* beta, const float* wnorm_max, float* tol, int32_t* code, float* margin, float* sens, void* stream);
+                      const float* beta, const float* wstats, float* tol, int32_t* code, float* margin, float* sens, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * ProtoRefiner prototype-distance refinement over a CSR prototype bank.
@@ -251,12 +253,12 @@ int pg_refine_forward_ex(const pg_bank* bank, const float* q, int B, int P, cons
  * beyond the evaluated ones (getting in counts; only when n_eval > topk, i.e. when the caller supplied candidates past the set), and
  * for the refined and the finally chosen candidate the nearest-prototype and farthest-member picks.  The haversine veto compares
  * two discrete points and has no margin.   W (C,1024) = the head's weights (the candidates' log-probabilities move with the
- * embedding through them), wnorm_max as above, refined / choice as pg_refine_forward_ex wrote them.
+ * embedding through them), wstats as above, refined / choice as pg_refine_forward_ex wrote them.
  *   tol DEVICE (B) fp32 out;  code DEVICE (B) int32 out: 1000 + j / 2000 + j / 2999 / 3000 + w / 4000 + w (see csrc/certainty.hip), -9 = the
  *   winning product underflows in fp32 (uncertain), 0 = nothing can change the row.   Limits: topk <= 64, n_eval <= min(k, 96). */
 int pg_refine_certainty(const pg_bank* bank, const float* q, int B, int P, const int64_t* cand, const float* cand_prob, int k,
                         int topk, int n_eval, const float* scratch12, const float* W, int C, const float* beta,
-                        const float* wnorm_max, float temperature, const int32_t* refined, const int32_t* choice,
+                        const float* wstats, float temperature, const int32_t* refined, const int32_t* choice,
                         float* tol, int32_t* code, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

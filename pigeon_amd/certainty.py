@@ -66,7 +66,7 @@ class Certainty:
                 drift = rel.mean(dim=0).contiguous()
                 st['drift_used'] = True
         eps = st['residual_rms'] if drift is not None else total
-        self.rel_tol = max(safety * eps, 4.0 * self.rel_tol_exact)
+        self.rel_tol = max(safety * eps, 2.0 * self.rel_tol_exact)
         self.drift = drift
         self.calibrated = True
         st['rel_tol'] = self.rel_tol

@@ -104,7 +104,7 @@ __device__ __forceinline__ MinTol block_min(MinTol v, float* red_t, int* red_c) 
 // code: j >= 1 = the candidate that sets the tolerance, -1 = the cells beyond the list
 __global__ __launch_bounds__(256) void head_certainty_kernel(const float* __restrict__ logits, int C, const float* __restrict__ emb, int P,
                                                              const float* __restrict__ W, const int64_t* __restrict__ topk_idx, int kx,
-                                                             const float* __restrict__ beta, const float* __restrict__ wnorm_max,
+                                                             const float* __restrict__ beta, const float* __restrict__ wstats,
                                                              float* __restrict__ tol, int32_t* __restrict__ code,
                                                              float* __restrict__ margin, float* __restrict__ sens) {
     __shared__ float red_t[4];
@@ -113,8 +113,7 @@ __global__ __launch_bounds__(256) void head_certainty_kernel(const float* __rest
     f32x4 ev[4], bv[4];
     panel_mean16(emb + (int64_t)b * P * CT_DIM, P, lane, ev);
     const float en = sqrtf(dot16(ev, ev));
-    float bn = 0.f;
-    if (beta) { ld16(beta, lane, bv); bn = sqrtf(dot16(bv, bv)); } else zero16(bv);
+    if (beta) ld16(beta, lane, bv); else zero16(bv);
     const int64_t* idx = topk_idx + (int64_t)b * kx;
     const float* row = logits + (int64_t)b * C;
     const int64_t c0 = idx[0];
@@ -138,15 +137,16 @@ __global__ __launch_bounds__(256) void head_certainty_kernel(const float* __rest
             if (j == 1 && lane == 0) { if (margin) margin[b] = m; if (sens) sens[b] = en * sqrtf(g2) * (1.0f / 32.0f); }
         }
         if (wave == 0 && kx < C) {
-            // cells beyond the list: logit <= the list's last, |W[c0] - W[c]| <= |W[c0]| + max row norm, drift bounded by Cauchy-Schwarz
+            // cells beyond the list: logit <= the list's last, |W[c0] - W[c]| <= |W[c0]| + the largest row norm (wstats[0]), and the
+            // systematic part (W[c0] - W[c]).beta <= W[c0].beta + max_c |W[c].beta| (wstats[1], computed once per calibration)
             const int64_t ck = idx[kx - 1];
             float t = 0.f;
             if (ck >= 0 && ck < C) {
                 f32x4 g[4];
                 zero16(g);
                 axpy16(g, W + c0 * CT_DIM, 1.f, lane);
-                const float gmax = sqrtf(dot16(g, g)) + wnorm_max[0];
-                t = tol_of(l0 - row[ck], gmax * gmax, gmax * bn, en);
+                const float gmax = sqrtf(dot16(g, g)) + wstats[0];
+                t = tol_of(l0 - row[ck], gmax * gmax, dot16(g, bv) + wstats[1], en);
             }
             best.take(t, -1);
         }
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void refine_certainty_kernel(pg_bank bank, con
                                                                const int64_t* __restrict__ cand, const float* __restrict__ cand_prob,
                                                                int k, int topk, int n_eval, const float* __restrict__ scratch12,
                                                                const float* __restrict__ W, int C, const float* __restrict__ beta,
-                                                               const float* __restrict__ wnorm_max, float temperature,
+                                                               const float* __restrict__ wstats, float temperature,
                                                                const int32_t* __restrict__ refined, const int32_t* __restrict__ choice,
                                                                float* __restrict__ tol, int32_t* __restrict__ code) {
     __shared__ float L[CT_MAX_EVAL], S[CT_MAX_EVAL];
@@ -195,8 +195,7 @@ __global__ __launch_bounds__(256) void refine_certainty_kernel(pg_bank bank, con
     f32x4 ev[4], bv[4];
     panel_mean16(q + (int64_t)b * P * CT_DIM, P, lane, ev);
     const float en = sqrtf(dot16(ev, ev));
-    float bn = 0.f;
-    if (beta) { ld16(beta, lane, bv); bn = sqrtf(dot16(bv, bv)); } else zero16(bv);
+    if (beta) ld16(beta, lane, bv); else zero16(bv);
 
     auto wrow = [&](int64_t c) -> const float* { return (c >= 0 && c < C) ? W + c * CT_DIM : nullptr; };
     // tolerance of "candidate a stays ahead of candidate j in s = log p - d / T"
@@ -247,12 +246,12 @@ __global__ __launch_bounds__(256) void refine_certainty_kernel(pg_bank bank, con
         }
         if (n_eval > topk && n_eval < C && (task++ & 3) == wave) {
             // cells beyond the evaluated ones: their log-probability is <= the last evaluated one's; nothing is known about their
-            // prototypes, so getting into the set already counts
+            // prototypes, so getting into the set already counts (bounds as in head_certainty_kernel: wstats)
             f32x4 g[4];
             zero16(g);
             axpy16(g, wrow(cd[topk - 1]), 1.f, lane);
-            const float gmax = sqrtf(dot16(g, g)) + wnorm_max[0];
-            best.take(tol_of(L[topk - 1] - L[n_eval - 1], gmax * gmax, gmax * bn, en), 2999);
+            const float gmax = sqrtf(dot16(g, g)) + wstats[0];
+            best.take(tol_of(L[topk - 1] - L[n_eval - 1], gmax * gmax, dot16(g, bv) + wstats[1], en), 2999);
         }
         for (int which = 0; which < 2; ++which) {            // the discrete picks inside the refined / the finally chosen candidate
             const int x = which == 0 ? r : ch;
@@ -273,24 +272,24 @@ __global__ __launch_bounds__(256) void refine_certainty_kernel(pg_bank bank, con
 }  // namespace
 
 extern "C" int pg_head_certainty(const float* logits, int B, int C, const float* emb, int P, const float* W, const int64_t* topk_idx,
-                                 int kx, const float* beta, const float* wnorm_max, float* tol, int32_t* code, float* margin,
+                                 int kx, const float* beta, const float* wstats, float* tol, int32_t* code, float* margin,
                                  float* sens, void* stream) {
     if (B < 0) { pg_set_error("head_certainty: B = %d", B); return PG_EINVAL; }
     if (B == 0) return PG_OK;
-    if (!logits || !emb || !W || !topk_idx || !wnorm_max || !tol || !code) { pg_set_error("head_certainty: null pointer argument"); return PG_EINVAL; }
+    if (!logits || !emb || !W || !topk_idx || !wstats || !tol || !code) { pg_set_error("head_certainty: null pointer argument"); return PG_EINVAL; }
     if (P < 1 || C < 1 || kx < 1 || kx > C) { pg_set_error("head_certainty: bad P=%d C=%d kx=%d", P, C, kx); return PG_EINVAL; }
     hipLaunchKernelGGL(head_certainty_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, C, emb, P, W, topk_idx, kx, beta,
-                       wnorm_max, tol, code, margin, sens);
+                       wstats, tol, code, margin, sens);
     return pg_check_launch("head_certainty");
 }
 
 extern "C" int pg_refine_certainty(const pg_bank* bank, const float* q, int B, int P, const int64_t* cand, const float* cand_prob, int k,
                                    int topk, int n_eval, const float* scratch12, const float* W, int C, const float* beta,
-                                   const float* wnorm_max, float temperature, const int32_t* refined, const int32_t* choice, float* tol,
+                                   const float* wstats, float temperature, const int32_t* refined, const int32_t* choice, float* tol,
                                    int32_t* code, void* stream) {
     if (B < 0) { pg_set_error("refine_certainty: B = %d", B); return PG_EINVAL; }
     if (B == 0) return PG_OK;
-    if (!bank || !q || !cand || !scratch12 || !W || !wnorm_max || !refined || !choice || !tol || !code) {
+    if (!bank || !q || !cand || !scratch12 || !W || !wstats || !refined || !choice || !tol || !code) {
         pg_set_error("refine_certainty: null pointer argument"); return PG_EINVAL;
     }
     if (topk < 1 || topk > 64 || n_eval < topk || n_eval > k || n_eval > CT_MAX_EVAL || P < 1 || C < 1 || !(temperature > 0.f)) {
@@ -299,6 +298,6 @@ extern "C" int pg_refine_certainty(const pg_bank* bank, const float* q, int B, i
         return PG_EINVAL;
     }
     hipLaunchKernelGGL(refine_certainty_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, *bank, q, P, cand, cand_prob, k, topk, n_eval,
-                       scratch12, W, C, beta, wnorm_max, temperature, refined, choice, tol, code);
+                       scratch12, W, C, beta, wstats, temperature, refined, choice, tol, code);
     return pg_check_launch("refine_certainty");
 }

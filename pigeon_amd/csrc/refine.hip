@@ -58,8 +58,12 @@ struct Top2 {
     __device__ __forceinline__ void clear() { d1 = d2 = INFINITY; i1 = i2 = RF_SENT; }
     __device__ __forceinline__ void push(float d, long long i) {
         if (i == RF_SENT) return;
-        if (i1 == RF_SENT || nan_aware_less(d, i, d1, i1)) { d2 = d1; i2 = i1; d1 = d; i1 = i; }
-        else if (i2 == RF_SENT || nan_aware_less(d, i, d2, i2)) { d2 = d; i2 = i; }
+        const bool first = i1 == RF_SENT || nan_aware_less(d, i, d1, i1);
+        const bool second = i2 == RF_SENT || nan_aware_less(d, i, d2, i2);
+        const float nd2 = first ? d1 : (second ? d : d2);
+        const long long ni2 = first ? i1 : (second ? i : i2);
+        d1 = first ? d : d1; i1 = first ? i : i1;
+        d2 = nd2; i2 = ni2;
     }
 };
 
@@ -75,7 +79,8 @@ __global__ __launch_bounds__(256) void refine_candidates_kernel(pg_bank bank, co
                                                                 const int64_t* __restrict__ cand, int k, int topk,
                                                                 float* __restrict__ scratch) {
     constexpr int SC = EXT ? 12 : 4;
-    __shared__ Top2 red[4];
+    __shared__ float red_d[8];                              // per wave: best, runner-up (plain arrays: no struct copies through LDS)
+    __shared__ long long red_i[8];
     __shared__ long long chosen;
     const int b = blockIdx.x / topk, j = blockIdx.x % topk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -140,11 +145,11 @@ __global__ __launch_bounds__(256) void refine_candidates_kernel(pg_bank bank, co
         }
         for (; r < e; r += 4) near.push(sqrtf(row_sqdist(bank.proto_emb + r * RF_DIM, lane, qv)), r);
     }
-    if (lane == 0) red[wave] = near;
+    if (lane == 0) { red_d[2 * wave] = near.d1; red_i[2 * wave] = near.i1; red_d[2 * wave + 1] = near.d2; red_i[2 * wave + 1] = near.i2; }
     __syncthreads();
     if (tid == 0) {
-        Top2 m = red[0];
-        for (int w = 1; w < 4; ++w) { m.push(red[w].d1, red[w].i1); m.push(red[w].d2, red[w].i2); }
+        Top2 m; m.clear();
+        for (int x = 0; x < 8; ++x) m.push(red_d[x], red_i[x]);
         chosen = m.i1;
         outp[0] = -m.d1;                                    // score = max(-distance)
         if (EXT) {
@@ -180,11 +185,11 @@ __global__ __launch_bounds__(256) void refine_candidates_kernel(pg_bank bank, co
         far.push(-sqrtf(row_sqdist(bank.train_emb + tr * RF_DIM, lane, qv)), r);
     }
     __syncthreads();
-    if (lane == 0) red[wave] = far;
+    if (lane == 0) { red_d[2 * wave] = far.d1; red_i[2 * wave] = far.i1; red_d[2 * wave + 1] = far.d2; red_i[2 * wave + 1] = far.i2; }
     __syncthreads();
     if (tid == 0) {
-        Top2 m = red[0];
-        for (int w = 1; w < 4; ++w) { m.push(red[w].d1, red[w].i1); m.push(red[w].d2, red[w].i2); }
+        Top2 m; m.clear();
+        for (int x = 0; x < 8; ++x) m.push(red_d[x], red_i[x]);
         float lng = 0.f, lat = 0.f;
         int64_t t1 = -1, t2 = -1;
         if (m.i1 != RF_SENT) {

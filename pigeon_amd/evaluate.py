@@ -71,30 +71,36 @@ def certain_forward(model: SuperGuessr, refiner: Optional[ProtoRefiner], pixel_v
     recomputed.  One host synchronisation (the uncertain set is data dependent).  The refinement itself is left to the caller (it runs
     on the corrected embeddings / candidates: `evaluate_model` right away, `PanoramaPipeline.step` after its all-gather).
     Returns (outputs as `model.forward` returns them, info) with info = dict(certain (B,) bool: every output of the sample is the
-    reference's; reencoded (n,) int64; head_tol, refine_tol (B,) f32 or None; boundary_checked)."""
+    reference's; cause (B,) int32: why a sample was not certain after the fast pass; reencoded (n,) int64; head_tol, refine_tol (B,)
+    f32 or None; boundary_checked)."""
     st = model.encode_head(pixel_values, embedding)
     info = dict(head_tol=st['tol'], refine_tol=None, refine_code=None, boundary_checked=None)
     can_fix = model.exact_top1 and st['pixel_values'] is not None
     flag = ~st['certain']
-    k = model.num_candidates
+    # why a sample was sent to the exact tier (before anything is patched): 0 = certain, 1 = the head's top-1, else the refiner's
+    # decision code (pg_refine_certainty: 1xxx winner, 2xxx set boundary, 3xxx nearest prototype, 4xxx farthest member, -9 underflow)
+    cause = flag.to(torch.int32)
     W = model.cell_layer.weight.data
     if refiner is not None:
         _, _, rtol, rcode, checked = refiner.forward_certain(st['embedding'], st['preds_LLH'], st['topk_indices'], st['topk_values'],
-                                                            W, model.wnorm_max(), model.certainty.drift_on(W.device))
+                                                            W, model.wstats(False), model.certainty.drift_on(W.device))
         info.update(refine_tol=rtol, refine_code=rcode, boundary_checked=checked)
-        flag = flag | ~(rtol > model.certainty.threshold())
+        r_unc = ~(rtol > model.certainty.threshold())
+        cause = torch.where((cause == 0) & r_unc, rcode, cause)
+        flag = flag | r_unc
     if can_fix:
         idx = torch.nonzero(flag).flatten()                                       # the step's one host synchronisation
         model.reencode_rows(st, idx)
         if refiner is not None and idx.numel():
             # the re-encoded samples, judged again at the exact tier's floor (no systematic part there)
             _, _, rt2, rc2, _ = refiner.forward_certain(st['embedding'][idx], st['preds_LLH'][idx], st['topk_indices'][idx],
-                                                        st['topk_values'][idx], W, model.wnorm_max(), None)
+                                                        st['topk_values'][idx], W, model.wstats(True), None)
             info['refine_tol'][idx], info['refine_code'][idx] = rt2, rc2
             flag[idx] = ~st['certain'][idx] | ~(rt2 > model.certainty.threshold(exact=True))
         elif idx.numel():
             flag[idx] = ~st['certain'][idx]
     info['certain'] = ~flag
+    info['cause'] = cause
     info['reencoded'] = st['reencoded']
     out = model.package(st, labels, labels_clf)
     model.last_certain = info['certain']

@@ -472,16 +472,16 @@ def head_margin(logits: torch.Tensor, emb: torch.Tensor, W: torch.Tensor):
 
 
 def head_certainty(logits: torch.Tensor, emb: torch.Tensor, W: torch.Tensor, topk_idx: torch.Tensor,
-                   drift: Optional[torch.Tensor], wnorm_max: torch.Tensor):
+                   drift: Optional[torch.Tensor], wstats: torch.Tensor):
     """pg_head_certainty: tolerance of the top-1 against every cell.  logits (B,C) as written by head_forward, emb (B,P,1024) or
-    (B,1024), topk_idx (B,kx) int64 from the same head_forward call, drift (1024,) fp32 or None, wnorm_max (1,) fp32 = the largest
-    row norm of W.  Returns (tol (B,) f32, code (B,) i32, margin (B,) f32, sens (B,) f32)."""
+    (B,1024), topk_idx (B,kx) int64 from the same head_forward call, drift (1024,) fp32 or None, wstats (2,) fp32 = [largest row
+    norm of W, max_c |W[c].drift| (0 without drift)].  Returns (tol (B,) f32, code (B,) i32, margin (B,) f32, sens (B,) f32)."""
     _dev(logits, torch.float32); _dev(emb, torch.float32); _dev(W, torch.float32); _dev(topk_idx, torch.int64)
-    _dev(wnorm_max, torch.float32)
+    _dev(wstats, torch.float32)
     B, Cn = logits.shape
     P = emb.shape[1] if emb.dim() == 3 else 1
     _shape(emb, "emb", *((B, P, HIDDEN) if emb.dim() == 3 else (B, HIDDEN)))
-    _shape(W, "W", Cn, HIDDEN); _shape(topk_idx, "topk_idx", B, None); _shape(wnorm_max, "wnorm_max", 1)
+    _shape(W, "W", Cn, HIDDEN); _shape(topk_idx, "topk_idx", B, None); _shape(wstats, "wstats", 2)
     kx = topk_idx.shape[1]
     if drift is not None:
         _dev(drift, torch.float32); _shape(drift, "drift", HIDDEN)
@@ -490,7 +490,7 @@ def head_certainty(logits: torch.Tensor, emb: torch.Tensor, W: torch.Tensor, top
     code = torch.empty((B,), dtype=torch.int32, device=dev)
     margin = torch.empty((B,), dtype=torch.float32, device=dev)
     sens = torch.empty((B,), dtype=torch.float32, device=dev)
-    check(load().pg_head_certainty(_p(logits), B, Cn, _p(emb), P, _p(W), _p(topk_idx), kx, _p(drift), _p(wnorm_max), _p(tol), _p(code),
+    check(load().pg_head_certainty(_p(logits), B, Cn, _p(emb), P, _p(W), _p(topk_idx), kx, _p(drift), _p(wstats), _p(tol), _p(code),
                                    _p(margin), _p(sens), _stream()), "pg_head_certainty")
     return tol, code, margin, sens
 
@@ -618,18 +618,18 @@ def refine_forward_ex(bank: DeviceBank, q: torch.Tensor, init_llh: torch.Tensor,
 
 
 def refine_certainty(bank: DeviceBank, q: torch.Tensor, cand: torch.Tensor, cand_prob: Optional[torch.Tensor], topk: int,
-                     scratch12: torch.Tensor, W: torch.Tensor, drift: Optional[torch.Tensor], wnorm_max: torch.Tensor,
+                     scratch12: torch.Tensor, W: torch.Tensor, drift: Optional[torch.Tensor], wstats: torch.Tensor,
                      temperature: float, refined: torch.Tensor, choice: torch.Tensor):
     """pg_refine_certainty over the records refine_forward_ex left.  Returns (tol (B,) f32, code (B,) i32)."""
     _dev(q, torch.float32); _dev(cand, torch.int64); _dev(scratch12, torch.float32); _dev(W, torch.float32)
-    _dev(wnorm_max, torch.float32); _dev(refined, torch.int32); _dev(choice, torch.int32)
+    _dev(wstats, torch.float32); _dev(refined, torch.int32); _dev(choice, torch.int32)
     B = q.shape[0]
     P = q.shape[1] if q.dim() == 3 else 1
     k = cand.shape[1]
     n_eval = scratch12.shape[1]
     _shape(q, "q", *((B, P, HIDDEN) if q.dim() == 3 else (B, HIDDEN)))
     _shape(cand, "cand", B, k); _shape(scratch12, "scratch12", B, n_eval, 12); _shape(W, "W", None, HIDDEN)
-    _shape(refined, "refined", B); _shape(choice, "choice", B); _shape(wnorm_max, "wnorm_max", 1)
+    _shape(refined, "refined", B); _shape(choice, "choice", B); _shape(wstats, "wstats", 2)
     if cand_prob is not None:
         _dev(cand_prob, torch.float32); _shape(cand_prob, "cand_prob", B, k)
     if drift is not None:
@@ -637,7 +637,7 @@ def refine_certainty(bank: DeviceBank, q: torch.Tensor, cand: torch.Tensor, cand
     tol = torch.empty((B,), dtype=torch.float32, device=q.device)
     code = torch.empty((B,), dtype=torch.int32, device=q.device)
     check(load().pg_refine_certainty(C.byref(bank.struct), _p(q), B, P, _p(cand), _p(cand_prob), k, int(topk), int(n_eval), _p(scratch12),
-                                     _p(W), W.shape[0], _p(drift), _p(wnorm_max), float(temperature), _p(refined), _p(choice), _p(tol),
+                                     _p(W), W.shape[0], _p(drift), _p(wstats), float(temperature), _p(refined), _p(choice), _p(tol),
                                      _p(code), _stream()), "pg_refine_certainty")
     return tol, code
 

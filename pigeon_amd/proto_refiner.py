@@ -176,24 +176,53 @@ def load_refiner_cache(path: str):
     class _Shell(nn.Module):
         """stands in for any class of the reference's `models` package found in the pickle"""
 
-    # A pickle executes what it names.  The reference's cache holds: its own ProtoRefiner (-> _Shell), torch tensors / parameters /
-    # module bookkeeping, `datasets` objects (per-cell Dataset, DatasetDict, features, the in-memory Arrow table), pyarrow, numpy
-    # and plain containers.  Globals of exactly those packages are resolved; anything else (os, subprocess, builtins.eval ...)
-    # is refused by name -- evaluate() reads this file implicitly whenever the packed .npz is absent.
-    allowed_roots = ('torch', 'collections', 'datasets', 'pyarrow', 'numpy', 'pandas', 'copyreg', '_codecs', 'functools', 'dill',
-                     'multiprocess', 'fsspec', 'pathlib', 'types', 'typing')
+    # A pickle executes what it names.  This is an ALLOW-LIST, not a sandbox: it narrows what a cache file can reach to the data model a
+    # refiner cache really holds -- the reference's own ProtoRefiner (-> _Shell), torch tensor / parameter reconstruction, `datasets`
+    # tables and features, pyarrow / numpy / pandas array reconstruction, plain containers -- by exact module and, where a module also
+    # exports callables that do more than build data, by exact name.  Dotted names (attribute chains such as `Dataset.load_from_disk`)
+    # are refused, and so is everything else (os, subprocess, builtins.getattr / eval, types, functools, dill, multiprocess ...).
+    # Only load caches you (or the reference on this machine) wrote; the packed `.npz` bank (`HostBank.save`) needs no pickle at all.
+    _any = None
+    allowed = {
+        'collections': {'OrderedDict', 'defaultdict'},
+        '_codecs': {'encode'},
+        'copyreg': {'_reconstructor'},
+        'numpy': {'dtype', 'ndarray'},
+        'numpy.core.multiarray': {'_reconstruct', 'scalar'}, 'numpy._core.multiarray': {'_reconstruct', 'scalar'},
+        'numpy.core.numeric': {'_frombuffer'}, 'numpy._core.numeric': {'_frombuffer'},
+        'torch._utils': {'_rebuild_tensor', '_rebuild_tensor_v2', '_rebuild_parameter', '_rebuild_parameter_with_state'},
+        'torch': {'FloatStorage', 'DoubleStorage', 'HalfStorage', 'BFloat16Storage', 'LongStorage', 'IntStorage', 'ShortStorage',
+                  'CharStorage', 'ByteStorage', 'BoolStorage', 'Size', 'device'},
+        'torch.storage': {'UntypedStorage', 'TypedStorage', '_load_from_bytes'},
+        'torch.nn.parameter': {'Parameter'},
+        'datasets.arrow_dataset': {'Dataset'}, 'datasets.dataset_dict': {'DatasetDict'},
+        'datasets.features.features': _any, 'datasets.features': _any, 'datasets.info': _any, 'datasets.table': _any,
+        'datasets.splits': _any, 'datasets.utils.version': _any, 'datasets.naming': _any,
+        'pyarrow.lib': _any,
+        'pandas.core.frame': {'DataFrame'}, 'pandas.core.series': {'Series'},
+        'pandas._libs.internals': {'_unpickle_block'}, 'pandas.core.internals.managers': {'BlockManager', 'SingleBlockManager'},
+        'pandas.core.internals.blocks': {'new_block'},
+        'pandas.core.indexes.base': {'Index', '_new_Index'}, 'pandas.core.indexes.range': {'RangeIndex'},
+        'pandas.core.indexes.numeric': {'Int64Index', 'Float64Index'},
+    }
     allowed_builtins = {'set', 'frozenset', 'list', 'dict', 'tuple', 'bytes', 'bytearray', 'str', 'int', 'float', 'bool', 'complex',
-                        'slice', 'range', 'object', 'getattr', 'NoneType'}
+                        'slice', 'range', 'NoneType'}
 
     class _Unpickler(pickle.Unpickler):
         def find_class(self, module, name):
             if module == 'models' or module.startswith('models.'):
                 return _Shell
-            root = module.split('.')[0]
-            if root in allowed_roots or (module in ('builtins', '__builtin__') and name in allowed_builtins):
+            ok = False
+            if '.' not in name:
+                if module in ('builtins', '__builtin__'):
+                    ok = name in allowed_builtins
+                elif module in allowed:
+                    ok = allowed[module] is _any or name in allowed[module]
+            if ok:
                 return super().find_class(module, name)
-            raise pickle.UnpicklingError(f'refiner cache {path!r} names {module}.{name}: not a class a refiner cache holds '
-                                         f'(allowed: the reference\'s models.*, {", ".join(allowed_roots)}, plain containers)')
+            raise pickle.UnpicklingError(f'refiner cache {path!r} names {module}.{name}: not part of the data model a refiner cache holds '
+                                         f'(the reference\'s models.*, torch / numpy / pandas / pyarrow / datasets array and table '
+                                         f'reconstruction, plain containers)')
 
     pm = types.ModuleType('pigeon_amd._refiner_pickle')
     pm.Unpickler = _Unpickler
@@ -289,7 +318,7 @@ class ProtoRefiner(nn.Module):
 
     @torch.no_grad()
     def forward_certain(self, embedding: Tensor, initial_preds: Tensor, candidate_cells: Tensor, candidate_probs: Tensor,
-                        head_weight: Tensor, wnorm_max: Tensor, drift: Tensor = None):
+                        head_weight: Tensor, wstats: Tensor, drift: Tensor = None):
         """`forward` plus the TOLERANCE of its discrete outputs against an embedding error (round 5; error model:
         pigeon_amd/certainty.py, kernels: pg_refine_forward_ex + pg_refine_certainty).  `candidate_cells` / `candidate_probs` may hold
         more than `topk` candidates (SuperGuessr computes `num_candidates + 4`): up to 4 of those beyond `topk` are evaluated too --
@@ -310,6 +339,6 @@ class ProtoRefiner(nn.Module):
         T = self._temperature_value()
         llh, cell, choice, refined, scratch = hip_ops.refine_forward_ex(bank, q, init, cand, probs, self.topk, n_eval, T,
                                                                        float(self.max_refinement))
-        tol, code = hip_ops.refine_certainty(bank, q, cand, probs, self.topk, scratch, head_weight, drift, wnorm_max, T, refined, choice)
+        tol, code = hip_ops.refine_certainty(bank, q, cand, probs, self.topk, scratch, head_weight, drift, wstats, T, refined, choice)
         self.last_scratch = scratch[:, :self.topk, :4]
         return llh, cell, tol, code, n_eval > self.topk

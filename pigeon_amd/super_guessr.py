@@ -98,7 +98,7 @@ class SuperGuessr(nn.Module):
         self._freeze_params()
         self.loss_fnc = nn.CrossEntropyLoss()
         self._hip_base = None
-        self._wnorm = None                                   # (key, device tensor): largest row norm of cell_layer.weight
+        self._wnorm = {}                                     # exact? -> (key, device tensor): see wstats()
         if self.exact_top1 and isinstance(self.base_model, HipCLIPVisionModel):
             self.base_model.enable_precise(True)             # pack the split-weight copy with the first build, not inside a request
         print(f'Initialized SuperGuessr classification model with {self.num_cells} geocells.')
@@ -192,14 +192,22 @@ class SuperGuessr(nn.Module):
             return one_hot
         return tensor
 
-    def wnorm_max(self) -> Tensor:
-        """(1,) fp32 on the head's device: the largest row norm of cell_layer.weight (bounds |W[a] - W[c]| for the cells the certainty
-        pass does not visit one by one); recomputed when the weight tensor changes (in-place edits bump its version)."""
+    def wstats(self, exact: bool = False) -> Tensor:
+        """(2,) fp32 on the head's device: [largest row norm of cell_layer.weight, max over cells of |W[c] . drift|] -- what bounds
+        |W[a] - W[c]| and (W[a] - W[c]).drift for the cells the certainty pass does not visit one by one.  `exact`: the exact tier has
+        no systematic part (second entry 0).  Recomputed when the weight tensor (in-place edits bump its version) or the calibrated
+        drift changes."""
         W = self.cell_layer.weight
-        key = (W.data_ptr(), W._version, str(W.device))
-        if self._wnorm is None or self._wnorm[0] != key:
-            self._wnorm = (key, W.data.float().norm(dim=1).max().reshape(1).contiguous())
-        return self._wnorm[1]
+        drift = None if exact else self.certainty.drift_on(W.device)
+        key = (W.data_ptr(), W._version, str(W.device), None if drift is None else (drift.data_ptr(), drift._version))
+        hit = self._wnorm.get(exact) if isinstance(self._wnorm, dict) else None
+        if hit is None or hit[0] != key:
+            Wf = W.data.float()
+            wb = (Wf @ drift).abs().max() if drift is not None else torch.zeros((), device=W.device)
+            if not isinstance(self._wnorm, dict):
+                self._wnorm = {}
+            self._wnorm[exact] = (key, torch.stack([Wf.norm(dim=1).max(), wb.float()]).contiguous())
+        return self._wnorm[exact][1]
 
     def _panels(self) -> int:
         return 4 if self.panorama else 1
@@ -220,7 +228,7 @@ class SuperGuessr(nn.Module):
         o = hip_ops.head_forward(head_in, W, self.cell_layer.bias.data, self.lla_geocells.data, kx)
         drift = None if exact else self.certainty.drift_on(W.device)
         o['tol'], o['code'], o['margin'], o['sens'] = hip_ops.head_certainty(o['logits'], head_in, W, o['topk_indices'], drift,
-                                                                             self.wnorm_max())
+                                                                             self.wstats(exact))
         return o
 
     @torch.no_grad()

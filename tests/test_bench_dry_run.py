@@ -60,6 +60,32 @@ def test_bench_under_torchrun():
     _check(p.stdout, 2, 2, 1, "torchrun")
 
 
+def test_bench_world8_exact_mode_with_unequal_reencodes():
+    """The 8-rank launch the driver will make on an 8-GPU node, on the CPU: 8 ranks over gloo, the exact mode's data-dependent control
+    flow with UNEQUAL work per rank (the stub model of rank r finds r panoramas uncertain per step and pays 2 ms for each: the ranks
+    reach the all-gather at different times).  Asserted: one JSON line, every rank's results on rank 0 in sample order, and the
+    per-rank split -- the straggler (rank 7) shows up as compute on its own row and as gather-wait on everybody else's."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--panoramas", "12",
+                        "--cells", "50", "--steps", "6", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=_env())
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["config"]["images_per_step"] == 12 * 4 * 8 and r["config"]["parallelism"] == "dp8"
+    assert r["gathered_results"] == {"panoramas": 96, "ranks": 8, "refined_shape": [96, 2], "complete_and_in_sample_order": True}
+    sp = r["per_rank_split_ms"]
+    assert sp["reencoded_panoramas_per_step"] == [float(i) for i in range(8)]
+    assert len(sp["compute"]) == 8 and len(sp["gather_incl_wait"]) == 8 and len(r["per_rank_ms_per_step"]) == 8
+    assert sp["compute"][7] > sp["compute"][0] + 8.0, sp            # 7 x 2 ms of exact-tier work on rank 7, none on rank 0
+    assert sp["gather_incl_wait"][0] > sp["gather_incl_wait"][7] + 4.0, sp      # ... which rank 0 spends waiting at the collective
+    # the fast mode of the same launch: nobody re-encodes, nobody waits for a straggler
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--fast", "--panoramas", "12",
+                        "--cells", "50", "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=_env())
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert r["per_rank_split_ms"]["reencoded_panoramas_per_step"] == [0.0] * 8
+
+
 def test_bench_single_rank_dry_run_and_world_mismatch():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--panoramas", "6", "--cells", "50",
                         "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=_env())

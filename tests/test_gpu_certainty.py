@@ -74,6 +74,9 @@ def test_refine_forward_ex_records(env):
                 continue
             d = (torch.from_numpy(hb.proto_emb[s:e]).double() - qm[b]).norm(dim=1)
             order = torch.argsort(d, stable=True)
+            if e - s > 1 and (p1 != s + int(order[0]) or p2 != s + int(order[1])):
+                print(f"\nrecord mismatch at (b={b}, j={j}): cell rows [{s},{e}), kernel nearest {p1} / runner-up {p2}, record {r.tolist()}, "
+                      f"distances {[round(float(x), 3) for x in d]}")
             assert p1 == s + int(order[0]) and abs(float(-r[0]) - float(d[order[0]])) < 1e-4 * float(d[order[0]])
             if e - s > 1:
                 assert p2 == s + int(order[1]) and abs(float(r[4]) - float(d[order[1]])) < 1e-4 * float(d[order[1]])
@@ -99,7 +102,7 @@ def _tol(m, g, beta, en):
     return (m - en * float(g @ beta)) / (en * np.sqrt(g2) / 32.0)
 
 
-def _head_tol_restated(logits, e, W, idx, beta, wmax):
+def _head_tol_restated(logits, e, W, idx, beta, wmax, wbmax):
     C = W.shape[0]
     en = np.linalg.norm(e)
     c0 = idx[0]
@@ -110,7 +113,7 @@ def _head_tol_restated(logits, e, W, idx, beta, wmax):
             best, code = t, j
     if len(idx) < C:
         gmax = np.linalg.norm(W[c0]) + wmax
-        t = (logits[c0] - logits[idx[-1]] - en * gmax * np.linalg.norm(beta)) / (en * gmax / 32.0)
+        t = (logits[c0] - logits[idx[-1]] - en * (float(W[c0] @ beta) + wbmax)) / (en * gmax / 32.0)
         if t < best:
             best, code = t, -1
     return best, code
@@ -127,15 +130,15 @@ def test_head_certainty_vs_restatement(env, with_drift):
     cent = torch.from_numpy(syn.make_geocells(C, seed=1))
     beta = (2e-4 * torch.randn((1024,), generator=g) / 32).float() if with_drift else None
     o = ops.head_forward(emb.to(DEV), W.to(DEV), b.to(DEV), cent.to(DEV), kx)
-    wmax = W.norm(dim=1).max().reshape(1)
+    wst = torch.stack([W.norm(dim=1).max(), (W @ beta).abs().max() if beta is not None else torch.zeros(())]).float()
     tol, code, margin, sens = ops.head_certainty(o["logits"], emb.to(DEV), W.to(DEV), o["topk_indices"],
-                                                 None if beta is None else beta.to(DEV), wmax.to(DEV))
+                                                 None if beta is None else beta.to(DEV), wst.to(DEV))
     lg, idx = o["logits"].cpu().double().numpy(), o["topk_indices"].cpu().numpy()
     pe = emb.mean(dim=1).double().numpy()
     Wd = W.double().numpy()
     bz = np.zeros(1024) if beta is None else beta.double().numpy()
     for i in range(B):
-        t, c = _head_tol_restated(lg[i], pe[i], Wd, idx[i], bz, float(wmax))
+        t, c = _head_tol_restated(lg[i], pe[i], Wd, idx[i], bz, float(wst[0]), float(wst[1]))
         assert abs(float(tol[i]) - t) <= 2e-3 * abs(t) + 1e-6, (i, float(tol[i]), t)
         assert int(code[i]) == c
     # the legacy pair (top-1 against top-2) rides along
@@ -146,10 +149,10 @@ def test_head_certainty_vs_restatement(env, with_drift):
     # the whole head listed: nothing beyond the list; one geocell: nothing to be uncertain about
     Cs = 7
     o7 = ops.head_forward(emb.to(DEV), W[:Cs].contiguous().to(DEV), b[:Cs].to(DEV), cent[:Cs].to(DEV), Cs)
-    t7, c7, _, _ = ops.head_certainty(o7["logits"], emb.to(DEV), W[:Cs].contiguous().to(DEV), o7["topk_indices"], None, wmax.to(DEV))
+    t7, c7, _, _ = ops.head_certainty(o7["logits"], emb.to(DEV), W[:Cs].contiguous().to(DEV), o7["topk_indices"], None, wst.to(DEV))
     assert (c7 >= 1).all() and torch.isfinite(t7).all()
     o1 = ops.head_forward(emb.to(DEV), W[:1].contiguous().to(DEV), b[:1].to(DEV), cent[:1].to(DEV), 1)
-    t1, c1, m1, s1 = ops.head_certainty(o1["logits"], emb.to(DEV), W[:1].contiguous().to(DEV), o1["topk_indices"], None, wmax.to(DEV))
+    t1, c1, m1, s1 = ops.head_certainty(o1["logits"], emb.to(DEV), W[:1].contiguous().to(DEV), o1["topk_indices"], None, wst.to(DEV))
     assert torch.isinf(t1).all() and torch.isinf(m1).all() and (s1 == 0).all()
 
 
@@ -163,11 +166,11 @@ def test_head_tolerance_means_what_it_says(env):
     W, b = syn.make_head_weights(C, seed=5)
     W = W * 8
     cent = torch.from_numpy(syn.make_geocells(C, seed=1))
-    wmax = W.norm(dim=1).max().reshape(1).to(DEV)
+    wst = torch.stack([W.norm(dim=1).max(), torch.zeros(())]).float().to(DEV)
 
     def run(e):
         o = ops.head_forward(e.to(DEV), W.to(DEV), b.to(DEV), cent.to(DEV), kx)
-        return o, ops.head_certainty(o["logits"], e.to(DEV), W.to(DEV), o["topk_indices"], None, wmax)
+        return o, ops.head_certainty(o["logits"], e.to(DEV), W.to(DEV), o["topk_indices"], None, wst)
     o, (tol, code, _, _) = run(emb)
     idx = o["topk_indices"].cpu()
     moved = 0
@@ -187,7 +190,7 @@ def test_head_tolerance_means_what_it_says(env):
     assert moved >= 8
 
 
-def _refine_tol_restated(rec, ints, L, cand, topk, n_eval, C, W, bankp, bankt, e, beta, wmax, T, r, ch, fin_r):
+def _refine_tol_restated(rec, ints, L, cand, topk, n_eval, C, W, bankp, bankt, e, beta, wmax, wbmax, T, r, ch, fin_r):
     en = np.linalg.norm(e)
     S = L + rec[:, 0] / T
     if not (fin_r >= 1e-30) and ints[r, 0] >= 0:
@@ -216,7 +219,7 @@ def _refine_tol_restated(rec, ints, L, cand, topk, n_eval, C, W, bankp, bankt, e
             best, code = t, 2000 + j
     if n_eval > topk and n_eval < C:
         gmax = np.linalg.norm(W[cand[topk - 1]]) + wmax
-        t = (L[topk - 1] - L[n_eval - 1] - en * gmax * np.linalg.norm(beta)) / (en * gmax / 32.0)
+        t = (L[topk - 1] - L[n_eval - 1] - en * (float(W[cand[topk - 1]] @ beta) + wbmax)) / (en * gmax / 32.0)
         if t < best:
             best, code = t, 2999
     for which, x in enumerate((r, ch)):
@@ -249,11 +252,11 @@ def test_refine_certainty_vs_restatement(env, topk, k, T, max_km, with_drift):
     g = torch.Generator().manual_seed(2)
     W = torch.randn((C, 1024), generator=g) * 0.3
     beta = (3e-4 * torch.randn((1024,), generator=g) / 32).float() if with_drift else None
-    wmax = W.norm(dim=1).max().reshape(1)
+    wst = torch.stack([W.norm(dim=1).max(), (W @ beta).abs().max() if beta is not None else torch.zeros(())]).float()
     n_eval = min(k, topk + 4)
     llh, cell, ch, refined, sc = ops.refine_forward_ex(db, q.to(DEV), init.to(DEV), cand.to(DEV), prob.to(DEV), topk, n_eval, T, max_km)
     tol, code = ops.refine_certainty(db, q.to(DEV), cand.to(DEV), prob.to(DEV), topk, sc, W.to(DEV),
-                                     None if beta is None else beta.to(DEV), wmax.to(DEV), T, refined, ch)
+                                     None if beta is None else beta.to(DEV), wst.to(DEV), T, refined, ch)
     sc = sc.cpu()
     ints = sc[..., [5, 6, 9, 10]].contiguous().view(torch.int32).numpy()
     rec = sc.double().numpy()
@@ -267,7 +270,8 @@ def test_refine_certainty_vs_restatement(env, topk, k, T, max_km, with_drift):
         r, c = int(refined[b]), int(ch[b])
         ex = np.exp((sc[b, :topk, 0] / T).float().numpy()).astype(np.float32)
         fin_r = float(prob[b, r]) * float(ex[r] / ex.sum(dtype=np.float32))
-        t, cd = _refine_tol_restated(rec[b], ints[b], L, cand[b].numpy(), topk, n_eval, C, Wd, bp, bt, qm[b], bz, float(wmax), T, r, c, fin_r)
+        t, cd = _refine_tol_restated(rec[b], ints[b], L, cand[b].numpy(), topk, n_eval, C, Wd, bp, bt, qm[b], bz, float(wst[0]), float(wst[1]),
+                                     T, r, c, fin_r)
         got = float(tol[b])
         assert (np.isinf(t) and np.isinf(got)) or abs(got - t) <= 5e-3 * abs(t) + 1e-5, (b, got, t, int(code[b]), cd)
         if np.isfinite(t) and abs(t) > 1e-3:

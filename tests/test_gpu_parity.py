@@ -105,7 +105,8 @@ def test_gemm_persistent_many_tiles_bit_identical(env):
             if epi in (L.EPI_QKV, L.EPI_GELU):
                 o = torch.full((M + 3, N), 7.0, dtype=torch.float16, device=DEV)
             elif epi == L.EPI_RESID:
-                o = torch.cat([X0, torch.full((3, N), 7.0, device=DEV)]).contiguous()
+                # >= 384 guard rows: the wrapper then runs the kernel IN PLACE (no padded copy), so a write past row M would be seen
+                o = torch.cat([X0, torch.full((387, N), 7.0, device=DEV)]).contiguous()
             else:
                 o = torch.full((M + 3, N), 7.0, device=DEV)
             ops.gemm16(A, W, bias, o, epi, qscale=0.25, qcols=256, variant=var, M=M)
@@ -130,7 +131,8 @@ def _gemm_all_epilogues(ops, L, A, W, bias, X0, cs, rs, M, variant):
         if epi in (L.EPI_QKV, L.EPI_GELU):
             o = torch.full((M + 3, N), 7.0, dtype=A.dtype, device=DEV)
         elif epi == L.EPI_RESID:
-            o = torch.cat([X0, torch.full((3, N), 7.0, device=DEV)]).contiguous()
+            # >= 384 guard rows: the wrapper then runs the kernel IN PLACE (no padded copy), so a write past row M would be seen
+            o = torch.cat([X0, torch.full((387, N), 7.0, device=DEV)]).contiguous()
         else:
             o = torch.full((M + 3, N), 7.0, device=DEV)
         ops.gemm16(A, W, bias, o, epi, qscale=0.25, qcols=256, variant=variant, M=M)
@@ -207,7 +209,8 @@ def test_gemm_resid_stat_on_384_row_tiles_bit_identical(env):
     A = torch.randn((M, K), generator=g).to(torch.float16).to(DEV)
     W = (torch.randn((N, K), generator=g) * 0.03).to(torch.float16).to(DEV)
     bias = torch.randn(N, generator=g).to(DEV)
-    X0 = torch.cat([torch.randn((M, N), generator=g), torch.full((5, N), 7.0)]).to(DEV)     # 5 guard rows past M
+    # 389 guard rows past M (>= 384: gemm16_resid_stat then runs in place on this very buffer, so the guard check below is real)
+    X0 = torch.cat([torch.randn((M, N), generator=g), torch.full((389, N), 7.0)]).to(DEV)
     res = {}
     try:
         for tail in (0, 768):
@@ -255,7 +258,8 @@ def test_gemm_w4_one_wave_per_simd_kernel(env):
             if epi in (L.EPI_QKV, L.EPI_GELU):
                 o = torch.full((M + 3, N), 7.0, dtype=dt, device=DEV)
             elif epi == L.EPI_RESID:
-                o = torch.cat([X0, torch.full((3, N), 7.0, device=DEV)]).contiguous()
+                # >= 384 guard rows: the wrapper then runs the kernel IN PLACE (no padded copy), so a write past row M would be seen
+                o = torch.cat([X0, torch.full((387, N), 7.0, device=DEV)]).contiguous()
             else:
                 o = torch.full((M + 3, N), 7.0, device=DEV)
             ops.gemm16(A, W, bias, o, epi, qscale=0.25, qcols=256, variant=var, M=M)
