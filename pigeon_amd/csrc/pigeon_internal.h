@@ -64,3 +64,4 @@ int pg_x3_ln_launch(const float* x, const float* gamma, const float* beta, void*
 int pg_x3_split_launch(const float* x, void* y3, int64_t rows, int C, int gelu, hipStream_t s);
 int pg_x3_im2col_launch(const void* pixels, int pix_dtype, void* out3, int n_images, hipStream_t s);
 int pg_attention_f32_launch(const float* qkv, float* out, int n_images, hipStream_t s);
+int pg_sum_parts_launch(const float* parts, int S, int64_t part_elems, float* dst, int64_t n, int resid, hipStream_t s);

@@ -17,6 +17,7 @@
 //   im2col_x3_kernel   pixels (n,3,336,336) -> patch matrix triple [576 n][3 * 640] fp16
 //   ln_x3_kernel       LayerNorm of fp32 rows -> triple [M][3 * 1024]
 //   split_x3_kernel    fp32 [M][C] (optionally through QuickGELU) -> triple [M][3 * C]
+//   sum_parts_kernel   (round 5) fixed-order sum of the K-split partial products of one GEMM (+ the fp32 residual row)
 //   attention_f32_kernel  fp32 QKV [M][3072] -> fp32 O [M][1024], softmax(q k^T / 8) v per (image, head)
 #include "common.h"
 #include "pigeon_internal.h"
@@ -106,6 +107,28 @@ int pg_x3_split_launch(const float* x, void* y3, int64_t rows, int C, int gelu, 
     if (gelu) hipLaunchKernelGGL(split_x3_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, x, (uint16_t*)y3, rows, C);
     else hipLaunchKernelGGL(split_x3_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, x, (uint16_t*)y3, rows, C);
     return pg_check_launch("split_x3");
+}
+
+// ---- fixed-order sum of the K-split partial products (vit.hip precise_gemm): dst = (RESID ? dst : 0) + ((p0 + p1) + p2 ...) -----
+template <bool RESID>
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ parts, int S, int64_t stride4, float* __restrict__ dst,
+                                                        int64_t n4) {
+    const f32x4* p = (const f32x4*)parts;
+    f32x4* d = (f32x4*)dst;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 acc = p[i];
+        for (int k = 1; k < S; ++k) acc += p[k * stride4 + i];
+        d[i] = RESID ? d[i] + acc : acc;
+    }
+}
+int pg_sum_parts_launch(const float* parts, int S, int64_t part_elems, float* dst, int64_t n, int resid, hipStream_t s) {
+    if (n <= 0) return PG_OK;
+    if ((n & 3) || (part_elems & 3) || S < 1) { pg_set_error("sum_parts: element counts must be multiples of 4"); return PG_EINVAL; }
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (resid) hipLaunchKernelGGL(sum_parts_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, parts, S, part_elems / 4, dst, n / 4);
+    else hipLaunchKernelGGL(sum_parts_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, parts, S, part_elems / 4, dst, n / 4);
+    return pg_check_launch("sum_parts");
 }
 
 // ---- im2col -> triple [576 n][3 * 640]; k order == Conv2d weight [1024,3,14,14] flattened, columns 588..639 zero ----------------

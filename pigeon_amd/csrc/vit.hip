@@ -171,6 +171,9 @@ struct pg_vit {
     // always-on fp16 range alarm (rowstat_finalize_kernel): rows of the residual stream whose sum of squares reaches 65504^2
     unsigned long long* range_alarm = nullptr;
     float range_alarm_sumsq = 0.f;
+    // exact mode (round 5): side streams on which the K-split parts of one GEMM run concurrently (precise_gemm)
+    hipStream_t ps[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t p_fork = nullptr, p_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     // hipGraph of the encoder body (round 4): the ~250 launches between im2col and the token mean touch only the workspace and the
     // weights, so one captured graph per (workspace, n_images) replays them with one host call.  Built at the SECOND forward of a
     // key (the first runs eagerly: it also sets the kernels' LDS attributes, which is not a stream operation), on an internal
@@ -699,18 +702,59 @@ extern "C" int pg_vit_forward(pg_vit* h, const void* pixels, int pix_dtype, int 
 // pg_vit_forward_precise: the same encoder in near-fp32 arithmetic (precise.hip: split-fp16 GEMM operands on the persistent MFMA
 // kernels, fp32 LayerNorm / attention / QuickGELU / residual), for the panoramas whose top-1 margin the 16-bit path cannot decide.
 // Workspace per token row: X fp32 4 KB | T3 triple of a 1024-wide row 6 KB | F fp32 QKV (12 KB) / fc1 (16 KB) | G3 triple of the
-// 4096-wide activation 24 KB (the im2col triple and the fp32 attention output live there too) = 50 KB; chunks of <= 64 images.
+// 4096-wide activation 24 KB (the im2col triple and the fp32 attention output live there too) | (round 5) PP, the K-split partial
+// products of one GEMM, 48 KB (fc1: 3 x 4096 fp32) = 98 KB; chunks of <= 64 images.
+//
+// Round 5: every GEMM of the layer loop is cut along K' into S parts (QKV / out / fc1: the three products hi.Wh | lo.Wh | hi.Wl, S = 3;
+// fc2, K' = 12288: S = 6) that run CONCURRENTLY on side streams into fp32 partial buffers and are then summed in a fixed order
+// (sum_parts_kernel).  The exact tier is run on the handful of panoramas a step finds uncertain -- 4 to 16 images, 10 to 40 row panels:
+// one K' = 12288 launch then puts 40 tiles of 192 K tiles each on 256 CUs (326 us per layer for fc2 alone, latency, not work);
+// six launches of 32 K tiles fill the chip instead.  S is fixed per GEMM whatever the batch, so a row's value still does not depend
+// on the batch it rides in; at large batches the parts simply queue behind each other (same MFMA work, one extra streaming pass).
 #define PG_PRECISE_CHUNK 64
 static size_t precise_ws_bytes_for(int chunk) {
     const size_t M = (size_t)chunk * VIT_TOKENS;
     return align_up(M * VIT_HIDDEN * 4, 256) + align_up(M * 3 * VIT_HIDDEN * 2, 256) + align_up(M * VIT_MLP * 4, 256) +
-           align_up(M * 3 * VIT_MLP * 2, 256) + 256;
+           align_up(M * 3 * VIT_MLP * 2, 256) + align_up(M * 3 * VIT_MLP * 4, 256) + 256;
 }
 extern "C" int pg_vit_precise_workspace_bytes(const pg_vit* h, int n_images, size_t* bytes) {
     if (!h || !bytes || n_images < 0) { pg_set_error("vit_precise_workspace_bytes: bad argument"); return PG_EINVAL; }
     const int chunk = n_images < PG_PRECISE_CHUNK ? n_images : PG_PRECISE_CHUNK;
     *bytes = precise_ws_bytes_for(chunk > 0 ? chunk : 1);
     return PG_OK;
+}
+
+// One GEMM of the exact mode, cut along K' into S concurrent parts: part p multiplies columns [p Kp, (p + 1) Kp) of the triple
+// operands into the fp32 partial buffer p (bias rides in part 0), parts 1.. run on side streams forked from / joined to `s` with
+// events; then dst = (resid ? dst : 0) + sum of the parts, in part order.
+static int precise_gemm(pg_vit* h, const uint16_t* A3, int64_t lda, const uint16_t* W3, int64_t ldw, const float* bias, float* parts,
+                        float* dst, bool resid, int M, int N, int Ktot, int S, hipStream_t s) {
+    const int dt = PG_DTYPE_F16, V = 36;
+    const int Kp = Ktot / S;
+    if (S < 1 || S > 6 || Kp * S != Ktot || (Kp % 128) != 0) { pg_set_error("precise_gemm: bad K split (K' = %d, S = %d)", Ktot, S); return PG_EINVAL; }
+    if (!h->p_fork) PG_HIP(hipEventCreateWithFlags(&h->p_fork, hipEventDisableTiming));
+    for (int p = 0; p + 1 < S; ++p) {
+        if (!h->ps[p]) PG_HIP(hipStreamCreateWithFlags(&h->ps[p], hipStreamNonBlocking));
+        if (!h->p_join[p]) PG_HIP(hipEventCreateWithFlags(&h->p_join[p], hipEventDisableTiming));
+    }
+    const int64_t part_elems = (int64_t)M * N;
+    PG_HIP(hipEventRecord(h->p_fork, s));
+    int rc = PG_OK;
+    for (int p = 0; p < S && rc == PG_OK; ++p) {
+        hipStream_t sp = p == 0 ? s : h->ps[p - 1];
+        if (p > 0) { hipError_t e = hipStreamWaitEvent(sp, h->p_fork, 0); if (e != hipSuccess) { pg_set_error("precise_gemm: fork failed: %s", hipGetErrorString(e)); rc = PG_EHIP; break; } }
+        rc = pg_gemm_launch(dt, A3 + (int64_t)p * Kp, lda, W3 + (int64_t)p * Kp, ldw, p == 0 ? bias : nullptr, parts + p * part_elems, N, M, N, Kp,
+                            EPI_F32, 1.f, 0, nullptr, V, sp);
+    }
+    // the caller's stream continues when every part is done -- also after a failed launch in the middle (work already queued on a
+    // side stream still writes the partial buffers)
+    for (int p = 1; p < S; ++p) {
+        hipError_t e = hipEventRecord(h->p_join[p - 1], h->ps[p - 1]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, h->p_join[p - 1], 0);
+        if (e != hipSuccess && rc == PG_OK) { pg_set_error("precise_gemm: join failed: %s", hipGetErrorString(e)); rc = PG_EHIP; }
+    }
+    if (rc != PG_OK) return rc;
+    return pg_sum_parts_launch(parts, S, part_elems, dst, part_elems, resid ? 1 : 0, s);
 }
 
 static int vit_precise_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n, float* emb_out, float* hidden_out, char* ws,
@@ -722,6 +766,7 @@ static int vit_precise_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n
     float* Fb = (float*)((char*)T3 + align_up((size_t)M * 3 * D * 2, 256));
     uint16_t* G3 = (uint16_t*)((char*)Fb + align_up((size_t)M * F * 4, 256));
     float* O = (float*)G3;                                    // fp32 attention output, dead before G3 is written
+    float* PP = (float*)((char*)G3 + align_up((size_t)M * 3 * F * 2, 256));     // K-split partial products of one GEMM
     const float eps = h->cfg.ln_eps;
     const int dt = PG_DTYPE_F16, V = 36;                      // the 256 x 256 persistent kernel takes every epilogue used here
     RC(pg_x3_im2col_launch(pixels, pix_dtype, G3, n, s));
@@ -731,14 +776,14 @@ static int vit_precise_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n
     for (int l = 0; l < h->cfg.layers; ++l) {
         const LayerW& L = h->layers[l];
         RC(pg_x3_ln_launch(X, L.ln1g, L.ln1b, T3, M, eps, s));
-        RC(pg_gemm_launch(dt, T3, 3 * D, L.wqkv3, 3 * D, L.bqkv_raw, Fb, 3 * D, (int)M, 3 * D, 3 * D, EPI_F32, 1.f, 0, nullptr, V, s));
+        RC(precise_gemm(h, T3, 3 * D, L.wqkv3, 3 * D, L.bqkv_raw, PP, Fb, false, (int)M, 3 * D, 3 * D, 3, s));
         RC(pg_attention_f32_launch(Fb, O, n, s));
         RC(pg_x3_split_launch(O, T3, M, D, 0, s));
-        RC(pg_gemm_launch(dt, T3, 3 * D, L.wo3, 3 * D, L.bo, X, D, (int)M, D, 3 * D, EPI_RESID, 1.f, 0, nullptr, V, s));
+        RC(precise_gemm(h, T3, 3 * D, L.wo3, 3 * D, L.bo, PP, X, true, (int)M, D, 3 * D, 3, s));
         RC(pg_x3_ln_launch(X, L.ln2g, L.ln2b, T3, M, eps, s));
-        RC(pg_gemm_launch(dt, T3, 3 * D, L.w13, 3 * D, L.b1_raw, Fb, F, (int)M, F, 3 * D, EPI_F32, 1.f, 0, nullptr, V, s));
+        RC(precise_gemm(h, T3, 3 * D, L.w13, 3 * D, L.b1_raw, PP, Fb, false, (int)M, F, 3 * D, 3, s));
         RC(pg_x3_split_launch(Fb, G3, M, F, 1, s));
-        RC(pg_gemm_launch(dt, G3, 3 * F, L.w23, 3 * F, L.b2, X, D, (int)M, D, 3 * F, EPI_RESID, 1.f, 0, nullptr, V, s));
+        RC(precise_gemm(h, G3, 3 * F, L.w23, 3 * F, L.b2, PP, X, true, (int)M, D, 3 * F, 6, s));
     }
     RC(pg_token_mean_launch(X, emb_out, n, s));
     if (hidden_out) PG_HIP(hipMemcpyAsync(hidden_out, X, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
@@ -775,6 +820,8 @@ extern "C" int pg_vit_destroy(pg_vit* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& g : h->graphs) graph_entry_free(g);
+    for (int i = 0; i < 5; ++i) { if (h->ps[i]) (void)hipStreamDestroy(h->ps[i]); if (h->p_join[i]) (void)hipEventDestroy(h->p_join[i]); }
+    if (h->p_fork) (void)hipEventDestroy(h->p_fork);
     if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
     delete h;
     return PG_OK;

@@ -277,7 +277,7 @@ def test_refine_certainty_vs_restatement(env, topk, k, T, max_km, with_drift):
         if np.isfinite(t) and abs(t) > 1e-3:
             assert int(code[b]) == cd, (b, int(code[b]), cd, got, t)
         seen.add(cd // 1000)
-    assert 1 in seen                                              # winner-against-the-set decisions set some tolerances
+    assert seen & {1, 2, 3, 4}                                    # decisions of the refiner set the tolerances (which ones: by parameter set)
     # without candidates beyond the set the boundary question stays open: no 2xxx code
     if n_eval == topk:
         assert not ((code >= 2000) & (code < 3000)).any()

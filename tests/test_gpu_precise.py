@@ -262,14 +262,21 @@ def test_exact_mode_edges(env, tmp_path, capsys):
     assert torch.equal(e1.embedding, want[:1])
 
 
-def test_trained_like_and_spread_tower_vs_reference_module(env, capsys):
-    """The two stress regimes in ONE 24-layer tower -- massive activations / rows with |mean| >> std (make_vit_weights_trained_like)
-    AND input-selected global attention (make_vit_weights_spread) -- against the reference's own module
-    (transformers.CLIPVisionModel, fp32, eager attention, stock PyTorch-ROCm on this GPU; never part of the product): fast path
-    within the 1e-3 contract with no fp16 range alarm, exact mode within EXACT_TOL.  No committed fixture: the checker is computed here."""
+@pytest.mark.parametrize("tower", ["trained_like+spread", "all_heads_high_gain"])
+def test_stress_towers_vs_reference_module(env, capsys, tower):
+    """Stress regimes at 24 layers against the reference's own module (transformers.CLIPVisionModel, fp32, eager attention, stock
+    PyTorch-ROCm on this GPU; never part of the product) -- no committed fixture, the checker is computed here:
+      trained_like+spread   massive activations / rows with |mean| >> std (make_vit_weights_trained_like) AND input-selected global
+                            attention in a quarter of the heads (make_vit_weights_spread);
+      all_heads_high_gain   (round 5) large q.k gain and jittered affine parameters on ALL 16 heads of every layer: the regime in
+                            which 16-bit Q / K operands cost the most.
+    Fast path: within the 1e-3 contract PER IMAGE, no fp16 range alarm; exact mode within EXACT_TOL."""
     from transformers import CLIPVisionConfig, CLIPVisionModel
     ops, syn = env["ops"], env["syn"]
-    sd = syn.make_vit_weights_spread(seed=31, layers=24, base=syn.make_vit_weights_trained_like(seed=21, layers=24))
+    if tower == "trained_like+spread":
+        sd = syn.make_vit_weights_spread(seed=31, layers=24, base=syn.make_vit_weights_trained_like(seed=21, layers=24))
+    else:
+        sd = syn.make_vit_weights_spread(seed=47, layers=24, heads_frac=1.0)
     cfg = CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=336,
                            patch_size=14, projection_dim=768)
     hf = CLIPVisionModel._from_config(cfg, attn_implementation="eager")
@@ -291,10 +298,12 @@ def test_trained_like_and_spread_tower_vs_reference_module(env, capsys):
     exact = enc.forward_precise(px).cpu()
     e_fast, e_exact = _rel(fast, ref), _rel(exact, ref)
     worst = float(((fast.double() - ref.double()).norm(dim=1) / ref.double().norm(dim=1)).max())
+    line = (f"{tower}: |hidden| max {absmax:.0f}, image cos-sim mean {float(cs.mean()):.2f} max {float(cs.max()):.2f}; "
+            f"embedding rel err fast {e_fast:.2e} (worst image {worst:.2e}), exact {e_exact:.2e}; fp16 range alarm rows {alarm}")
     with capsys.disabled():
-        print(f"\ntrained-like + spread tower: |hidden| max {absmax:.0f}, image cos-sim mean {float(cs.mean()):.2f} max {float(cs.max()):.2f}; "
-              f"embedding rel err fast {e_fast:.2e} (worst image {worst:.2e}), exact {e_exact:.2e}; fp16 range alarm rows {alarm}")
+        print("\n" + line)
+    _report([line], f"stress_tower_{tower.replace('+', '_')}.txt")
     enc.close()
     assert alarm == 0
-    assert e_fast < 1e-3 and worst < 1.5e-3
+    assert e_fast < 1e-3 and worst < 1e-3, "the fast path leaves the 1e-3 contract on this tower (per image)"
     assert e_exact < EXACT_TOL

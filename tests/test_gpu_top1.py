@@ -152,6 +152,7 @@ def test_contract_pipeline24(env, vit24, golden_dir, tmp_path, capsys):
 def test_contract_pipeline24_wide(env, vit24, golden_dir, tmp_path, capsys):
     """One full bench step (128 panoramas = 512 images), default-init tower, head centred and scaled to sigma(logit) = 4."""
     g = np.load(os.path.join(golden_dir, "pipeline24_wide.npz"))
+    assert "evaluate_cell" in g.files, "run oracle/extend_golden_evaluate.py: the fixture lacks evaluate()'s refinement"
     _contract_run(env, vit24[1], golden_dir, tmp_path, "pipeline24_wide", capsys)
 
 
@@ -159,6 +160,7 @@ def test_contract_pipeline24_spread(env, vit24_spread, golden_dir, tmp_path, cap
     """128 panoramas on the tower whose embeddings SPREAD like a trained one's (pairwise cos-sim ~0.7), head at its natural scale."""
     g = np.load(os.path.join(golden_dir, "pipeline24_spread.npz"))
     assert g["image_cos_sim"][2] <= 0.8, "the fixture's embeddings must spread (pairwise cos-sim <= 0.8)"
+    assert "evaluate_cell" in g.files, "run oracle/extend_golden_evaluate.py: the fixture lacks evaluate()'s refinement"
     _contract_run(env, vit24_spread[1], golden_dir, tmp_path, "pipeline24_spread", capsys)
 
 

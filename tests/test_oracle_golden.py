@@ -191,8 +191,25 @@ def test_pipeline24_wide_head_and_refine_match_reference(golden_dir, tmp_path):
     margin = g["logit_margin"]
     assert len(set(g["preds_geocell"].tolist())) >= 100 and margin.min() > 0 and (margin < 0.03).sum() >= 2   # honest near-ties inside
     bank = synthetic.make_bank(C, ppc, seed=bseed, empty_frac=0.01, max_members=maxm, center=g["center"], radius=float(g["radius"]))
-    topk, T, mr = g["default_params"]
-    _, llh, cell = orc.proto_refiner_forward(bank, emb, torch.from_numpy(g["preds_LLH"]), torch.from_numpy(g["topk_indices"]),
-                                             torch.from_numpy(g["topk_values"]), int(topk), float(T), float(mr))
-    assert np.array_equal(cell.numpy(), g["default_cell"]) and np.array_equal(llh.numpy(), g["default_LLH"])
+    # both refiner settings the reference uses (round 5: evaluate()'s top-40 / T 0.6 added by oracle/extend_golden_evaluate.py)
+    for tag in ("default", "evaluate"):
+        topk, T, mr = g[f"{tag}_params"]
+        _, llh, cell = orc.proto_refiner_forward(bank, emb, torch.from_numpy(g["preds_LLH"]), torch.from_numpy(g["topk_indices"]),
+                                                 torch.from_numpy(g["topk_values"]), int(topk), float(T), float(mr))
+        assert np.array_equal(cell.numpy(), g[f"{tag}_cell"]) and np.array_equal(llh.numpy(), g[f"{tag}_LLH"]), tag
     assert int((g["default_LLH"] != g["preds_LLH"].astype(np.float32)).any(axis=1).sum()) > 100              # refinement moves the points
+    assert int((g["evaluate_cell"] != g["preds_geocell"]).sum()) >= 20                                         # evaluate()'s setting re-ranks cells
+
+
+def test_pipeline24_spread_refine_matches_reference(golden_dir, tmp_path):
+    """The 128-panorama SPREAD fixture (head at its natural scale: evaluate()'s refinement re-ranks every panorama): the oracle's
+    refiner on the reference's embeddings and candidates reproduces the reference's refined outputs at both settings."""
+    g = _load(golden_dir, "pipeline24_spread.npz")
+    wseed, layers, NP, pseed, C, ppc, bseed, maxm = [int(x) for x in g["meta"]]
+    emb = torch.from_numpy(g["embedding"])
+    bank = synthetic.make_bank(C, ppc, seed=bseed, empty_frac=0.01, max_members=maxm, center=g["center"], radius=float(g["radius"]))
+    for tag in ("default", "evaluate"):
+        topk, T, mr = g[f"{tag}_params"]
+        _, llh, cell = orc.proto_refiner_forward(bank, emb, torch.from_numpy(g["preds_LLH"]), torch.from_numpy(g["topk_indices"]),
+                                                 torch.from_numpy(g["topk_values"]), int(topk), float(T), float(mr))
+        assert np.array_equal(cell.numpy(), g[f"{tag}_cell"]) and np.array_equal(llh.numpy(), g[f"{tag}_LLH"]), tag
