@@ -381,6 +381,11 @@ int pg_op_cast_f32(const float* x, void* y, int out_dtype, int64_t n, void* stre
  *   pg_op_x3_split      x fp32 (rows,cols) -> triple (rows, 3 cols); gelu != 0: through QuickGELU first (expf, IEEE division)
  *   pg_op_x3_layernorm  LayerNorm(x fp32 (rows,1024)) -> triple (rows, 3072)
  *   pg_op_attention_f32 fused QKV fp32 (n_images*577, 3072), Q NOT pre-scaled -> softmax(q k^T / 8) v, fp32 (n_images*577, 1024) */
+/* S independent products in ONE persistent launch (the exact mode's K-split GEMMs, csrc/vit.hip precise_gemm): part p computes
+ * parts[p] (M,N) fp32 = A[:, p*Kp:(p+1)*Kp] x W[:, p*Kp:(p+1)*Kp]^T (+ bias for p = 0); A (M, >= S*Kp) and W (N, >= S*Kp) 16-bit with
+ * leading dimensions lda / ldw.  N % 256 == 0, Kp % 128 == 0, 1 <= S <= 8.  Each part is bit-identical to pg_op_gemm16_ld on its slice. */
+int pg_op_gemm16_parts(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* parts,
+                       int M, int N, int Kp, int S, void* stream);
 int pg_op_x3_split(const float* x, void* y3, int64_t rows, int cols, int gelu, void* stream);
 int pg_op_x3_layernorm(const float* x, const float* gamma, const float* beta, void* y3, int64_t rows, float eps, void* stream);
 int pg_op_attention_f32(const float* qkv, float* out, int n_images, void* stream);

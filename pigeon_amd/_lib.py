@@ -92,6 +92,7 @@ SIGNATURES = {
     "pg_op_im2col": (_I, [_P, _I, _P, _I, _I, _P]),
     "pg_op_token_mean": (_I, [_P, _P, _I, _P]),
     "pg_op_cast_f32": (_I, [_P, _P, _I, _I64, _P]),
+    "pg_op_gemm16_parts": (_I, [_I, _P, _I64, _P, _I64, _P, _P, _I, _I, _I, _I, _P]),
     "pg_op_x3_split": (_I, [_P, _P, _I64, _I, _I, _P]),
     "pg_op_x3_layernorm": (_I, [_P, _P, _P, _P, _I64, _F, _P]),
     "pg_op_attention_f32": (_I, [_P, _P, _I, _P]),

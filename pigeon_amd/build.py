@@ -20,7 +20,9 @@ SOURCES = ["vit.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_pp6.hip", "gemm_tail
 # additionally in the tools build (--dev), from tools/csrc/: kernel generations the product superseded, kept for A/B work
 # (gemm variant 64 = gemm_w4.hip; attention variants 1, 4..15 = attention_old.hip)
 DEV_DIR = os.path.join(os.path.dirname(HERE), "tools", "csrc")
-DEV_SOURCES = [os.path.join(DEV_DIR, "gemm_w4.hip"), os.path.join(DEV_DIR, "attention_old.hip")]
+# (round 5: the two files moved to the branch archive/kernel-generations-r04; a checkout that has them under tools/csrc/ again gets
+# them compiled in with -DPIGEON_OLD_GENERATIONS)
+DEV_SOURCES = [f for f in (os.path.join(DEV_DIR, "gemm_w4.hip"), os.path.join(DEV_DIR, "attention_old.hip")) if os.path.exists(f)]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "pigeon_internal.h"), os.path.join(CSRC, "gemm_epi.h"),
            os.path.join(CSRC, "attention_common.h"),
            os.path.join(os.path.dirname(HERE), "include", "pigeon_hip.h")]
@@ -49,7 +51,7 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
     global OBJ, LIB
     obj_dir = os.path.join(CSRC, "build_dev" if dev else "build")
     lib = os.path.join(HERE, "libpigeon_hip_dev.so" if dev else "libpigeon_hip.so")
-    flags = FLAGS + (["-DPIGEON_ABLATIONS"] if dev else [])
+    flags = FLAGS + (["-DPIGEON_ABLATIONS"] if dev else []) + (["-DPIGEON_OLD_GENERATIONS"] if dev and len(DEV_SOURCES) == 2 else [])
     return _build(obj_dir, lib, flags, force, verbose, SOURCES + (DEV_SOURCES if dev else []))
 
 

@@ -31,6 +31,9 @@ class Certainty:
         self.drift: Optional[torch.Tensor] = None     # (1024,) fp32 on the model's device, or None
         self.calibrated = False
         self.stats = {}
+        # the fast path measured OUTSIDE the embedding contract on this set of weights (see `calibrate`): every sample then goes
+        # through the exact encoder
+        self.force_exact = False
 
     def threshold(self, exact: bool = False) -> float:
         return self.kappa * (self.rel_tol_exact if exact else self.rel_tol)
@@ -43,12 +46,19 @@ class Certainty:
         return self.drift
 
     @torch.no_grad()
-    def calibrate(self, fast: torch.Tensor, exact: torch.Tensor, safety: float = 1.1, use_drift: bool = True) -> dict:
+    def calibrate(self, fast: torch.Tensor, exact: torch.Tensor, safety: float = 1.1, use_drift: bool = True,
+                  fast_images: Optional[torch.Tensor] = None, exact_images: Optional[torch.Tensor] = None,
+                  contract: float = 1e-3) -> dict:
         """fast, exact: (n,1024) embeddings of the same n samples (panel means for panoramas).  Sets `rel_tol` (and `drift` when a
         systematic part explains a worthwhile share of the error), freezes them, returns the measured statistics.
 
         The systematic part is fitted on the even samples and the residual measured on the ODD ones (out of sample, so that
-        `rel_tol` is not flattered by the fit); the vector finally kept is the mean over all samples."""
+        `rel_tol` is not flattered by the fit); the vector finally kept is the mean over all samples.
+
+        `fast_images` / `exact_images` (m,1024): the per-IMAGE embeddings behind them.  The contract is "embeddings within `contract`
+        relative" per image; a tower on which the 16-bit path itself measures outside it (whole-sample error above 0.85 x, or the
+        worst calibration image above 0.95 x the contract -- seen only on a synthetic extreme: every attention head at high q.k
+        gain, tests/test_gpu_precise.py) sets `force_exact`: every sample is then encoded by the exact encoder."""
         rel = (fast.float() - exact.float()) / exact.float().norm(dim=1, keepdim=True).clamp_min(1e-30)
         n = int(rel.shape[0])
         if n == 0:
@@ -65,6 +75,12 @@ class Certainty:
             if resid < 0.9 * total:
                 drift = rel.mean(dim=0).contiguous()
                 st['drift_used'] = True
+        if fast_images is not None and exact_images is not None and fast_images.numel():
+            fi, ei = fast_images.float(), exact_images.float()
+            st['image_rel_err'] = float((fi - ei).norm() / ei.norm().clamp_min(1e-30))
+            st['worst_image_rel_err'] = float(((fi - ei).norm(dim=1) / ei.norm(dim=1).clamp_min(1e-30)).max())
+            self.force_exact = st['image_rel_err'] > 0.85 * contract or st['worst_image_rel_err'] > 0.95 * contract
+        st['force_exact'] = self.force_exact
         eps = st['residual_rms'] if drift is not None else total
         self.rel_tol = max(safety * eps, 2.0 * self.rel_tol_exact)
         self.drift = drift
@@ -79,6 +95,9 @@ class Certainty:
         how = (f"calibrated on {s.get('samples')} samples through the fast and the exact encoder: total relative error RMS "
                f"{s.get('fast_vs_exact_rms', 0):.3g}, systematic part |beta| {s.get('drift_norm', 0):.3g} "
                f"({'used' if s.get('drift_used') else 'not used'}), residual RMS (out of sample) {s.get('residual_rms', 0):.3g}"
+               + (f"; per image: {s.get('image_rel_err', 0):.3g} overall, worst {s.get('worst_image_rel_err', 0):.3g}"
+                  + (" -- OUTSIDE the embedding contract: every sample goes through the exact encoder" if self.force_exact else "")
+                  if 'image_rel_err' in s else "")
                if self.calibrated else "uncalibrated: the contract's embedding tolerance")
         return (f"a sample is certain when every discrete decision downstream of its embedding (top-1 cell against every other cell; "
                 f"with a refiner: winning candidate, candidate-set boundary, nearest prototype, farthest member) keeps "

@@ -1,5 +1,5 @@
 // attention.hip -- multi-head self-attention of the ViT (16 heads x 64, 577 tokens, no mask), flash style: the PRODUCT kernel
-// (attention8_kernel, "v8") and its launcher.  The generations it superseded (v1, v4, v5 / v6) live in tools/csrc/attention_old.hip
+// (attention8_kernel, "v8") and its launcher.  The generations it superseded (v1, v4, v5 / v6): attention_old.hip on the branch archive/kernel-generations-r04
 // and compile into the tools build only (python -m pigeon_amd.build --dev, PIGEON_ATTN_VARIANT 1, 4..15).
 //
 // Replaces: transformers CLIPAttention.forward + eager_attention_forward (modeling_clip.py:259-335): per
@@ -436,13 +436,15 @@ static int att_launch3(int dtype, KF kf, KB kb, dim3 grid, int threads, const vo
     return pg_check_launch("attention");
 }
 
-#ifdef PIGEON_ABLATIONS
-int pg_attention_old_launch(int variant, int dtype, const void* qkv, void* out, dim3 grid, hipStream_t s, int* rc);   // tools/csrc/attention_old.hip
+#if defined(PIGEON_ABLATIONS) && defined(PIGEON_OLD_GENERATIONS)
+// attention_old.hip: the generations v1 / v4 / v5 / v6, archived on the branch archive/kernel-generations-r04 (round 5); a tools build
+// that finds the file under tools/csrc/ again compiles and dispatches to it
+int pg_attention_old_launch(int variant, int dtype, const void* qkv, void* out, dim3 grid, hipStream_t s, int* rc);
 #endif
 
 // Variants (env PIGEON_ATTN_VARIANT): 21 (default, the only one in the product library) = attention8_kernel, 32 queries per wave, row
 // sums out of the matrix pipe.  Tools build only: 20 = the same with v_dot2c row sums, 19 = 64 queries per wave (A/B arms of this
-// kernel); 1, 4..15 = the older generations in tools/csrc/attention_old.hip.
+// kernel); 1, 4..15 = the older generations (attention_old.hip, archived: branch archive/kernel-generations-r04).
 int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hipStream_t s) {
     if (n_images <= 0) return PG_OK;
     if (dtype != PG_DTYPE_F16 && dtype != PG_DTYPE_BF16) { pg_set_error("attention: dtype must be PG_DTYPE_F16 or PG_DTYPE_BF16"); return PG_EINVAL; }
@@ -466,10 +468,12 @@ int pg_attention_launch(int dtype, const void* qkv, void* out, int n_images, hip
     }
     if (variant == 19) return att_launch3(dtype, attention8_kernel<T_F16, 4, 2, 2>, attention8_kernel<T_BF16, 4, 2, 2>, grid, 128, qkv, out, s);
     if (variant == 20) return att_launch3(dtype, attention8_kernel<T_F16, 2, 4, 3, false>, attention8_kernel<T_BF16, 2, 4, 3, false>, grid, 256, qkv, out, s);
+#ifdef PIGEON_OLD_GENERATIONS
     if (variant != 21) {
         int rc = PG_OK;
         if (pg_attention_old_launch(variant, dtype, qkv, out, grid, s, &rc) == 0) return rc;
     }
+#endif
 #endif
     if (variant != 21) {
         pg_set_error("attention: PIGEON_ATTN_VARIANT=%d is not part of this build (product: 21; others need -DPIGEON_ABLATIONS)", variant);

@@ -490,8 +490,12 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
     GemmArgs g;
     g.A = (const uint16_t*)A; g.lda = lda; g.W = (const uint16_t*)W; g.ldw = ldw > 0 ? ldw : K; g.bias = bias; g.out = out; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.qscale = qscale; g.qcols = qcols; g.aux = aux;
-    g.tilesM = 0; g.tilesN = 0; g.ntiles = 0; g.gn = 0; g.stagger = 0; g.xcd_stagger_ticks = 0;
+    g.tilesM = 0; g.tilesN = 0; g.ntiles = 0; g.part_tiles = 0; g.gn = 0; g.stagger = 0; g.xcd_stagger_ticks = 0;
     if (extra) g.ex = *extra;
+    if (g.ex.parts > 1) {                                    // several products in one launch: 256 x 256 persistent kernel, EPI_F32 only
+        if (epi != EPI_F32 || N % 256 != 0 || K % 128 != 0) { pg_set_error("gemm: parts > 1 needs EPI_F32, N %% 256 == 0, K %% 128 == 0"); return PG_EINVAL; }
+        return pg_gemm_pp_launch(dtype, g, epi, 36, s);
+    }
     if ((epi == EPI_GELU || epi == EPI_RESID || epi >= EPI_RESID_STAT) && !bias) { pg_set_error("gemm: epilogue %d needs a bias", epi); return PG_EINVAL; }
     if (epi == EPI_RESID_STAT && (!g.ex.x16 || !g.ex.statpart || g.ex.ldx != ldc)) { pg_set_error("gemm: EPI_RESID_STAT needs x16 / statpart and ldx == ldc"); return PG_EINVAL; }
     if ((epi == EPI_QKV_LN || epi == EPI_GELU_LN) && (!g.ex.colsum || !g.ex.rowstat)) { pg_set_error("gemm: LN epilogue needs colsum / rowstat"); return PG_EINVAL; }
@@ -545,8 +549,8 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
             }
         }
     }
-    if (variant == 64) {                                     // one-wave-per-SIMD persistent kernel (tools build only)
-#ifdef PIGEON_ABLATIONS
+    if (variant == 64) {                                     // one-wave-per-SIMD persistent kernel (gemm_w4.hip: archived, branch archive/kernel-generations-r04)
+#if defined(PIGEON_ABLATIONS) && defined(PIGEON_OLD_GENERATIONS)
         if (pg_gemm_w4_supported(epi, N, K)) return pg_gemm_w4_launch(dtype, g, epi, s);
         variant = 36;
 #else

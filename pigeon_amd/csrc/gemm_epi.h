@@ -16,6 +16,7 @@ struct GemmArgs {
     float qscale; int qcols;
     const float* aux;             // epi 3: position embedding [577][N]
     int tilesM, tilesN, ntiles;
+    int part_tiles;               // tiles of ONE part (tilesM x tilesN); ntiles = ex.parts x part_tiles (EPI_F32, gemm_pp.hip)
     int gn;                       // N tiles per raster group (see tile_coords)
     int stagger;                  // gemm_pp (tools build): shader cycles of one output tile, per-CU start stagger (0 = off)
     int xcd_stagger_ticks;        // persistent kernels: XCD x starts x * ticks / 8 wall-clock ticks (100 MHz) late (0 = off)

@@ -62,6 +62,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
 struct TileCtx {
     __amdgpu_buffer_rsrc_t ra, rw;
     int m0, n0;
+    int part;                                                // PARTS (EPI_F32 with PgGemmExtra::parts > 1): which product this tile belongs to
 };
 
 // Tile order.  Logical ids are laid out band by band (a band = 32/gn M-panels x all N-panels); inside a band the ids
@@ -69,9 +70,18 @@ struct TileCtx {
 // is plain N-fastest order.  A persistent round gives every XCD 32 consecutive ids, i.e. one (32/gn) x gn super-tile:
 // the unique operand bytes an XCD's L2 must fetch per K step are (32/gn + gn) panels (12 for 8 x 4, against 14.7 /
 // 18 for N-fastest rows of 12 / 16 tiles).
-template <int ABL>
+template <int ABL, bool PARTS = false>
 __device__ __forceinline__ TileCtx make_tile(const GemmArgs& g, int L) {
     TileCtx c;
+    c.part = 0;
+    const uint16_t* Ab = g.A;
+    const uint16_t* Wb = g.W;
+    if constexpr (PARTS) {                                   // tiles of part 0 first, then part 1, ...: same raster inside each part
+        c.part = L / g.part_tiles;
+        L -= c.part * g.part_tiles;
+        Ab += (int64_t)c.part * g.ex.a_part;
+        Wb += (int64_t)c.part * g.ex.w_part;
+    }
     const int gmax = g.gn >= 32 ? 1 : 32 / g.gn;
     const int band_sz = gmax * g.tilesN;
     const int band = L / band_sz, rem = L - band * band_sz;
@@ -85,8 +95,8 @@ __device__ __forceinline__ TileCtx make_tile(const GemmArgs& g, int L) {
         c.ra = make_rsrc(g.A, (uint32_t)PP_BM * (uint32_t)g.lda * 2u);
         c.rw = make_rsrc(g.W, (uint32_t)PP_BN * (uint32_t)g.ldw * 2u);
     } else {
-        c.ra = make_rsrc(g.A + (int64_t)c.m0 * g.lda, (uint32_t)rows * (uint32_t)g.lda * 2u);
-        c.rw = make_rsrc(g.W + (int64_t)c.n0 * g.ldw, (uint32_t)PP_BN * (uint32_t)g.ldw * 2u);
+        c.ra = make_rsrc(Ab + (int64_t)c.m0 * g.lda, (uint32_t)rows * (uint32_t)g.lda * 2u);
+        c.rw = make_rsrc(Wb + (int64_t)c.n0 * g.ldw, (uint32_t)PP_BN * (uint32_t)g.ldw * 2u);
     }
     return c;
 }
@@ -414,6 +424,11 @@ __device__ __forceinline__ void load_bias(EpiBias<EPI>& b, const GemmArgs& g, in
         b.shi = *(const f32x4*)(g.ex.colsum + col + 4);
     }
 }
+template <int EPI>
+__device__ __forceinline__ void zero_bias(EpiBias<EPI>& b) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    b.lo = z; b.hi = z;
+}
 // (rstd, mean*rstd) of the 16 rows this lane stores: issued right after the tile's first wait, lands under the K loop
 template <int EPI>
 __device__ __forceinline__ void load_rowstat(u32x2 (&rs)[4][4], const GemmArgs& g, int row0, int rr) {
@@ -643,6 +658,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     const int ecc = EPI == EPI_RESID_STAT ? (lane & 7) * 4 : (lane % (64 / ECPL)) * ECPL;
     const int nt = g.K / BK;                                 // even (checked on the host)
     const int nblk = gridDim.x;
+    // EPI_F32 only (the exact mode's GEMMs): several independent products in one launch, see PgGemmExtra::parts.  The other
+    // epilogues -- every kernel of the fast path -- compile exactly as before.
+    constexpr bool PARTS = (EPI == EPI_F32) && ABL == 0;
     int L = xcd_remap(blockIdx.x, nblk);
     if (L >= g.ntiles) return;
     xcd_stagger_wait(g.xcd_stagger_ticks);
@@ -654,11 +672,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         const long long until = (long long)__builtin_readcyclecounter() + (long long)g.stagger * slot / 32;
         while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(8);
     }
-    TileCtx c = make_tile<ABL>(g, L);
+    TileCtx c = make_tile<ABL, PARTS>(g, L);
     issue_dma<0, 8>(c, smem, wave, voffA, voffW, 0);         // K tile 0 of the first output tile -> stage 0
     EpiBias<EPI> bias;
     const int err = lane / (64 / ECPL);                      // the lane's first row inside a 32-row slab on the store side
     load_bias<EPI>(bias, g, c.n0 + wn * 64 + ecc);
+    if constexpr (PARTS) { if (c.part > 0) zero_bias<EPI>(bias); }       // the bias rides in part 0 only
     pin_bias<EPI>(bias);
     // Number of global stores an epilogue issues AFTER its last load / DMA.  vmcnt retires in order, so at the top of
     // the next tile `vmcnt(NST)` means "the prefetched K tile 0 (and the next bias) has landed" while the epilogue's
@@ -729,6 +748,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
         PG_TS(g, dbg_iter, wave, 2);
         const int row0 = c.m0 + wm * 128, col0 = c.n0 + wn * 64;
+        const int part_now = c.part;                         // (prefetch_next below replaces c by the NEXT tile's context)
         L += nblk;
         const bool more = L < g.ntiles;
         EpiBias<EPI> bias_next = bias;
@@ -737,11 +757,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         // count its in-order vmcnt waits along the path WITHOUT the block, i.e. on the common path it waits for ten extra
         // (younger) operations -- a full memory latency at the start of every epilogue.
         auto prefetch_next = [&]() {
-            c = make_tile<ABL>(g, more ? L : L - nblk);
+            c = make_tile<ABL, PARTS>(g, more ? L : L - nblk);
             issue_dma<0, 8>(c, smem, wave, voffA, voffW, 0);      // next output tile's K tile 0 -> stage 0 (free since K tile nt-2)
             load_bias<EPI>(bias_next, g, c.n0 + wn * 64 + ecc);   // older than the epilogue's last stores: see NST
+            if constexpr (PARTS) { if (c.part > 0) zero_bias<EPI>(bias_next); }
         };
-        pp_epilogue<T, EPI, XEARLY>(acc, g, smem, wave, lane, row0, col0, bias, rs, prefetch_next, xc, xq, dbg_iter);
+        if constexpr (PARTS) {
+            GemmArgs ge = g;                                 // what the epilogue sees: this tile's own output buffer
+            ge.out = (float*)g.out + (int64_t)part_now * g.ex.c_part;
+            pp_epilogue<T, EPI, XEARLY>(acc, ge, smem, wave, lane, row0, col0, bias, rs, prefetch_next, xc, xq, dbg_iter);
+        } else {
+            pp_epilogue<T, EPI, XEARLY>(acc, g, smem, wave, lane, row0, col0, bias, rs, prefetch_next, xc, xq, dbg_iter);
+        }
         PG_TS(g, dbg_iter, wave, 9);
         ++dbg_iter;
         if (!more) break;
@@ -843,7 +870,11 @@ int pg_gemm_pp_launch(int dtype, GemmArgs g, int epi, int variant, hipStream_t s
     }
     g.tilesM = (g.M + PP_BM - 1) / PP_BM;
     g.tilesN = g.N / PP_BN;
-    g.ntiles = g.tilesM * g.tilesN;
+    g.part_tiles = g.tilesM * g.tilesN;
+    if (g.ex.parts < 1) g.ex.parts = 1;
+    if (g.ex.parts > 1 && epi != EPI_F32) { pg_set_error("gemm_pp: parts > 1 exists for EPI_F32 only (epi = %d)", epi); return PG_EINVAL; }
+    if ((int64_t)g.part_tiles * g.ex.parts >= (1ll << 30)) { pg_set_error("gemm_pp: too many tiles"); return PG_EINVAL; }
+    g.ntiles = g.part_tiles * g.ex.parts;
     int cap = num_cus();
     if (pg_gemm_block_cap() > 0 && pg_gemm_block_cap() < cap) cap = pg_gemm_block_cap();   // tuning: share the chip between streams
     const int nblk = g.ntiles < cap ? g.ntiles : cap;

@@ -18,6 +18,11 @@ struct PgGemmExtra {
     int64_t ldx = 0;
     float* statpart = nullptr;         // [N/64][stat_rows][2] EPI_RESID_STAT: partial (sum, sum of squares) per 64-column slice
     int64_t stat_rows = 0;             // rows per slice of statpart; 0 = M (pg_gemm_launch fills it in before it splits a problem)
+    // EPI_F32 on the 256 x 256 persistent kernel only (exact mode, round 5): the problem is `parts` independent products that share
+    // M, N, K and the leading dimensions -- part p reads A + p * a_part and W + p * w_part (elements) and writes out + p * c_part
+    // (floats); the bias goes into part 0 only.  All parts' tiles form ONE persistent launch (parts x tilesM x tilesN tiles).
+    int parts = 1;
+    int64_t a_part = 0, w_part = 0, c_part = 0;
 };
 
 void pg_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));

@@ -171,9 +171,6 @@ struct pg_vit {
     // always-on fp16 range alarm (rowstat_finalize_kernel): rows of the residual stream whose sum of squares reaches 65504^2
     unsigned long long* range_alarm = nullptr;
     float range_alarm_sumsq = 0.f;
-    // exact mode (round 5): side streams on which the K-split parts of one GEMM run concurrently (precise_gemm)
-    hipStream_t ps[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t p_fork = nullptr, p_join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     // hipGraph of the encoder body (round 4): the ~250 launches between im2col and the token mean touch only the workspace and the
     // weights, so one captured graph per (workspace, n_images) replays them with one host call.  Built at the SECOND forward of a
     // key (the first runs eagerly: it also sets the kernels' LDS attributes, which is not a stream operation), on an internal
@@ -706,11 +703,12 @@ extern "C" int pg_vit_forward(pg_vit* h, const void* pixels, int pix_dtype, int 
 // products of one GEMM, 48 KB (fc1: 3 x 4096 fp32) = 98 KB; chunks of <= 64 images.
 //
 // Round 5: every GEMM of the layer loop is cut along K' into S parts (QKV / out / fc1: the three products hi.Wh | lo.Wh | hi.Wl, S = 3;
-// fc2, K' = 12288: S = 6) that run CONCURRENTLY on side streams into fp32 partial buffers and are then summed in a fixed order
-// (sum_parts_kernel).  The exact tier is run on the handful of panoramas a step finds uncertain -- 4 to 16 images, 10 to 40 row panels:
-// one K' = 12288 launch then puts 40 tiles of 192 K tiles each on 256 CUs (326 us per layer for fc2 alone, latency, not work);
-// six launches of 32 K tiles fill the chip instead.  S is fixed per GEMM whatever the batch, so a row's value still does not depend
-// on the batch it rides in; at large batches the parts simply queue behind each other (same MFMA work, one extra streaming pass).
+// fc2, K' = 12288: S = 6) that run as ONE persistent launch over S x tilesM x tilesN tiles (PgGemmExtra::parts) into fp32 partial
+// buffers, which sum_parts_kernel then adds in a fixed order.  The exact tier runs on the handful of panoramas a step finds
+// uncertain -- 4 to 16 images, 10 to 40 row panels: a K' = 12288 launch then puts 40 tiles of 192 K tiles each on 256 CUs (326 us per
+// layer for fc2 alone: latency, not work); 240 tiles of 32 K tiles fill the chip instead.  S is fixed per GEMM whatever the batch,
+// so a row's value still does not depend on the batch it rides in.  (First tried as S concurrent launches on side streams: the
+// launches did not overlap -- 4 images 15.9 against 14.3 ms, 52 images 112 against 76 ms, gpurun_out/r05 -- hence the in-kernel form.)
 #define PG_PRECISE_CHUNK 64
 static size_t precise_ws_bytes_for(int chunk) {
     const size_t M = (size_t)chunk * VIT_TOKENS;
@@ -724,36 +722,18 @@ extern "C" int pg_vit_precise_workspace_bytes(const pg_vit* h, int n_images, siz
     return PG_OK;
 }
 
-// One GEMM of the exact mode, cut along K' into S concurrent parts: part p multiplies columns [p Kp, (p + 1) Kp) of the triple
-// operands into the fp32 partial buffer p (bias rides in part 0), parts 1.. run on side streams forked from / joined to `s` with
-// events; then dst = (resid ? dst : 0) + sum of the parts, in part order.
+// One GEMM of the exact mode, cut along K' into S parts that run as ONE persistent launch (PgGemmExtra::parts: S x tilesM x tilesN
+// tiles on the 256 CUs): part p multiplies columns [p Kp, (p + 1) Kp) of the triple operands into the fp32 partial buffer p (the
+// bias rides in part 0); then dst = (resid ? dst : 0) + sum of the parts, in part order (sum_parts_kernel).
 static int precise_gemm(pg_vit* h, const uint16_t* A3, int64_t lda, const uint16_t* W3, int64_t ldw, const float* bias, float* parts,
                         float* dst, bool resid, int M, int N, int Ktot, int S, hipStream_t s) {
-    const int dt = PG_DTYPE_F16, V = 36;
+    (void)h;
     const int Kp = Ktot / S;
-    if (S < 1 || S > 6 || Kp * S != Ktot || (Kp % 128) != 0) { pg_set_error("precise_gemm: bad K split (K' = %d, S = %d)", Ktot, S); return PG_EINVAL; }
-    if (!h->p_fork) PG_HIP(hipEventCreateWithFlags(&h->p_fork, hipEventDisableTiming));
-    for (int p = 0; p + 1 < S; ++p) {
-        if (!h->ps[p]) PG_HIP(hipStreamCreateWithFlags(&h->ps[p], hipStreamNonBlocking));
-        if (!h->p_join[p]) PG_HIP(hipEventCreateWithFlags(&h->p_join[p], hipEventDisableTiming));
-    }
+    if (S < 1 || S > 8 || Kp * S != Ktot || (Kp % 128) != 0) { pg_set_error("precise_gemm: bad K split (K' = %d, S = %d)", Ktot, S); return PG_EINVAL; }
     const int64_t part_elems = (int64_t)M * N;
-    PG_HIP(hipEventRecord(h->p_fork, s));
-    int rc = PG_OK;
-    for (int p = 0; p < S && rc == PG_OK; ++p) {
-        hipStream_t sp = p == 0 ? s : h->ps[p - 1];
-        if (p > 0) { hipError_t e = hipStreamWaitEvent(sp, h->p_fork, 0); if (e != hipSuccess) { pg_set_error("precise_gemm: fork failed: %s", hipGetErrorString(e)); rc = PG_EHIP; break; } }
-        rc = pg_gemm_launch(dt, A3 + (int64_t)p * Kp, lda, W3 + (int64_t)p * Kp, ldw, p == 0 ? bias : nullptr, parts + p * part_elems, N, M, N, Kp,
-                            EPI_F32, 1.f, 0, nullptr, V, sp);
-    }
-    // the caller's stream continues when every part is done -- also after a failed launch in the middle (work already queued on a
-    // side stream still writes the partial buffers)
-    for (int p = 1; p < S; ++p) {
-        hipError_t e = hipEventRecord(h->p_join[p - 1], h->ps[p - 1]);
-        if (e == hipSuccess) e = hipStreamWaitEvent(s, h->p_join[p - 1], 0);
-        if (e != hipSuccess && rc == PG_OK) { pg_set_error("precise_gemm: join failed: %s", hipGetErrorString(e)); rc = PG_EHIP; }
-    }
-    if (rc != PG_OK) return rc;
+    PgGemmExtra ex;
+    ex.parts = S; ex.a_part = Kp; ex.w_part = Kp; ex.c_part = part_elems;
+    RC(pg_gemm_launch(PG_DTYPE_F16, A3, lda, W3, ldw, bias, parts, N, M, N, Kp, EPI_F32, 1.f, 0, nullptr, 36, s, &ex));
     return pg_sum_parts_launch(parts, S, part_elems, dst, part_elems, resid ? 1 : 0, s);
 }
 
@@ -820,8 +800,6 @@ extern "C" int pg_vit_destroy(pg_vit* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (auto& e : h->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& g : h->graphs) graph_entry_free(g);
-    for (int i = 0; i < 5; ++i) { if (h->ps[i]) (void)hipStreamDestroy(h->ps[i]); if (h->p_join[i]) (void)hipEventDestroy(h->p_join[i]); }
-    if (h->p_fork) (void)hipEventDestroy(h->p_fork);
     if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
     delete h;
     return PG_OK;
@@ -971,6 +949,15 @@ extern "C" int pg_op_token_mean(const float* x, float* out, int n_images, void* 
 extern "C" int pg_op_cast_f32(const float* x, void* y, int out_dtype, int64_t n, void* stream) {
     if (!x || !y) { pg_set_error("op_cast_f32: null argument"); return PG_EINVAL; }
     return pg_cast_f32_launch(x, y, out_dtype, n, (hipStream_t)stream);
+}
+
+extern "C" int pg_op_gemm16_parts(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* parts,
+                                  int M, int N, int Kp, int S, void* stream) {
+    if (!A || !W || !parts) { pg_set_error("op_gemm16_parts: null argument"); return PG_EINVAL; }
+    if (S < 1 || S > 8) { pg_set_error("op_gemm16_parts: 1 <= S <= 8"); return PG_EINVAL; }
+    PgGemmExtra ex;
+    ex.parts = S; ex.a_part = Kp; ex.w_part = Kp; ex.c_part = (int64_t)M * N;
+    return pg_gemm_launch(dtype, A, lda, W, ldw, bias, parts, N, M, N, Kp, EPI_F32, 1.f, 0, nullptr, 36, (hipStream_t)stream, &ex);
 }
 
 // exact-mode building blocks (precise.hip), exported for the parity tests

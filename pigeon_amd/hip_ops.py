@@ -505,6 +505,20 @@ def x3_split(x: torch.Tensor, gelu: bool = False) -> torch.Tensor:
     return y
 
 
+def gemm16_parts(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], S: int) -> torch.Tensor:
+    """pg_op_gemm16_parts: A (M, S*Kp), W (N, S*Kp) 16-bit -> (S, M, N) fp32, part p = A[:, p Kp:(p+1) Kp] x W[:, p Kp:(p+1) Kp]^T
+    (+ bias for p = 0), all parts in one persistent launch."""
+    _dev(A); _dev(W)
+    if W.dtype != A.dtype or A.shape[1] != W.shape[1] or A.shape[1] % S:
+        raise _lib.PigeonHipError("gemm16_parts: A and W must share dtype and a K' divisible by S")
+    M, Kt = A.shape
+    N = W.shape[0]
+    out = torch.empty((S, M, N), dtype=torch.float32, device=A.device)
+    check(load().pg_op_gemm16_parts(_dt16(A), _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(out), M, N, Kt // S, S, _stream()),
+          "pg_op_gemm16_parts")
+    return out
+
+
 def x3_layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     _dev(x, torch.float32)
     rows = x.numel() // HIDDEN

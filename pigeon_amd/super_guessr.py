@@ -259,6 +259,8 @@ class SuperGuessr(nn.Module):
         st = self._head_with_tol(head_in, exact=False)
         st['embedding'], st['head_in'], st['pixel_values'] = embedding, head_in, px
         st['certain'] = st['tol'] > self.certainty.threshold()
+        if self.certainty.force_exact and px is not None and self.exact_top1:
+            st['certain'] = torch.zeros_like(st['certain'])              # the fast path is outside the contract on these weights
         st['exact'] = torch.zeros_like(st['certain'])
         st['reencoded'] = torch.empty((0,), dtype=torch.int64, device=dev)
         return st
@@ -335,9 +337,14 @@ class SuperGuessr(nn.Module):
         n = min(max_samples, px.shape[0] // P)
         px = px[:n * P]
         enc = self._encoder()
-        fast = enc.embed(px).reshape((-1, P, CLIP_EMBED_DIM)).mean(dim=1)
-        exact = enc.embed_precise(px).reshape((-1, P, CLIP_EMBED_DIM)).mean(dim=1)
-        return self.certainty.calibrate(fast, exact)
+        fast_i, exact_i = enc.embed(px), enc.embed_precise(px)
+        st = self.certainty.calibrate(fast_i.reshape((-1, P, CLIP_EMBED_DIM)).mean(dim=1), exact_i.reshape((-1, P, CLIP_EMBED_DIM)).mean(dim=1),
+                                      fast_images=fast_i, exact_images=exact_i)
+        if self.certainty.force_exact:
+            print(f'pigeon_amd.SuperGuessr: the 16-bit encoder measures {st["image_rel_err"]:.2e} (worst image '
+                  f'{st["worst_image_rel_err"]:.2e}) against the exact encoder on these weights -- outside the 1e-3 embedding '
+                  f'contract; every sample will be encoded in the exact mode (about 4x the time per image).')
+        return st
 
     @torch.no_grad()
     def calibrate_certainty(self, pixel_values: Tensor, max_samples: int = 32) -> float:

@@ -232,61 +232,6 @@ def test_gemm_resid_stat_on_384_row_tiles_bit_identical(env):
     assert torch.allclose(ref[0][:2048], want, rtol=2e-3, atol=2e-3)
 
 
-def test_gemm_w4_one_wave_per_simd_kernel(env):
-    """gemm_w4.hip (variant 64, experimental): v_mfma_f32_16x16x32 sums the k products of an instruction in another
-    association than the 32x32x16 kernels, so it is held to fp32 rounding against variant 36 -- every epilogue incl. the
-    LayerNorm-fold ones, many tiles per block, ragged M, guard rows -- and to bit-exactness against ITSELF across batch
-    positions (a row's result must not depend on which tile / block computes it)."""
-    ops, L = env["ops"], env["lib"]
-    if not L.LIB_PATH.endswith("_dev.so"):
-        pytest.skip("variant 64 lives in the tools build only (PIGEON_HIP_LIB=pigeon_amd/libpigeon_hip_dev.so)")
-    g = torch.Generator().manual_seed(10)
-    M, N, K = 70 * 256 + 19, 1024, 256
-    dt = torch.float16
-    A = torch.randn((M, K), generator=g).to(dt).to(DEV)
-    W = (torch.randn((N, K), generator=g) * 0.05).to(dt).to(DEV)
-    bias = torch.randn(N, generator=g).to(DEV)
-    X0 = torch.randn((M, N), generator=g).to(DEV)
-
-    def close(a, b):
-        a, b = a.float(), b.float()
-        return bool(((a - b).abs() <= 1e-5 * a.abs().max() + 2e-3 * a.abs()).all())
-
-    for epi in (L.EPI_QKV, L.EPI_GELU, L.EPI_RESID, L.EPI_F32):
-        outs = []
-        for var in (36, 64):
-            if epi in (L.EPI_QKV, L.EPI_GELU):
-                o = torch.full((M + 3, N), 7.0, dtype=dt, device=DEV)
-            elif epi == L.EPI_RESID:
-                # >= 384 guard rows: the wrapper then runs the kernel IN PLACE (no padded copy), so a write past row M would be seen
-                o = torch.cat([X0, torch.full((387, N), 7.0, device=DEV)]).contiguous()
-            else:
-                o = torch.full((M + 3, N), 7.0, device=DEV)
-            ops.gemm16(A, W, bias, o, epi, qscale=0.25, qcols=256, variant=var, M=M)
-            outs.append(o)
-        torch.cuda.synchronize()
-        assert close(outs[0][:M], outs[1][:M]), f"epilogue {epi}"
-        assert bool((outs[1][M:].float() == 7.0).all())
-    rs = torch.stack([torch.rand(M, generator=g) + 0.5, torch.randn(M, generator=g)], dim=1).contiguous().to(DEV)
-    cs = torch.randn(N, generator=g).to(DEV)
-    for epi in (L.EPI_QKV_LN, L.EPI_GELU_LN):
-        a_, b_ = (ops.gemm16_ln(A, W, bias, cs, rs, epi, qscale=0.25, qcols=256, variant=v) for v in (36, 64))
-        assert close(a_, b_), f"epilogue {epi}"
-    res = []
-    for v in (36, 64):
-        X = X0.clone()
-        x16, part = ops.gemm16_resid_stat(A, W, bias, X, variant=v)
-        res.append((X, x16, part))
-    for a_, b_ in zip(res[0], res[1]):
-        assert close(a_, b_)
-    # self-consistency: rows 512.. of the big problem == the same rows computed as a problem of their own
-    sub = torch.zeros((M - 512, N), device=DEV)
-    full = torch.zeros((M, N), device=DEV)
-    ops.gemm16(A, W, bias, full, L.EPI_F32, variant=64)
-    ops.gemm16(A[512:].contiguous(), W, bias, sub, L.EPI_F32, variant=64)
-    assert torch.equal(full[512:], sub)
-
-
 def test_gemm_identity_is_not_transposed(env):
     ops, L = env["ops"], env["lib"]
     A = torch.eye(256).to(torch.float16).to(DEV)

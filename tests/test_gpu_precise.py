@@ -78,6 +78,25 @@ def test_split_gemm_vs_fp64(env, capsys):
     assert e3 < e1 / 100
 
 
+def test_gemm_parts_one_launch(env):
+    """PgGemmExtra::parts (round 5): S products in ONE persistent launch.  Every part must equal -- bit for bit -- the same kernel
+    launched on its column slice alone (same tiles, same K order), the bias must ride in part 0 only, and the fixed-order sum of the
+    parts of a triple GEMM must be the fp32-grade product; ragged M, more tiles than CUs, S = 3 and 6."""
+    ops, lib = env["ops"], env["lib"]
+    g = torch.Generator().manual_seed(15)
+    for (M, N, Kp, S) in ((1000, 512, 256, 3), (2308, 1024, 512, 6), (70 * 256 + 19, 1024, 128, 3)):
+        A = torch.randn((M, S * Kp), generator=g).half().to(DEV)
+        W = (torch.randn((N, S * Kp), generator=g) * 0.05).half().to(DEV)
+        bias = torch.randn((N,), generator=g).to(DEV)
+        parts = ops.gemm16_parts(A, W, bias, S)
+        for p in range(S):
+            one = torch.empty((M, N), dtype=torch.float32, device=DEV)
+            ops.gemm16(A[:, p * Kp:(p + 1) * Kp], W[:, p * Kp:(p + 1) * Kp], bias if p == 0 else None, one, lib.EPI_F32, variant=36)
+            assert torch.equal(parts[p], one), (M, N, Kp, S, p)
+        ref = A.double() @ W.double().t() + bias.double()
+        assert _rel(parts.double().sum(dim=0).cpu(), ref.cpu()) < 1e-6
+
+
 def test_x3_layernorm_and_gelu(env):
     ops = env["ops"]
     g = torch.Generator().manual_seed(6)
@@ -305,5 +324,23 @@ def test_stress_towers_vs_reference_module(env, capsys, tower):
     _report([line], f"stress_tower_{tower.replace('+', '_')}.txt")
     enc.close()
     assert alarm == 0
-    assert e_fast < 1e-3 and worst < 1e-3, "the fast path leaves the 1e-3 contract on this tower (per image)"
     assert e_exact < EXACT_TOL
+    if tower == "trained_like+spread":
+        assert e_fast < 1e-3 and worst < 1e-3, "the fast path leaves the 1e-3 contract on this tower (per image)"
+        return
+    # all heads at high gain: the 16-bit path itself is at / beyond the contract (measured 9.5e-4 overall, worst image 1.1e-3).  The
+    # PRODUCT must notice: the calibration (on other images) measures it and sends every sample through the exact encoder.
+    from pigeon_amd.clip_embedder import HipCLIPVisionModel
+    from pigeon_amd.super_guessr import SuperGuessr
+    import tempfile
+    gp = os.path.join(tempfile.mkdtemp(prefix="pigeon_stress_"), "g.csv")
+    syn.write_geocell_csv(gp, syn.make_geocells(300, seed=0))
+    model = SuperGuessr(HipCLIPVisionModel(sd, layers=24).to(DEV), freeze_base=True, num_candidates=5, geocell_path=gp).to(DEV).eval()
+    model.calibrate_certainty(syn.make_pixels(32, seed=99).to(DEV))
+    st = model.certainty.stats
+    out = model(pixel_values=px, labels_clf=None)
+    worst_p = float(((out.embedding.cpu().double() - ref.double()).norm(dim=1) / ref.double().norm(dim=1)).max())
+    with capsys.disabled():
+        print(f"   product on this tower: calibration per image {st['image_rel_err']:.2e} (worst {st['worst_image_rel_err']:.2e}) -> force_exact "
+              f"{st['force_exact']}; embeddings returned: worst image {worst_p:.2e}, re-encoded {model.last_reencoded.numel()}/16")
+    assert st["force_exact"] and model.last_reencoded.numel() == 16 and worst_p < EXACT_TOL
