@@ -17,6 +17,7 @@
 #include "common.h"
 #include "pigeon_internal.h"
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -702,13 +703,13 @@ extern "C" int pg_vit_forward(pg_vit* h, const void* pixels, int pix_dtype, int 
 // 4096-wide activation 24 KB (the im2col triple and the fp32 attention output live there too) | (round 5) PP, the K-split partial
 // products of one GEMM, 48 KB (fc1: 3 x 4096 fp32) = 98 KB; chunks of <= 64 images.
 //
-// Round 5: every GEMM of the layer loop is cut along K' into S parts (QKV / out / fc1: the three products hi.Wh | lo.Wh | hi.Wl, S = 3;
-// fc2, K' = 12288: S = 6) that run as ONE persistent launch over S x tilesM x tilesN tiles (PgGemmExtra::parts) into fp32 partial
+// Round 5: a GEMM of the layer loop whose tiles would not fill the chip is cut along K' into S parts (the products hi.Wh | lo.Wh |
+// hi.Wl, or halves of them) that run as ONE persistent launch over S x tilesM x tilesN tiles (PgGemmExtra::parts) into fp32 partial
 // buffers, which sum_parts_kernel then adds in a fixed order.  The exact tier runs on the handful of panoramas a step finds
 // uncertain -- 4 to 16 images, 10 to 40 row panels: a K' = 12288 launch then puts 40 tiles of 192 K tiles each on 256 CUs (326 us per
-// layer for fc2 alone: latency, not work); 240 tiles of 32 K tiles fill the chip instead.  S is fixed per GEMM whatever the batch,
-// so a row's value still does not depend on the batch it rides in.  (First tried as S concurrent launches on side streams: the
-// launches did not overlap -- 4 images 15.9 against 14.3 ms, 52 images 112 against 76 ms, gpurun_out/r05 -- hence the in-kernel form.)
+// layer for fc2 alone: latency, not work); 240 tiles of 32 K tiles fill the chip instead.  S is chosen per shape by a small cost
+// model (precise_parts).  (First tried as S concurrent launches on side streams: the launches did not overlap -- 4 images 15.9
+// against 14.3 ms, 52 images 112 against 76 ms, gpurun_out/r05/exact_small_batches_ksplit.txt -- hence the in-kernel form.)
 #define PG_PRECISE_CHUNK 64
 static size_t precise_ws_bytes_for(int chunk) {
     const size_t M = (size_t)chunk * VIT_TOKENS;
@@ -722,14 +723,39 @@ extern "C" int pg_vit_precise_workspace_bytes(const pg_vit* h, int n_images, siz
     return PG_OK;
 }
 
-// One GEMM of the exact mode, cut along K' into S parts that run as ONE persistent launch (PgGemmExtra::parts: S x tilesM x tilesN
-// tiles on the 256 CUs): part p multiplies columns [p Kp, (p + 1) Kp) of the triple operands into the fp32 partial buffer p (the
-// bias rides in part 0); then dst = (resid ? dst : 0) + sum of the parts, in part order (sum_parts_kernel).
+// How many K-parts for one GEMM of the exact mode: the S (out of `cand`) with the smallest modelled time on `ncu` CUs --
+//   rounds(S) x (K tiles per part x 1.7 us + epilogue) + the sum pass (S + 1 or S + 2 streams of M x N floats at ~4 TB/s).
+// A pure function of the shape: the same batch size always takes the same path (results differ between S only in fp32 summation
+// order, ~1e-7 relative, two orders below the exact tier's own floor).  Measured on MI355X (gpurun_out/r05/exact8_kernel_stats.csv,
+// 8 images): out-projection 107 -> 54 us, fc2 351 -> 158 us with S = 3 / 6; QKV and fc1 (216 / 288 tiles of 48 K tiles) gain nothing
+// from a split at that size and lose at larger ones, which the model reproduces.
+static int precise_parts(int M, int N, int Ktot, bool resid, const int* cand, int ncand) {
+    const double ncu = (double)pg_num_cus();
+    const double tiles = (double)((M + 255) / 256) * (N / 256);
+    int best = 1; double best_us = 1e30;
+    for (int i = 0; i < ncand; ++i) {
+        const int S = cand[i];
+        if (Ktot % S || (Ktot / S) % 128) continue;
+        const double rounds = ceil(S * tiles / ncu);
+        const double epi = (S == 1 && resid) ? 25.0 : 12.0;
+        double us = rounds * ((Ktot / S / 64) * 1.7 + epi);
+        if (S > 1) us += 4.0 + (double)(S + (resid ? 2 : 1)) * M * N * 4.0 / 4.0e6;
+        if (us < best_us) { best_us = us; best = S; }
+    }
+    return best;
+}
+
+// One GEMM of the exact mode.  S = 1: the plain launch (EPI_F32 into dst / EPI_RESID onto dst).  S > 1: cut along K' into S parts
+// that run as ONE persistent launch (PgGemmExtra::parts: S x tilesM x tilesN tiles on the 256 CUs): part p multiplies columns
+// [p Kp, (p + 1) Kp) of the triple operands into the fp32 partial buffer p (the bias rides in part 0); then
+// dst = (resid ? dst : 0) + sum of the parts, in part order (sum_parts_kernel).
 static int precise_gemm(pg_vit* h, const uint16_t* A3, int64_t lda, const uint16_t* W3, int64_t ldw, const float* bias, float* parts,
-                        float* dst, bool resid, int M, int N, int Ktot, int S, hipStream_t s) {
+                        float* dst, bool resid, int M, int N, int Ktot, const int* cand, int ncand, hipStream_t s) {
     (void)h;
+    const int S = precise_parts(M, N, Ktot, resid, cand, ncand);
+    if (S == 1)
+        return pg_gemm_launch(PG_DTYPE_F16, A3, lda, W3, ldw, bias, dst, N, M, N, Ktot, resid ? EPI_RESID : EPI_F32, 1.f, 0, nullptr, 36, s);
     const int Kp = Ktot / S;
-    if (S < 1 || S > 8 || Kp * S != Ktot || (Kp % 128) != 0) { pg_set_error("precise_gemm: bad K split (K' = %d, S = %d)", Ktot, S); return PG_EINVAL; }
     const int64_t part_elems = (int64_t)M * N;
     PgGemmExtra ex;
     ex.parts = S; ex.a_part = Kp; ex.w_part = Kp; ex.c_part = part_elems;
@@ -749,6 +775,7 @@ static int vit_precise_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n
     float* PP = (float*)((char*)G3 + align_up((size_t)M * 3 * F * 2, 256));     // K-split partial products of one GEMM
     const float eps = h->cfg.ln_eps;
     const int dt = PG_DTYPE_F16, V = 36;                      // the 256 x 256 persistent kernel takes every epilogue used here
+    static const int S3[2] = {1, 3}, S6[4] = {1, 2, 3, 6};    // K-part counts precise_parts may choose from (K' = 3072 / 12288)
     RC(pg_x3_im2col_launch(pixels, pix_dtype, G3, n, s));
     RC(pg_gemm_launch(dt, G3, 3 * VIT_PATCH_KPAD, h->wpatch3, 3 * VIT_PATCH_KPAD, nullptr, X, D, n * VIT_PATCHES, D, 3 * VIT_PATCH_KPAD,
                       EPI_PATCH, 1.f, 0, h->pos, V, s));
@@ -756,14 +783,14 @@ static int vit_precise_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n
     for (int l = 0; l < h->cfg.layers; ++l) {
         const LayerW& L = h->layers[l];
         RC(pg_x3_ln_launch(X, L.ln1g, L.ln1b, T3, M, eps, s));
-        RC(precise_gemm(h, T3, 3 * D, L.wqkv3, 3 * D, L.bqkv_raw, PP, Fb, false, (int)M, 3 * D, 3 * D, 3, s));
+        RC(precise_gemm(h, T3, 3 * D, L.wqkv3, 3 * D, L.bqkv_raw, PP, Fb, false, (int)M, 3 * D, 3 * D, S3, 2, s));
         RC(pg_attention_f32_launch(Fb, O, n, s));
         RC(pg_x3_split_launch(O, T3, M, D, 0, s));
-        RC(precise_gemm(h, T3, 3 * D, L.wo3, 3 * D, L.bo, PP, X, true, (int)M, D, 3 * D, 3, s));
+        RC(precise_gemm(h, T3, 3 * D, L.wo3, 3 * D, L.bo, PP, X, true, (int)M, D, 3 * D, S3, 2, s));
         RC(pg_x3_ln_launch(X, L.ln2g, L.ln2b, T3, M, eps, s));
-        RC(precise_gemm(h, T3, 3 * D, L.w13, 3 * D, L.b1_raw, PP, Fb, false, (int)M, F, 3 * D, 3, s));
+        RC(precise_gemm(h, T3, 3 * D, L.w13, 3 * D, L.b1_raw, PP, Fb, false, (int)M, F, 3 * D, S3, 2, s));
         RC(pg_x3_split_launch(Fb, G3, M, F, 1, s));
-        RC(precise_gemm(h, G3, 3 * F, L.w23, 3 * F, L.b2, PP, X, true, (int)M, D, 3 * F, 6, s));
+        RC(precise_gemm(h, G3, 3 * F, L.w23, 3 * F, L.b2, PP, X, true, (int)M, D, 3 * F, S6, 4, s));
     }
     RC(pg_token_mean_launch(X, emb_out, n, s));
     if (hidden_out) PG_HIP(hipMemcpyAsync(hidden_out, X, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));
