@@ -591,7 +591,7 @@ def test_evaluate_consumes_the_references_refiner_cache(env, golden_dir, tmp_pat
 
 def test_run_py_evaluate_exact_top1(env, monkeypatch, capsys):
     """`run.py evaluate none --synthetic 16 --exact-top1`: the entry point with the exact mode on (PIGEON_EXACT_TOP1=1 through the
-    flag).  PIGEON_MARGIN_KAPPA = 1000 puts every panorama inside the certainty band, so the exact pass really runs on all 16;
+    flag).  PIGEON_MARGIN_KAPPA = 1e9 puts every panorama inside the certainty band, so the exact pass really runs on all 16;
     the result dict carries `geocell_certain`, and every geocell equals the oracle's fp32 argmax."""
     import pigeon_amd.evaluate as ev
     orc = env["orc"]
@@ -604,7 +604,7 @@ def test_run_py_evaluate_exact_top1(env, monkeypatch, capsys):
 
     monkeypatch.setattr(ev, "evaluate_model", spy)
     monkeypatch.delenv("PIGEON_EXACT_TOP1", raising=False)
-    monkeypatch.setenv("PIGEON_MARGIN_KAPPA", "1000")
+    monkeypatch.setenv("PIGEON_MARGIN_KAPPA", "1e9")
     try:
         results = _run_main(monkeypatch, ["evaluate", "none", "--synthetic", "16", "--layers", "2", "--geocells", "300", "--exact-top1"])
     finally:

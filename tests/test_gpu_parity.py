@@ -692,8 +692,13 @@ def test_full_size_step_properties(env, vit24, tmp_path):
     px = torch.randn((128, 12, 336, 336), generator=g, device=DEV)
     out = model(pixel_values=px, labels_clf=None)
     assert out.embedding.shape == (128, 4, 1024) and bool(torch.isfinite(out.embedding).all())
+    re_all = set(model.last_reencoded.tolist())
     sub = model(pixel_values=px[17:19].contiguous(), labels_clf=None)               # same panoramas, tiny batch
-    assert torch.equal(sub.embedding, out.embedding[17:19]) and torch.equal(sub.preds_geocell, out.preds_geocell[17:19])
+    if re_all & {17, 18}:      # re-encoded rows: the exact tier's K-part count follows the batch size (fp32 summation order, ~1e-7)
+        assert torch.allclose(sub.embedding, out.embedding[17:19], rtol=1e-5, atol=1e-6)
+    else:
+        assert torch.equal(sub.embedding, out.embedding[17:19])
+    assert torch.equal(sub.preds_geocell, out.preds_geocell[17:19])
     assert torch.equal(out.top5_geocells.indices[:, 0], out.preds_geocell)
     ref = env["orc"].super_guessr_forward(W, b, model.lla_geocells.data.cpu(), 5, embedding=out.embedding.cpu())
     assert torch.equal(out.preds_geocell.cpu(), ref["preds_geocell"])               # head argmax bit-exact on 128 rows

@@ -38,9 +38,9 @@ CLASSES = {"gemm_qkv": (("gemm_pp6_kernel<T_F16, 6", "gemm_pp6_kernel<T_F16, 0",
            # before that the two shared one kernel name ("gemm_out_fc2_mixed")
            "gemm_fc2": (("gemm_pp6_kernel<T_F16, 5",), 2 * 4096 + 4 * 1024 + 4 * 1024 + 2 * 1024),
            "gemm_out": (("gemm_pp_kernel<T_F16, 5,", "gemm_pp_kernel<T_F16, 2,"), 2 * 1024 + 4 * 1024 + 4 * 1024 + 2 * 1024),
-           "attention": (("attention",), 2 * 3072 + 2 * 1024),
+           "attention": (("attention8_kernel",), 2 * 3072 + 2 * 1024),          # (attention_f32_kernel: the exact pass, a few images)
            "layernorm": (("layernorm_kernel",), 4 * 1024 + 2 * 1024),
-           "refine_candidates": (("refine_candidates_kernel",), None)}
+           "refine_candidates": (("refine_candidates_kernel<false>", "refine_candidates_kernel"), None)}    # <true>: the certainty pass
 TAIL_SPLIT = ("gemm_fc1", "gemm_fc2")                # the product's tail policy: K >= 2048 or N >= 4096 (vit.hip PG_DEFAULT_GEMM_TAIL_*)
 res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py, one launch = %d token rows; KiB as "
                "reported; hbm_bytes_per_launch_corrected = 2 x FETCH_SIZE (gfx950 under-report of wide coalesced reads, "
