@@ -827,10 +827,12 @@ def _worker(args, comm):
             model.cell_layer.weight.mul_(sc[0])
             model.cell_layer.bias.copy_(b.to(dev) - model.cell_layer.weight.data @ center)
     if not dry:
-        # one-off, per set of weights: what the 16-bit path's embedding error IS on this model -- 32 panoramas through the fast and the
-        # exact encoder: the systematic part of their difference and the RMS of the rest (pigeon_amd/certainty.py); frozen afterwards
+        # one-off, per set of weights: what the 16-bit path's embedding error IS on this model -- one whole batch through the fast and
+        # the exact encoder: the systematic part of their difference and the RMS of the rest (pigeon_amd/certainty.py); frozen
+        # afterwards.  (A whole batch, not 32 panoramas: every fast-path launch of this process then has the step's shape, so that
+        # rocprofv3's per-kernel averages of this command are the step's.)
         try:
-            model.calibrate_certainty(pixel_batches[nb - 1][-32:])
+            model.calibrate_certainty(pixel_batches[nb - 1], max_samples=args.panoramas)
         except Exception as e:  # noqa  (nothing depends on it but the size of the re-encoded set: the threshold stays at the contract's 1e-3)
             print(f"[bench] certainty calibration failed: {e!r}", file=sys.stderr)
     for i in range(max(args.warmup, 1)):

@@ -115,6 +115,28 @@ def _contract_run(env, vit, golden_dir, tmp_path, fixture, capsys):
                          f"{e_all:.2e} (worst image {e_row:.2e}); top-1 mismatches {len(top1_bad)} {top1_bad.tolist()}; refined (cell or lng/lat) "
                          f"mismatches, unconditional {len(ref_bad)} {ref_bad.tolist()}; certain {int(certain.sum())}/{NP}; re-encoded "
                          f"{len(re)} {re.tolist()}; boundary checked {info['boundary_checked']}")
+            if mode == "fast" and tag == "default" and "top8_cells" in g.files:
+                # is the error model calibrated?  The REAL reference's logits of its eight best cells are in the fixture: per pair
+                # (top-1, rank j) the margin change this path actually shows, minus the systematic part the model predicts
+                # (|e| g.beta), in units of the model's one-sigma (eps |e| |g| / 32) -- should be ~N(0, 1) if the residual error is
+                # isotropic with the measured RMS
+                pe = emb.mean(dim=1).double()
+                Wd = W.double()
+                beta = calib.drift.cpu().double() if calib.drift is not None else torch.zeros(1024, dtype=torch.float64)
+                eps = calib.stats["residual_rms"] if calib.drift is not None else calib.stats["fast_vs_exact_rms"]
+                cells8 = torch.from_numpy(g["top8_cells"])
+                ref8 = torch.from_numpy(g["top8_logits"]).double()
+                hip8 = (pe @ Wd.t() + b.double())[torch.arange(NP)[:, None], cells8]
+                zs = []
+                for j in range(1, 8):
+                    gvec = Wd[cells8[:, 0]] - Wd[cells8[:, j]]
+                    en = pe.norm(dim=1)
+                    d_margin = (hip8[:, 0] - hip8[:, j]) - (ref8[:, 0] - ref8[:, j])
+                    zs.append((d_margin - en * (gvec @ beta)) / (eps * en * gvec.norm(dim=1) / 32.0))
+                z = torch.stack(zs, dim=1)
+                lines.append(f"   error model check on {z.numel()} (top-1, rank j) pairs: (margin change - predicted systematic part) / one-sigma has "
+                             f"RMS {float(z.pow(2).mean().sqrt()):.2f}, max |z| {float(z.abs().max()):.2f} (without the systematic part: RMS "
+                             f"{float(torch.stack([((hip8[:, 0] - hip8[:, j]) - (ref8[:, 0] - ref8[:, j])) / (eps * pe.norm(dim=1) * (Wd[cells8[:, 0]] - Wd[cells8[:, j]]).norm(dim=1) / 32.0) for j in range(1, 8)], dim=1).pow(2).mean().sqrt()):.2f})")
             if mode == "fast":
                 unc = np.nonzero(~certain)[0]
                 by = {}
