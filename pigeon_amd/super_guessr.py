@@ -296,7 +296,9 @@ class SuperGuessr(nn.Module):
         self.last_state = st
 
     def package(self, st: dict, labels: Tensor = None, labels_clf: Tensor = None):
-        """State -> the reference's outputs (:459-483)."""
+        """State -> the reference's outputs (:459-483).  The state's reference to the input pixels is dropped here (it was only
+        needed for a possible re-encode): `last_state` must not keep a whole batch of pixels alive."""
+        st['pixel_values'] = None
         self._publish(st)
         k = self.num_candidates
         geocell_topk = TopK(st['topk_values'][:, :k], st['topk_indices'][:, :k])
