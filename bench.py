@@ -11,9 +11,12 @@ The reference's embed / evaluate path is launched by `accelerate`, which owns pr
 the launcher process starts N workers (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT), rank 0
 prints the JSON line, the launcher returns the first non-zero exit code.
 
-One STEP = one pass of the hot path over one batch of synthetic input already resident in HBM:
+One STEP = one pass of the hot path over one batch of synthetic input already resident in HBM, in the PRODUCT configuration
+(round 5: SuperGuessr(exact_top1=True) -- every discrete output is the fp32 reference's; --fast times the 16-bit path alone):
   BASELINE.json configs[3]: 128 panoramas (4 x 3x336x336 = 512 images) per GPU -> ViT-L/14-336 (24 layers, random
-  init seed 0) -> token mean -> SuperGuessr geocell head (C = 10 000) -> [N>1: one grouped RCCL all-gather of embeddings /
+  init seed 0) -> token mean -> SuperGuessr geocell head (C = 10 000) -> certainty of every decision the head and the refinement
+  will take (pg_head_certainty, pg_refine_forward_ex + pg_refine_certainty) -> ONE exact re-encode (pg_vit_forward_precise) of the
+  panoramas that are not certain, their head outputs recomputed -> [N>1: one grouped RCCL all-gather of embeddings /
   candidates through the C ABI] -> ProtoRefiner top-5 over a 1M x 1024 fp32 prototype bank (10 000 cells x 100) on the
   rank's slice -> [N>1: a second, tiny grouped all-gather of the refined (lng,lat) / geocell, so every rank holds the batch].
 Weak scaling: every rank processes its own 128 panoramas; value = total images / max-over-ranks time.
@@ -23,6 +26,8 @@ streams different prototype rows from HBM every step (otherwise every query asks
 Infinity Cache serves them).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  certainty           the rule, the calibration's measurements, panoramas re-encoded per step and why; fast_mode / exact_cost_vs_fast:
+                      the 16-bit path alone for a few steps after the timed region; per_rank_split_ms: compute vs gather(-wait);
   roofline            the dominant kernel (the fc1 GEMM), algorithmic FLOPs per launch / mean launch time measured live with
                       HIP events on the launch stream during the timed region; `frac_rocprof` = the same fraction from the
                       committed rocprofv3 kernel stats of this command (profiles/rNN/traffic.json);
@@ -40,8 +45,11 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
                       resident pixel batch; plus `reference_module`: transformers.CLIPVisionModel -- the module the reference
                       itself calls -- on the CPU on 32 of those images (rank 0, N=1 only);
   parity_vs_oracle_sample   the oracle's answer for those 16 panoramas FROM THE PIXELS against this very run's outputs: per
-                      panorama the oracle's top-1 / top-2 logit margin, the HIP - oracle logit deltas of those two cells, and
-                      whether the argmax differs; a flip counts as explained only below margin < 2 x the measured logit error.
+                      panorama the oracle's top-1 / top-2 logit margin, the HIP - oracle logit deltas of those two cells,
+                      whether the argmax differs, and `refined_mismatch_unconditional` (refined cell or (lng, lat) different from
+                      the oracle chain's, whatever the reason); the same for the fast mode beside it;
+  parity_vs_reference_module_gpu_fp32   the same over ALL 512 panoramas of the resident batches, against the reference's own
+                      module in fp32 on this GPU (+ the oracle's head and refinement).
 """
 import argparse
 import contextlib
