@@ -11,16 +11,18 @@
 // so one K' = 3K GEMM with fp32 accumulation delivers the fp32-grade product (the 2^8 keeps Wl -- ~2^-12 |W| ~ 5e-6 for
 // |W| ~ 0.02 -- out of fp16's subnormal range; lo needs no scale: its absolute error is bounded by the subnormal quantum 2^-24).
 // 3x the MFMA work of the fast path per image, 1/5 of what fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak) would cost.
-// Attention (8.6 % of the FLOPs) runs in plain fp32 on that fp32 MFMA: attention_f32_kernel below.
+// Attention (8.6 % of the FLOPs): round 4 ran it in plain fp32 on that fp32 MFMA (attention_f32_kernel, kept as the A/B arm); round 5
+// runs it on split fp16 operands like the GEMMs (attention_x3_kernel).
 //
 // Kernels here (all HBM-bound streaming except attention):
 //   im2col_x3_kernel   pixels (n,3,336,336) -> patch matrix triple [576 n][3 * 640] fp16
 //   ln_x3_kernel       LayerNorm of fp32 rows -> triple [M][3 * 1024]
 //   split_x3_kernel    fp32 [M][C] (optionally through QuickGELU) -> triple [M][3 * C]
 //   sum_parts_kernel   (round 5) fixed-order sum of the K-split partial products of one GEMM (+ the fp32 residual row)
-//   attention_f32_kernel  fp32 QKV [M][3072] -> fp32 O [M][1024], softmax(q k^T / 8) v per (image, head)
+//   attention_x3_kernel / attention_f32_kernel  fp32 QKV [M][3072] -> fp32 O [M][1024], softmax(q k^T / 8) v per (image, head)
 #include "common.h"
 #include "pigeon_internal.h"
+#include <cstdlib>
 
 #define X3_SHIFT_DOWN 0.00390625f          // 2^-8 on the activation side ...
 #define X3_SHIFT_UP 256.0f                 // ... 2^8 on the weight side (vit.hip packs the weights with it)
@@ -180,6 +182,7 @@ int pg_x3_im2col_launch(const void* pixels, int pix_dtype, void* out3, int n_ima
 #define AF_KS 66
 #define AF_VS 72
 typedef __attribute__((ext_vector_type(16))) float af16;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
 
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n_images) {
     __shared__ float Ks[2][32 * AF_KS];
@@ -281,8 +284,174 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
         *(f32x4*)(op + 32 + 8 * j) = b;
     }
 }
+// ---- the same attention on split-fp16 operands (round 5) -----------------------------------------------------------------------
+// attention_f32_kernel spends 64 x v_mfma_f32_32x32x2_f32 (64 cycles each on a SIMD) per 32-key tile and wave; on a few images it is
+// a quarter of the exact pass.  Here both products run on v_mfma_f32_32x32x16_f16 with every operand split in two fp16 halves and the
+// three significant partial products accumulated in fp32 -- x.y ~= xh.yh + xl.yh + xh.yl, the arithmetic of the exact mode's GEMMs:
+//   S^T += Kh.Qh^T + Kl.Qh^T + Kh.Ql^T     A = K tile rows (keys) from LDS (fp16 hi / lo images, 16-byte fragments: key l%32, dims
+//                                          16 kk + 8 (l/32) ..+8), B = Q^T in registers (split once, scaled by log2(e) / 8 first)
+//   O^T += Vh^T.Ph^T + Vl^T.Ph^T + Vh^T.Pl^T   B = the lane's own probabilities: in the 32x32 accumulator layout a lane holds keys
+//                                          8 j + 4 (l/32) + i of query l%32, so for k-step s (keys 16 s ..) its eight k slots are
+//                                          registers 8 s .. 8 s + 7 = keys {16 s + 4 h + i, 16 s + 8 + 4 h + i}; A = V^T rows (dims)
+//                                          from an LDS image that is TRANSPOSED and stored in that very key order (pos_of), so a
+//                                          fragment is one 16-byte read again.
+// 24 MFMAs of 32 cycles per tile and wave instead of 64 of 64; 39 KB of LDS and ~130 VGPRs: three blocks per CU instead of two.
+// Same online softmax (fp32, base 2), same masking of the keys past token 576.  Products lose the lo.lo term (2^-22 relative), as in
+// the GEMMs; fp16 subnormal halves are not flushed by the MFMA (tests/test_gpu_precise.py).
+#define AX_KS 72                                            // halves per K row in LDS (64 + 8): 144-byte rows, 16-byte aligned
+#define AX_VS 40                                            // halves per V^T row (32 keys + 8): 80-byte rows
+__device__ __forceinline__ int ax_pos_of(int key) {         // position of tile-local key 0..31 in a V^T row (see above)
+    const int w = key & 15;
+    return (key & 16) + ((w >> 2) & 1) * 8 + (w >> 3) * 4 + (w & 3);
+}
+
+__global__ __launch_bounds__(256, 3) void attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n_images) {
+    __shared__ __attribute__((aligned(16))) _Float16 Kh[2][32 * AX_KS];
+    __shared__ __attribute__((aligned(16))) _Float16 Kl[2][32 * AX_KS];
+    __shared__ __attribute__((aligned(16))) _Float16 Vh[2][64 * AX_VS];
+    __shared__ __attribute__((aligned(16))) _Float16 Vl[2][64 * AX_VS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qb = blockIdx.x % 5, head = (blockIdx.x / 5) % VIT_HEADS, img = blockIdx.x / (5 * VIT_HEADS);
+    const int half = lane >> 5, l32 = lane & 31;
+    const int64_t row0 = (int64_t)img * VIT_TOKENS;
+    const float* base = qkv + row0 * (3 * VIT_HIDDEN) + head * VIT_HEAD_DIM;
+    const int q = qb * 128 + wave * 32 + l32;
+    const bool q_ok = q < VIT_TOKENS;
+    const bool wave_ok = qb * 128 + wave * 32 < VIT_TOKENS;
+    // Q^T fragments: Q[q][16 kk + 8 half + e] * (1/8) * log2(e), split in fp16 halves
+    f16x8 qh[4], ql[4];
+    {
+        const float* qp = base + (int64_t)(q_ok ? q : 0) * (3 * VIT_HIDDEN) + 8 * half;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = q_ok ? (qp[16 * kk + e] * 0.125f) * 1.4426950408889634f : 0.f;
+                const _Float16 h = (_Float16)v;
+                qh[kk][e] = h;
+                ql[kk][e] = (_Float16)(v - (float)h);
+            }
+    }
+    // cooperative tile loads: thread -> key tid/16 (+16), d4 = (tid%16)*4
+    const int lk = tid >> 4, ld4 = (tid & 15) * 4;
+    f32x4 pk[2], pv[2];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int key = t * 32 + lk + 16 * h;
+            if (key < VIT_TOKENS) {
+                const float* p = base + (int64_t)key * (3 * VIT_HIDDEN) + ld4;
+                pk[h] = *(const f32x4*)(p + VIT_HIDDEN);
+                pv[h] = *(const f32x4*)(p + 2 * VIT_HIDDEN);
+            } else { pk[h] = f32x4{0.f, 0.f, 0.f, 0.f}; pv[h] = pk[h]; }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int key = lk + 16 * h;
+            _Float16 kh4[4], kl4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const _Float16 hh = (_Float16)pk[h][e];
+                kh4[e] = hh; kl4[e] = (_Float16)(pk[h][e] - (float)hh);
+            }
+            *(u32x2*)&Kh[buf][key * AX_KS + ld4] = __builtin_bit_cast(u32x2, *(const f16x4_t*)kh4);
+            *(u32x2*)&Kl[buf][key * AX_KS + ld4] = __builtin_bit_cast(u32x2, *(const f16x4_t*)kl4);
+            const int pos = ax_pos_of(key);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const _Float16 hh = (_Float16)pv[h][e];
+                Vh[buf][(ld4 + e) * AX_VS + pos] = hh;
+                Vl[buf][(ld4 + e) * AX_VS + pos] = (_Float16)(pv[h][e] - (float)hh);
+            }
+        }
+    };
+    af16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m = -INFINITY, lsum = 0.f;
+    const int NT = (VIT_TOKENS + 31) / 32;     // 19
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < NT; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < NT) load_tile(t + 1);
+        if (wave_ok) {
+            af16 sc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+            const _Float16* khp = &Kh[buf][l32 * AX_KS + 8 * half];
+            const _Float16* klp = &Kl[buf][l32 * AX_KS + 8 * half];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const f16x8 ah = *(const f16x8*)(khp + 16 * kk), al = *(const f16x8*)(klp + 16 * kk);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[kk], sc, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[kk], sc, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[kk], sc, 0, 0, 0);
+            }
+            if (t == NT - 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                    if (key >= VIT_TOKENS) sc[r] = -INFINITY;
+                }
+            }
+            float tm = sc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tm = fmaxf(tm, sc[r]);
+            tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+            const float mn = fmaxf(m, tm);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);      // m = -inf on the first tile -> 0
+            m = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sc[r] = __builtin_amdgcn_exp2f(sc[r] - mn); ps += sc[r]; }
+            lsum = lsum * alpha + ps;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                f16x8 ph, pl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const _Float16 hh = (_Float16)sc[8 * s2 + e];
+                    ph[e] = hh;
+                    pl[e] = (_Float16)(sc[8 * s2 + e] - (float)hh);
+                }
+                const int voff = 16 * s2 + 8 * half;
+                const f16x8 v0h = *(const f16x8*)&Vh[buf][l32 * AX_VS + voff], v0l = *(const f16x8*)&Vl[buf][l32 * AX_VS + voff];
+                const f16x8 v1h = *(const f16x8*)&Vh[buf][(l32 + 32) * AX_VS + voff], v1l = *(const f16x8*)&Vl[buf][(l32 + 32) * AX_VS + voff];
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, ph, o0, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l, ph, o0, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pl, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, ph, o1, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l, ph, o1, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, pl, o1, 0, 0, 0);
+            }
+        }
+        if (t + 1 < NT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    if (!q_ok) return;
+    lsum += __shfl_xor(lsum, 32, 64);
+    float* op = out + (row0 + q) * VIT_HIDDEN + head * VIT_HEAD_DIM + 4 * half;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 a = {o0[4 * j] / lsum, o0[4 * j + 1] / lsum, o0[4 * j + 2] / lsum, o0[4 * j + 3] / lsum};
+        f32x4 b = {o1[4 * j] / lsum, o1[4 * j + 1] / lsum, o1[4 * j + 2] / lsum, o1[4 * j + 3] / lsum};
+        *(f32x4*)(op + 8 * j) = a;
+        *(f32x4*)(op + 32 + 8 * j) = b;
+    }
+}
+
+// PIGEON_EXACT_ATTN=f32 selects the fp32-MFMA kernel (the A/B arm and the checker of the split one)
 int pg_attention_f32_launch(const float* qkv, float* out, int n_images, hipStream_t s) {
     if (n_images <= 0) return PG_OK;
-    hipLaunchKernelGGL(attention_f32_kernel, dim3(n_images * VIT_HEADS * 5), dim3(256), 0, s, qkv, out, n_images);
+    static int use_f32 = -1;
+    if (use_f32 < 0) { const char* e = getenv("PIGEON_EXACT_ATTN"); use_f32 = (e && e[0] == 'f') ? 1 : 0; }
+    if (use_f32) hipLaunchKernelGGL(attention_f32_kernel, dim3(n_images * VIT_HEADS * 5), dim3(256), 0, s, qkv, out, n_images);
+    else hipLaunchKernelGGL(attention_x3_kernel, dim3(n_images * VIT_HEADS * 5), dim3(256), 0, s, qkv, out, n_images);
     return pg_check_launch("attention_f32");
 }
