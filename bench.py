@@ -856,8 +856,7 @@ def _worker(args, comm):
         elif args.profile == "none":
             enc.graph(False)                                     # A/B arm: eager launches, no events
         g0 = enc.graph()
-        pipe.refine_events = [] if (refiner is not None and args.profile != "none") else None
-    refine_rows = []
+        pipe.refine_events = None
     outs_by_batch = {}
     certain_by_batch = {}
     info_by_step = []
@@ -874,8 +873,6 @@ def _worker(args, comm):
         info_by_step.append(pipe.last_info)                        # device tensors; read after the timed region
         if not dry:
             certain_by_batch[i % nb] = (pipe.last_info["certain"], model.last_margin, model.last_bound)
-        if refiner is not None and not dry:
-            refine_rows.append(refiner.last_scratch)             # device tensor kept; summed after the timed region
     sync()
     comm.barrier()
     dt = time.perf_counter() - t0
@@ -1043,21 +1040,40 @@ def _worker(args, comm):
     if rccl_error is not None:
         result["rccl"] = {"error": rccl_error, "forced_at_one_rank": False,
                           "note": "the 1-rank RCCL communicator could not be created; the step ran with the identity gather"}
-    if refiner is not None and pipe.refine_events:
-        ms = [a.elapsed_time(b_) for a, b_ in pipe.refine_events]
-        rows = [float(s[..., 3].sum()) for s in refine_rows]
-        bytes_per_launch = 4096.0 * float(np.mean(rows))
-        t = float(np.mean(ms)) * 1e-3
+    if refiner is not None:
+        # The refinement against the HBM roofline.  Timed here, back to back on the launch stream (the host runs ahead), over the
+        # candidate sets of the resident pixel batches in turn (different cells every launch: ~1 GB of distinct bank rows, nothing
+        # comes from the 256 MB Infinity Cache).  Inside the step the exact mode's host synchronisation leaves the launch thread only
+        # microseconds ahead of the GPU at this point, so stream events around the step's own refinement would time the launch
+        # latency (measured: 0.115 ms against 0.058 ms of kernel time in profiles/r05/bench_kernel_stats.csv).
+        sets = [outs_by_batch[j] for j in sorted(outs_by_batch)]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        rows, n_it = [], 20
+        for it in range(2 + n_it):
+            o_ = sets[it % len(sets)]
+            if it == 2:
+                e0.record()
+            refiner(o_["embedding"][own], initial_preds=o_["preds_LLH"][own], candidate_cells=o_["topk_indices"][own],
+                    candidate_probs=o_["topk_values"][own], quiet=True)
+            if it >= 2:
+                rows.append(refiner.last_scratch)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / n_it
+        bytes_per_launch = 4096.0 * float(np.mean([float(s_[..., 3].sum()) for s_ in rows]))
         result["roofline_refine"] = {
             "bound": "hbm", "kernel": "refine_candidates_kernel + refine_select_kernel (one refinement of the rank's 128 queries)",
             "achieved": bytes_per_launch / t / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": bytes_per_launch / t / PEAK_HBM,
             "algorithmic_bytes_per_launch": bytes_per_launch, "avg_ms": t * 1e3,
             "traffic": _committed_traffic("refine_candidates", chunk_rows)[0],
+            "timing": f"{n_it} refinements back to back on the launch stream after the timed region, the candidate sets of the {len(sets)} resident "
+                      "pixel batches in turn",
             "note": "bytes = 4096 B x bank rows streamed (prototypes of the top-k cells + members of the chosen clusters), counted by the "
-                    f"kernel; {nb} pixel batches in turn -> different cells every step, {distinct_cells} distinct argmax cells in the last step. "
-                    "`traffic` (2 x FETCH_SIZE of the committed PMC pass) is ~26 % below the algorithmic bytes: that pass runs ONE timed "
-                    "step after one warm-up step on the same pixel batch, so part of the 265 MB it streams is still in the 256 MB Infinity "
-                    "Cache and never reaches the fabric counters; `achieved` (time-based, 4 batches in turn) does not depend on it"}
+                    f"kernel; {distinct_cells} distinct argmax cells in the last step.  A 128-query launch (640 blocks, 2.5 per CU) is over "
+                    "before it reaches a steady state: the same kernels stream 0.70 of the HBM peak at 1024 queries and 0.75 at 2048 "
+                    "(profiles/r05/refine_bandwidth_vs_batch.txt).  `traffic` (2 x FETCH_SIZE of the committed PMC pass) is below the "
+                    "algorithmic bytes: that pass runs few steps on few pixel batches, so part of what it streams is still in the "
+                    "256 MB Infinity Cache and never reaches the fabric counters"}
     pipe.refine_events = None
     enc.profile_reset()
 

@@ -144,6 +144,9 @@ int pg_tune_gemm_tail_shape(int min_k, int min_n);
  * before it moves to the next row panels.  0 = default (4: 8 x 4 super-tiles, 2 MB of weights resident per XCD), -1 = all N tiles
  * (each activation panel crosses the fabric once, the weight panels are re-streamed per XCD), 1..64 = explicit.  Timing only. */
 int pg_tune_gemm_raster(int gn);
+/* Exact mode's attention (also env PIGEON_EXACT_ATTN=f32): 0 = split-fp16 operands on v_mfma_f32_32x32x16_f16 (default, round 5),
+ * 1 = plain fp32 on v_mfma_f32_32x32x2_f32 (round 4's kernel; the A/B arm).  Both are fp32-grade (6e-7 / 8e-7 against fp64). */
+int pg_tune_exact_attention(int use_f32_mfma);
 int pg_vit_saturation_check(pg_vit* h, int on);
 int pg_vit_saturation_read(pg_vit* h, int64_t* count, int reset);
 /* Always-on range alarm of the fp16 operand path (no scan, no cost worth naming): the kernel that turns the residual GEMMs' row

@@ -446,12 +446,16 @@ __global__ __launch_bounds__(256, 3) void attention_x3_kernel(const float* __res
     }
 }
 
-// PIGEON_EXACT_ATTN=f32 selects the fp32-MFMA kernel (the A/B arm and the checker of the split one)
+// PIGEON_EXACT_ATTN=f32 / pg_tune_exact_attention(1) select the fp32-MFMA kernel (the A/B arm and the checker of the split one)
+static int g_exact_attn_f32 = -1;
+extern "C" int pg_tune_exact_attention(int use_f32_mfma) {
+    g_exact_attn_f32 = use_f32_mfma ? 1 : 0;
+    return PG_OK;
+}
 int pg_attention_f32_launch(const float* qkv, float* out, int n_images, hipStream_t s) {
     if (n_images <= 0) return PG_OK;
-    static int use_f32 = -1;
-    if (use_f32 < 0) { const char* e = getenv("PIGEON_EXACT_ATTN"); use_f32 = (e && e[0] == 'f') ? 1 : 0; }
-    if (use_f32) hipLaunchKernelGGL(attention_f32_kernel, dim3(n_images * VIT_HEADS * 5), dim3(256), 0, s, qkv, out, n_images);
+    if (g_exact_attn_f32 < 0) { const char* e = getenv("PIGEON_EXACT_ATTN"); g_exact_attn_f32 = (e && e[0] == 'f') ? 1 : 0; }
+    if (g_exact_attn_f32) hipLaunchKernelGGL(attention_f32_kernel, dim3(n_images * VIT_HEADS * 5), dim3(256), 0, s, qkv, out, n_images);
     else hipLaunchKernelGGL(attention_x3_kernel, dim3(n_images * VIT_HEADS * 5), dim3(256), 0, s, qkv, out, n_images);
     return pg_check_launch("attention_f32");
 }

@@ -112,23 +112,29 @@ def test_x3_layernorm_and_gelu(env):
     assert _rel(t[:, :4096] + t[:, 4096:8192], ref) < 1e-6
 
 
-def test_attention_f32_vs_fp64(env, capsys):
+@pytest.mark.parametrize("kernel", ["split_fp16", "fp32_mfma"])
+def test_attention_f32_vs_fp64(env, capsys, kernel):
+    """The exact mode's attention against fp64: round 5's kernel on split-fp16 operands (v_mfma_f32_32x32x16_f16, three partial
+    products per product) and round 4's on the fp32 MFMA (the A/B arm, pg_tune_exact_attention(1))."""
     ops = env["ops"]
     g = torch.Generator().manual_seed(7)
     n = 2
     qkv = torch.randn((n * 577, 3072), generator=g)
     qkv[:, :1024] *= 3.0                   # score spread ~ +-25: peaky rows next to flat ones
     qkv[:577, 1024:2048] *= 0.2
-    out = ops.attention_f32(qkv.to(DEV).contiguous(), n).cpu()
+    env["lib"].check(env["lib"].load().pg_tune_exact_attention(1 if kernel == "fp32_mfma" else 0), "pg_tune_exact_attention")
+    try:
+        out = ops.attention_f32(qkv.to(DEV).contiguous(), n).cpu()
+    finally:
+        env["lib"].load().pg_tune_exact_attention(0)
     q, k, v = [qkv[:, i * 1024:(i + 1) * 1024].double().reshape(n, 577, 16, 64).transpose(1, 2) for i in range(3)]
     p = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
     ref = (p @ v).transpose(1, 2).reshape(n * 577, 1024)
     e = _rel(out, ref)
     worst = float((out.double() - ref).abs().max() / ref.abs().max())
     with capsys.disabled():
-        print(f"\nattention_f32 vs fp64: rel {e:.2e}, worst element / max {worst:.2e}")
+        print(f"\nattention_f32 [{kernel}] vs fp64: rel {e:.2e}, worst element / max {worst:.2e}")
     assert e < 3e-6 and worst < 1e-5
-
 
 def test_head_margin_vs_torch(env):
     ops, syn = env["ops"], env["syn"]
