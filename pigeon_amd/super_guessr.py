@@ -55,8 +55,8 @@ class SuperGuessr(nn.Module):
           .last_reencoded (n,) int64  the samples the exact tier re-encoded (empty when it is off)
         With a ProtoRefiner, `pigeon_amd.evaluate.certain_forward` extends the same guarantee to the refined cell and point.
         Extra keywords: `exact_top1`, `margin_kappa` (z-score, default 3.6), `margin_rel_tol` (default 1e-3 = the contract's embedding
-        tolerance until `calibrate_certainty` -- called explicitly, or by the first forward that sees >= 8 samples with pixels --
-        replaces it by the measured error of THIS set of weights), `margin_rel_tol_exact` (2e-5).
+        tolerance until `calibrate_certainty` -- called explicitly, or by the first forward that sees >= 8 samples with pixels, or
+        once 16 samples have come in through smaller batches -- replaces it by the measured error of THIS set of weights), `margin_rel_tol_exact` (2e-5).
         """
         super(SuperGuessr, self).__init__()
         geocell_path = kwargs.pop('geocell_path', None)
@@ -99,6 +99,7 @@ class SuperGuessr(nn.Module):
         self.loss_fnc = nn.CrossEntropyLoss()
         self._hip_base = None
         self._wnorm = {}                                     # exact? -> (key, device tensor): see wstats()
+        self._cal_buffer = []                                # pixels of small first batches, until there are enough to calibrate on
         if self.exact_top1 and isinstance(self.base_model, HipCLIPVisionModel):
             self.base_model.enable_precise(True)             # pack the split-weight copy with the first build, not inside a request
         print(f'Initialized SuperGuessr classification model with {self.num_cells} geocells.')
@@ -247,9 +248,8 @@ class SuperGuessr(nn.Module):
             if pixel_values.dim() > 4:
                 pixel_values = pixel_values.squeeze(1)                          # :392-393
             px = pixel_values.to(dev)
-            if (self.exact_top1 and self.margin_autocalibrate and not self.certainty.calibrated
-                    and px.shape[0] >= 8 * self._panels()):
-                self._calibrate(px)
+            if self.exact_top1 and self.margin_autocalibrate and not self.certainty.calibrated:
+                self._autocalibrate(px)
             embedding = self._encoder().embed(px)                               # :395-398 (ViT + token mean)
             if self.panorama:
                 embedding = embedding.reshape((num_samples, 4, embedding.shape[-1]))   # :404-405 (explicit width: B = 0 stays legal)
@@ -332,6 +332,21 @@ class SuperGuessr(nn.Module):
                 # the one host synchronisation of the step: which samples are inside the error band is data dependent
                 self.reencode_rows(st, torch.nonzero(~st['certain']).flatten())
             return self.package(st, labels, labels_clf)
+
+    @torch.no_grad()
+    def _autocalibrate(self, px: Tensor) -> None:
+        """First use without an explicit `calibrate_certainty`: a batch of >= 8 samples calibrates right away; smaller batches (a
+        server answering one panorama at a time) are collected until 16 samples have been seen, then calibrate once.  Frozen after."""
+        P = self._panels()
+        if px.shape[0] == 0:
+            return
+        if px.shape[0] >= 8 * P and not self._cal_buffer:
+            self._calibrate(px)
+            return
+        self._cal_buffer.append(px.detach().clone())
+        if sum(t.shape[0] for t in self._cal_buffer) >= 16 * P:
+            buf, self._cal_buffer = torch.cat([t.to(px.dtype) for t in self._cal_buffer]), []
+            self._calibrate(buf)
 
     @torch.no_grad()
     def _calibrate(self, px: Tensor, max_samples: int = 32) -> dict:

@@ -273,6 +273,13 @@ def test_exact_mode_edges(env, tmp_path, capsys):
     assert mc.certainty.stats == st
     rms = mc.calibrate_certainty(px[:8])
     assert mc.certainty.stats["samples"] == 8 and abs(rms - mc.certainty.stats["fast_vs_exact_rms"]) < 1e-12
+    # a server's traffic: one sample per call -> collected, calibrated once 16 have been seen, nothing kept afterwards
+    ms = model(panorama=False, exact_top1=True)
+    for i in range(15):
+        ms(pixel_values=px[i % 12:i % 12 + 1], labels_clf=None)
+    assert not ms.certainty.calibrated and len(ms._cal_buffer) == 15
+    ms(pixel_values=px[3:4], labels_clf=None)
+    assert ms.certainty.calibrated and ms.certainty.stats["samples"] == 16 and ms._cal_buffer == []
     # bf16 operands on the fast path: the exact pass is unaffected
     vb = HipCLIPVisionModel(sd, layers=2).to(DEV)
     vb.enable_precise(True)
