@@ -142,7 +142,8 @@ int pg_tune_gemm_tail_rows(int rows);
 int pg_tune_gemm_tail_shape(int min_k, int min_n);
 /* Raster of the 384 x 256 persistent GEMM (QKV, fc1, fc2; also env PIGEON_GEMM_RASTER_GN): N tiles per group an XCD's round walks
  * before it moves to the next row panels.  0 = default (4: 8 x 4 super-tiles, 2 MB of weights resident per XCD), -1 = all N tiles
- * (each activation panel crosses the fabric once, the weight panels are re-streamed per XCD), 1..64 = explicit.  Timing only. */
+ * (each activation panel crosses the fabric once, the weight panels are re-streamed per XCD), 1..64 = explicit (honoured for a GEMM only when it divides that
+ * GEMM's count of 256-column tiles, or is at least that count; otherwise the default stays).  Timing only, never results. */
 int pg_tune_gemm_raster(int gn);
 /* Exact mode's attention (also env PIGEON_EXACT_ATTN=f32): 0 = split-fp16 operands on v_mfma_f32_32x32x16_f16 (default, round 5),
  * 1 = plain fp32 on v_mfma_f32_32x32x2_f32 (round 4's kernel; the A/B arm).  Both are fp32-grade (6e-7 / 8e-7 against fp64). */

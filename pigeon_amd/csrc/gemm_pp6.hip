@@ -672,10 +672,12 @@ int pg_gemm_pp6_launch(int dtype, GemmArgs g, int epi, hipStream_t s) {
     g.ntiles = g.tilesM * g.tilesN;
     g.gn = (g.tilesN % 4 == 0) ? 4 : g.tilesN;               // 8 x 4 super-tiles per XCD round (gemm_pp.hip variant 36)
     {   // pg_tune_gemm_raster: -1 = an XCD round walks ALL N tiles of 32 / tilesN row panels (the A panels cross the fabric once,
-        // the weight panels stream from L2 / the Infinity Cache); n > 0 = n N tiles per group.  Raster only: results do not move.
+        // the weight panels stream from L2 / the Infinity Cache); n > 0 = n N tiles per group -- honoured only when n divides
+        // tilesN (make_tile6's super-tile decode is a bijection only then; any other n keeps the default).  Raster only: results
+        // do not move (tests/test_gpu_parity.py::test_gemm_raster_knob_changes_nothing).
         const int rg = pg_gemm_raster_gn();
-        if (rg == -1) g.gn = g.tilesN;
-        else if (rg > 0) g.gn = rg < g.tilesN ? rg : g.tilesN;
+        if (rg == -1 || rg >= g.tilesN) g.gn = g.tilesN;
+        else if (rg > 0 && g.tilesN % rg == 0) g.gn = rg;
     }
     int cap = cus6();
     if (pg_gemm_block_cap() > 0 && pg_gemm_block_cap() < cap) cap = pg_gemm_block_cap();   // tuning: share the chip between streams

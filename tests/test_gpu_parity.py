@@ -198,6 +198,30 @@ def test_gemm_tail_split_changes_nothing(env):
         ops.tune_gemm_tail_shape(2048, 4096)
 
 
+def test_gemm_raster_knob_changes_nothing(env):
+    """pg_tune_gemm_raster (round 5): which N tiles an XCD round of the 384 x 256 kernel walks is a RASTER choice -- groups of 4 (default),
+    all of them (-1), 2, 6, and 8 (which does not divide fc1's 12 column tiles and is therefore ignored there) -- and must not change a bit
+    of any epilogue's output, many rounds and a ragged M tail included."""
+    ops, L = env["ops"], env["lib"]
+    A, W, bias, X0, cs, rs = _tail_problem(2 * 384 * 70 + 211, 3072, 1024, seed=5)      # 141 row panels x 12 column tiles: 6.6 rounds
+    ref = None
+    try:
+        for gn in (0, -1, 2, 6, 8):
+            ops.tune_gemm_raster(gn)
+            outs = [ops.gemm16_ln(A, W, bias, cs, rs, epi, qscale=0.25, qcols=1024, variant=56) for epi in (L.EPI_QKV_LN, L.EPI_GELU_LN)]
+            X = torch.cat([X0[:, :1024], torch.full((389, 1024), 7.0, device=DEV)]).contiguous()
+            x16, part = ops.gemm16_resid_stat(A, W[:1024].contiguous(), bias[:1024].contiguous(), X[:A.shape[0]], variant=56)
+            torch.cuda.synchronize()
+            outs += [X.clone(), x16, part]
+            if ref is None:
+                ref = outs
+            else:
+                for a, b in zip(ref, outs):
+                    assert torch.equal(a, b), gn
+    finally:
+        ops.tune_gemm_raster(0)
+
+
 def test_gemm_resid_stat_on_384_row_tiles_bit_identical(env):
     """Round 3: fc2 (K >= 2048) runs its fp32-residual + 16-bit-copy + row-statistics epilogue on the 384 x 256 kernel
     (gemm_pp6.hip epilogue6_resid).  Same MFMA chain, same epilogue arithmetic (gemm_epi.h), same split-halves geometry: the new
