@@ -259,7 +259,7 @@ int pg_refine_forward_ex(const pg_bank* bank, const float* q, int B, int P, cons
  * two discrete points and has no margin.   W (C,1024) = the head's weights (the candidates' log-probabilities move with the
  * embedding through them), wstats as above, refined / choice as pg_refine_forward_ex wrote them.
  *   tol DEVICE (B) fp32 out;  code DEVICE (B) int32 out: 1000 + j / 2000 + j / 2999 / 3000 + w / 4000 + w (see csrc/certainty.hip), -9 = the
- *   winning product underflows in fp32 (uncertain), 0 = nothing can change the row.   Limits: topk <= 64, n_eval <= min(k, 96). */
+ *   winning product underflows in fp32 (uncertain), -8 = refined / choice outside [0, topk) (tol 0), 0 = nothing can change the row.   Limits: topk <= 64, n_eval <= min(k, 96). */
 int pg_refine_certainty(const pg_bank* bank, const float* q, int B, int P, const int64_t* cand, const float* cand_prob, int k,
                         int topk, int n_eval, const float* scratch12, const float* W, int C, const float* beta,
                         const float* wstats, float temperature, const int32_t* refined, const int32_t* choice,

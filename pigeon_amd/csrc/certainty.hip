@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void head_certainty_kernel(const float* __rest
 // ---- refiner: are the refined cell and point certain?  (scratch12: the records pg_refine_forward_ex left) ------------------------
 // code: 1000 + j  winner against candidate j of the set;  2000 + j  candidate j outside the set could enter and win;  2999 the cells
 // beyond the evaluated ones could enter;  3000 / 3001 nearest prototype of the refined / the chosen candidate;  4000 / 4001 farthest
-// member likewise;  -9 the winning product underflows in fp32;  0 nothing can change it
+// member likewise;  -9 the winning product underflows in fp32;  -8 refined / choice out of range;  0 nothing can change it
 __global__ __launch_bounds__(256) void refine_certainty_kernel(pg_bank bank, const float* __restrict__ q, int P,
                                                                const int64_t* __restrict__ cand, const float* __restrict__ cand_prob,
                                                                int k, int topk, int n_eval, const float* __restrict__ scratch12,
@@ -182,6 +182,10 @@ __global__ __launch_bounds__(256) void refine_certainty_kernel(pg_bank bank, con
         S[tid] = l + rec0[12 * tid] * invT;
     }
     const int r = refined[b], ch = choice[b];
+    if (r < 0 || r >= topk || ch < 0 || ch >= topk) {        // not a record pg_refine_forward_ex wrote (block-uniform exit)
+        if (tid == 0) { tol[b] = 0.f; code[b] = -8; }
+        return;
+    }
     if (tid == 0) {
         // the product the reference's argmax looks at (proto_refiner.py:187-192), in its own fp32 arithmetic
         float sum = 0.f;
