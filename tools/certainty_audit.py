@@ -2,7 +2,8 @@
 sigma(logit) = 4, 1M-row bank, top-5 refinement), N batches of 128 fresh panoramas.  Ground truth = the same chain on the EXACT
 encoder's embeddings (pg_vit_forward_precise, ~2e-7 of the fp32 reference).  Reported: how many panoramas the fast mode flags, how
 many of its outputs differ from the truth, and whether any of those was flagged certain (must be none).
-   python tools/certainty_audit.py [n_batches]"""
+   python tools/certainty_audit.py [n_batches] [default|spread]      (spread: synthetic.make_vit_weights_spread(seed 31), the tower whose
+                                                                      embeddings spread like a trained one's and whose 16-bit error is 7e-4)"""
 import contextlib, io, os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,7 +18,10 @@ from pigeon_amd.super_guessr import SuperGuessr
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 dev = "cuda"
 C = 10000
-base = HipCLIPVisionModel(synthetic.make_vit_weights(seed=0, layers=24), layers=24)
+weights = sys.argv[2] if len(sys.argv) > 2 else "default"
+base = HipCLIPVisionModel(synthetic.make_vit_weights_spread(seed=31, layers=24) if weights == "spread"
+                          else synthetic.make_vit_weights(seed=0, layers=24), layers=24)
+print(f"tower: {weights}")
 geo = os.path.join(tempfile.mkdtemp(prefix="pigeon_audit_"), "g.csv")
 synthetic.write_geocell_csv(geo, synthetic.make_geocells(C, seed=0))
 with contextlib.redirect_stdout(io.StringIO()):
