@@ -76,8 +76,8 @@ def test_bench_world8_exact_mode_with_unequal_reencodes():
     sp = r["per_rank_split_ms"]
     assert sp["reencoded_panoramas_per_step"] == [float(i) for i in range(8)]
     assert len(sp["compute"]) == 8 and len(sp["gather_incl_wait"]) == 8 and len(r["per_rank_ms_per_step"]) == 8
-    assert sp["compute"][7] > sp["compute"][0] + 8.0, sp            # 7 x 2 ms of exact-tier work on rank 7, none on rank 0
-    assert sp["gather_incl_wait"][0] > sp["gather_incl_wait"][7] + 4.0, sp      # ... which rank 0 spends waiting at the collective
+    assert sp["compute"][7] > sp["compute"][0] + 6.0, sp            # 7 x 2 ms of exact-tier work on rank 7, none on rank 0 (slack: a loaded host)
+    assert sp["gather_incl_wait"][0] > sp["gather_incl_wait"][7] + 3.0, sp      # ... which rank 0 spends waiting at the collective
     # the fast mode of the same launch: nobody re-encodes, nobody waits for a straggler
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--fast", "--panoramas", "12",
                         "--cells", "50", "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=_env())
