@@ -204,13 +204,15 @@ def test_gemm_raster_knob_changes_nothing(env):
     of any epilogue's output, many rounds and a ragged M tail included."""
     ops, L = env["ops"], env["lib"]
     A, W, bias, X0, cs, rs = _tail_problem(2 * 384 * 70 + 211, 3072, 1024, seed=5)      # 141 row panels x 12 column tiles: 6.6 rounds
+    # the residual epilogue runs on the 384 x 256 kernel for K >= 2048 (fc2's shape class): K = 2048, 4 column tiles (gn = 2 regroups them)
+    A2, W2 = torch.cat([A, A], dim=1).contiguous(), torch.cat([W[:1024], W[1024:2048]], dim=1).contiguous()
     ref = None
     try:
         for gn in (0, -1, 2, 6, 8):
             ops.tune_gemm_raster(gn)
             outs = [ops.gemm16_ln(A, W, bias, cs, rs, epi, qscale=0.25, qcols=1024, variant=56) for epi in (L.EPI_QKV_LN, L.EPI_GELU_LN)]
             X = torch.cat([X0[:, :1024], torch.full((389, 1024), 7.0, device=DEV)]).contiguous()
-            x16, part = ops.gemm16_resid_stat(A, W[:1024].contiguous(), bias[:1024].contiguous(), X[:A.shape[0]], variant=56)
+            x16, part = ops.gemm16_resid_stat(A2, W2, bias[:1024].contiguous(), X[:A.shape[0]], variant=56)
             torch.cuda.synchronize()
             outs += [X.clone(), x16, part]
             if ref is None:
