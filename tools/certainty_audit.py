@@ -44,6 +44,7 @@ print(model.certainty.describe())
 enc = base._encoder(torch.device(dev))
 tot = dict(n=0, flagged=0, top1_bad=0, ref_bad=0, bad_certain=0, head=0, refine=0)
 worst_z = 0.0
+z_wrong, z_all = [], []
 for i in range(nb):
     px = torch.randn((128, 12, 336, 336), generator=g, device=dev)
     out, info = certain_forward(model, refiner, pixel_values=px)          # fast mode: nothing re-encoded, certainty reported
@@ -60,7 +61,19 @@ for i in range(nb):
     tot["n"] += 128; tot["flagged"] += int((~cert).sum()); tot["top1_bad"] += int(top1_bad.sum()); tot["ref_bad"] += int(ref_bad.sum())
     tot["bad_certain"] += int((bad & cert).sum())
     tot["head"] += int((info["cause"] == 1).sum()); tot["refine"] += int((info["cause"] > 1).sum() + (info["cause"] < 0).sum())
+    # how close the wrong ones came to being called certain: their tolerance in units of the calibrated residual error (a z-score;
+    # certain means > kappa)
+    z = torch.minimum(info["head_tol"], info["refine_tol"]) / model.certainty.rel_tol
+    z_wrong += z[bad].clamp_min(0).tolist()
+    z_all += z.clamp(0, 1e6).tolist()
 print(tot)
+zw, za = np.asarray(z_wrong), np.asarray(z_all)
+edges = [0, 0.5, 1, 1.5, 2, 2.5, 3, 3.6, 1e9]
+print("tolerance / rel_tol of the panoramas the fast mode gets WRONG (kappa = %.1f): max %.2f; histogram over %s: %s" %
+      (model.certainty.kappa, zw.max() if zw.size else float("nan"), edges[:-1], np.histogram(zw, bins=edges)[0].tolist()))
+print("the same of ALL panoramas: %s; so the share that is wrong per bin: %s" %
+      (np.histogram(za, bins=edges)[0].tolist(),
+       [round(float(a) / max(1, int(b)), 3) for a, b in zip(np.histogram(zw, bins=edges)[0], np.histogram(za, bins=edges)[0])]))
 print(f"{tot['n']} panoramas: {tot['flagged']} flagged uncertain ({100.0 * tot['flagged'] / tot['n']:.2f} %: {tot['head']} for the head's top-1, "
       f"{tot['refine']} for the refiner); fast-mode outputs differing from the exact chain: top-1 {tot['top1_bad']}, refined {tot['ref_bad']}; "
       f"of those, flagged CERTAIN: {tot['bad_certain']}")
