@@ -92,7 +92,10 @@ def parse(argv=None):
     ap.add_argument("--protos-per-cell", type=int, default=100)
     ap.add_argument("--topk", type=int, default=5)
     ap.add_argument("--layers", type=int, default=24)
-    ap.add_argument("--pixel-batches", type=int, default=4, help="distinct resident pixel batches used in turn")
+    ap.add_argument("--pixel-batches", type=int, default=16, help="distinct resident pixel batches used in turn (16 x 694 MB: the share of "
+                    "panoramas the exact tier re-encodes is then that of fresh data, ~2.2 %%, not that of 4 lucky batches)")
+    ap.add_argument("--min-flush", type=int, default=10, help="queued panoramas that trigger one exact pass (pigeon_amd.deferred)")
+    ap.add_argument("--max-lag", type=int, default=12, help="steps a queued panorama may wait for the exact pass")
     ap.add_argument("--cpu-images", type=int, default=64, help="images in the bounded CPU-baseline / CPU-oracle parity sample (0 = skip); 64 = 16 panoramas")
     ap.add_argument("--cpu-port-images", type=int, default=16, help="images through the oracle restatement (kind 'port') on the CPU (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="CPU-baseline worker processes x 16 threads (0 = hardware threads / 16)")
@@ -569,9 +572,10 @@ def ingest_leg(args, dev, pipe, index, resident_ms):
             main.wait_event(copied[b])
             px16 = prep(stage[b], out_dtype=torch.float16)         # (512,3,336,336) fp16
             consumed[b].record(main)
-            pipe.step(px16.view(args.panoramas, 12, 336, 336), index)
-            if pipe.last_info is not None:
-                n_re.append(pipe.last_info["reencoded"])
+            for r in pipe.submit(px16.view(args.panoramas, 12, 336, 336), index):
+                n_re.append(int(r["queued"][0]))
+        for r in pipe.flush():                                     # inside the timed region: every step's outputs are final
+            n_re.append(int(r["queued"][0]))
 
     n_re = []
     run(2)
@@ -585,7 +589,7 @@ def ingest_leg(args, dev, pipe, index, resident_ms):
     mb = n_img * RAW_HW * RAW_HW * 3 / 1e6
     res = {"value": n_img / t, "unit": "images/s", "ms_per_step": t * 1e3, "n_gpus": 1,
            "frac_of_resident": (resident_ms / 1e3) / t,
-           "reencoded_panoramas_per_step": [int(x.numel()) for x in n_re],
+           "reencoded_panoramas_per_step": n_re,
            "what": f"uint8 ({n_img},{RAW_HW},{RAW_HW},3) images in pinned host memory ({mb:.0f} MB per step) -> H2D on a side stream, "
                    "double-buffered with events -> pg_prep_forward (bit-exact CLIPProcessor resize / crop / normalise, fp16 out) -> "
                    "ViT + head + refine; whole chain inside the timed region.  NOTE: these are other images than the resident "
@@ -668,12 +672,14 @@ def _cause_counts(causes):
 
 
 def _dry_stubs(args):
-    """CPU stand-ins with the call surface PanoramaPipeline / certain_forward use (pigeon_amd.SuperGuessr / ProtoRefiner on this
-    path).  They exist so that the launch / shard / gather / restore-order / timing / JSON control flow -- INCLUDING the exact mode's
-    data-dependent part: rank r finds r panoramas uncertain per step and pays 2 ms per re-encoded panorama, so the ranks reach the
-    all-gather at different times -- can be exercised without a GPU (tests/test_bench_dry_run.py); nothing here is a fallback of the
+    """CPU stand-ins with the call surface pigeon_amd.deferred.DeferredExact uses (pigeon_amd.SuperGuessr / ProtoRefiner on this
+    path) plus the torch restatement of csrc/requeue.hip (oracle/requeue_oracle.py) as its `ops`.  They exist so that the launch / shard /
+    gather / restore-order / timing / JSON control flow -- INCLUDING the deferred exact tier's protocol: rank r finds r panoramas
+    uncertain per step, the queue lengths ride in the step's second gather, every rank flushes in the same step on the same number of
+    slots and pays 2 ms per slot -- can be exercised without a GPU (tests/test_bench_dry_run.py); nothing here is a fallback of the
     product: the real run never constructs them."""
     import torch
+    from oracle import requeue_oracle
     from pigeon_amd.certainty import Certainty
     from pigeon_amd.utils import ModelOutput, TopK
     g = torch.Generator().manual_seed(5)
@@ -689,29 +695,32 @@ def _dry_stubs(args):
         exact_top1 = not args.fast
         num_candidates = k
         certainty = Certainty()
-        last_margin = last_bound = last_certain = None
+        exact_log = []                                            # (slots, seconds) of every exact pass of this rank
 
         def wstats(self, exact=False):
             return torch.stack([W.norm(dim=1).max(), torch.zeros(())])
 
-        def encode_head(self, pixel_values=None, embedding=None):
-            B = pixel_values.shape[0]
-            emb = pixel_values.reshape(B, 4, 3, -1).float().mean(dim=-1) @ P                    # (B,4,1024)
+        def _head(self, emb):
             probs = torch.softmax(emb.mean(dim=1) @ W.t(), dim=-1)
             top = torch.topk(probs, k + min(4, max(0, args.cells - k)), dim=-1)           # k > cells raises, as the real head does
             cells = top.indices[:, 0].contiguous()
-            certain = torch.ones(B, dtype=torch.bool)
-            certain[:min(rank, B)] = False                                                      # rank r: r uncertain panoramas per step
-            return dict(embedding=emb, head_in=emb, pixel_values=pixel_values, topk_values=top.values, topk_indices=top.indices,
-                        preds_geocell=cells, preds_LLH=cen[cells], tol=certain.float(), certain=certain, exact=torch.zeros_like(certain),
-                        reencoded=torch.empty((0,), dtype=torch.int64), margin=certain.float(), sens=certain.float())
+            n = emb.shape[0]
+            return dict(embedding=emb, topk_values=top.values, topk_indices=top.indices, preds_geocell=cells, preds_LLH=cen[cells],
+                        tol=torch.ones(n), margin=torch.ones(n), sens=torch.ones(n))
 
-        def reencode_rows(self, st, idx):
-            if idx.numel():
-                time.sleep(2e-3 * idx.numel())                                                  # the exact tier's cost, per panorama
-                st["certain"][idx] = True
-                st["exact"][idx] = True
-                st["reencoded"] = idx
+        def encode_head(self, pixel_values=None, embedding=None):
+            B = pixel_values.shape[0]
+            st = self._head(pixel_values.reshape(B, 4, 3, -1).float().mean(dim=-1) @ P)         # (B,4,1024)
+            st["tol"][:min(rank, B)] = 0.0                                                      # rank r: r uncertain panoramas per step
+            st.update(pixel_values=pixel_values, exact_tier=False, thr=0.5, drift=None, wstats=self.wstats())
+            return st
+
+        def exact_rows(self, pixel_rows):
+            px = torch.cat(list(pixel_rows))
+            t0 = time.perf_counter()
+            time.sleep(2e-3 * px.shape[0])                                                      # the exact tier's cost, per SLOT run
+            self.exact_log.append((int(px.shape[0]), time.perf_counter() - t0))
+            return self._head(px.reshape(px.shape[0], 4, 3, -1).float().mean(dim=-1) @ P)
 
         def package(self, st, labels=None, labels_clf=None):
             return ModelOutput(None, None, 0, 0, 0, st["preds_LLH"], st["preds_geocell"], None, None, None,
@@ -728,7 +737,7 @@ def _dry_stubs(args):
         def __call__(self, emb, initial_preds=None, candidate_cells=None, candidate_probs=None, quiet=False):
             return None, (initial_preds + 0.25).float(), candidate_cells[:, min(1, k - 1)].contiguous()
 
-    return Model(), (None if args.no_refine else Refiner())
+    return Model(), (None if args.no_refine else Refiner()), requeue_oracle
 
 
 # ------------------------------------------------------------------------------------------------------ worker
@@ -762,10 +771,10 @@ def _worker(args, comm):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dry = args.dry_run
     nb = max(1, args.pixel_batches)
-    base = enc = refiner = bank_t = vit_sd = None
+    base = enc = refiner = bank_t = vit_sd = dry_ops = None
     if dry:
         dev = torch.device("cpu")
-        model, refiner = _dry_stubs(args)
+        model, refiner, dry_ops = _dry_stubs(args)
         g = torch.Generator().manual_seed(1234 + rank)
         pixel_batches = [torch.randn((args.panoramas, 12, 8, 8), generator=g) for _ in range(nb)]
     else:
@@ -815,7 +824,7 @@ def _worker(args, comm):
         except Exception as e:  # noqa
             rccl_error = repr(e)
             comm.force_rccl = False
-    pipe = PanoramaPipeline(model, refiner, comm)
+    pipe = PanoramaPipeline(model, refiner, comm, min_flush=args.min_flush, max_lag=args.max_lag, ops=dry_ops)
     # sample ids as a sharded DataLoader deals them (batch i -> rank i % world, preprocessing/embed.py:68): interleaved, so the
     # gathered results really need restore_order
     index = (torch.arange(args.panoramas, device=dev) * world + rank)
@@ -852,7 +861,8 @@ def _worker(args, comm):
         except Exception as e:  # noqa  (nothing depends on it but the size of the re-encoded set: the threshold stays at the contract's 1e-3)
             print(f"[bench] certainty calibration failed: {e!r}", file=sys.stderr)
     for i in range(max(args.warmup, 1)):
-        out = pipe.step(pixel_batches[i % nb], index)
+        pipe.submit(pixel_batches[i % nb], index)
+    pipe.flush()                                                   # the timed region starts with an empty queue
     sync()
     if not dry:
         enc = base._encoder(dev)
@@ -864,26 +874,39 @@ def _worker(args, comm):
         elif args.profile == "none":
             enc.graph(False)                                     # A/B arm: eager launches, no events
         g0 = enc.graph()
-        pipe.refine_events = None
     outs_by_batch = {}
     certain_by_batch = {}
     info_by_step = []
+    flushes_before = len(pipe.engine.flush_log)
+
+    def take(done):
+        # references only (device tensors); read after the timed region
+        for r in done:
+            outs_by_batch[r["meta"]] = r
+            certain_by_batch[r["meta"]] = (r["certain"][rank * args.panoramas:(rank + 1) * args.panoramas], None, None)
+            info_by_step.append(dict(certain=r["certain"][rank * args.panoramas:(rank + 1) * args.panoramas],
+                                     cause=r["cause"][rank * args.panoramas:(rank + 1) * args.panoramas],
+                                     queued=r["queued"], step=r["step"]))
 
     # five time stamps per step on the launch stream (host clock in --dry-run): compute vs gather(-wait), per rank
     pipe.split_marks = []
-    # ---- timed region: exactly K steps between barrier + synchronize on both sides ----
+    # ---- timed region: exactly K steps between barrier + synchronize on both sides.  A step is pigeon_amd.deferred's `submit`: no
+    # host synchronisation; the panoramas the 16-bit encoder cannot settle wait on the device for ONE exact pass per ~min_flush of
+    # them; `flush()` -- inside the timed region -- settles what is still queued after the last step, so that all K steps' outputs
+    # are final (and the reference's) when the clock stops. ----
     comm.barrier()
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = pipe.step(pixel_batches[i % nb], index)
-        outs_by_batch[i % nb] = out                               # references only; read after the timed region
-        info_by_step.append(pipe.last_info)                        # device tensors; read after the timed region
-        if not dry:
-            certain_by_batch[i % nb] = (pipe.last_info["certain"], model.last_margin, model.last_bound)
+        take(pipe.submit(pixel_batches[i % nb], index, meta=i % nb))
+    take(pipe.flush())
     sync()
     comm.barrier()
     dt = time.perf_counter() - t0
+    out = outs_by_batch[(args.steps - 1) % nb]
+    if len(info_by_step) != args.steps:
+        raise SystemExit(f"rank {rank}: {len(info_by_step)} of {args.steps} steps were handed out")
+    flush_log = pipe.engine.flush_log[flushes_before:]
     prof = {}
     ungraphed = None
     if not dry:
@@ -919,8 +942,18 @@ def _worker(args, comm):
     my_compute = float(np.mean([c for c, _ in sp])) if sp else 0.0
     my_gather = float(np.mean([g for _, g in sp])) if sp else 0.0
     rank_compute, rank_gather = comm.all_values(my_compute), comm.all_values(my_gather)
-    my_re = float(np.mean([int(inf["reencoded"].numel()) for inf in info_by_step if inf is not None])) if info_by_step else 0.0
+    my_re = float(np.mean([inf["queued"][rank] for inf in info_by_step])) if info_by_step else 0.0
     rank_reenc = comm.all_values(my_re)
+    # the exact passes of the timed region: every rank takes them in the same steps on the same number of slots
+    pass_ms = pipe.engine.exact_pass_ms(flush_log)
+    rank_exact = comm.all_values(float(np.sum(pass_ms)) / max(args.steps, 1))
+    flush_sched = [dict(at_step=f["at_step"], queued_per_rank=f["queued"], slots_run=f["slots_run"],
+                        ms=(round(pass_ms[j], 3) if j < len(pass_ms) else None)) for j, f in enumerate(flush_log)]
+    all_sched = [None] * world
+    if world > 1:
+        torch.distributed.all_gather_object(all_sched, [(f["at_step"], f["slots_run"]) for f in flush_log])
+    else:
+        all_sched = [[(f["at_step"], f["slots_run"]) for f in flush_log]]
     dt = comm.max_over_ranks(dt)
 
     # ---- what every rank (rank 0 in particular) holds after the last step: the whole batch, restorable to sample order ----
@@ -969,10 +1002,14 @@ def _worker(args, comm):
         "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": step_ms, "per_rank_ms_per_step": [round(x, 3) for x in rank_ms],
         "per_rank_split_ms": {"compute": [round(x, 3) for x in rank_compute], "gather_incl_wait": [round(x, 3) for x in rank_gather],
-                              "reencoded_panoramas_per_step": [round(x, 2) for x in rank_reenc],
+                              "exact_passes_per_step": [round(x, 3) for x in rank_exact],
+                              "queued_panoramas_per_step": [round(x, 2) for x in rank_reenc],
                               "what": "stream time stamps around the two grouped all-gathers of every timed step: compute = encoder + head + "
-                                      "certainty + exact re-encode + refinement; gather = both collectives including the wait for the "
-                                      "slowest rank"},
+                                      "certainty + refinement + queueing of the uncertain rows; gather = both collectives including the wait "
+                                      "for the slowest rank; exact_passes = the exact tier's passes (one per ~min_flush queued panoramas, "
+                                      "same steps and same slot count on every rank), averaged over the steps"},
+        "exact_pass_schedule": {"this_rank": flush_sched, "same_on_every_rank": bool(all(sc == all_sched[0] for sc in all_sched)),
+                                "min_flush": args.min_flush, "max_lag": args.max_lag},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32-stub" if dry else enc.mma_dtype, "data": "synthetic",
         "config": {"workload": "BASELINE configs[3]: SuperGuessr 4-panorama ViT-L/14-336 + 10k-geocell head + ProtoRefiner "
@@ -1134,15 +1171,17 @@ def _worker(args, comm):
     other_outs = {}
     cpu_sample_emb, cpu_per = None, 0
     headline_exact = bool(model.exact_top1)
-    n_re = [int(inf["reencoded"].numel()) for inf in info_by_step if inf is not None]
-    cert_all = [inf["certain"] for inf in info_by_step if inf is not None]
+    n_re = [int(inf["queued"][0]) for inf in info_by_step]
+    cert_all = [inf["certain"] for inf in info_by_step]
     result["certainty"] = {
         "mode": "exact_top1 (product default)" if headline_exact else "fast (--fast): certainty reported, nothing re-encoded",
         "rule": model.certainty.describe(), "calibration": model.certainty.stats,
         "reencoded_panoramas_per_step": n_re, "panoramas_per_step": args.panoramas,
+        "reencoded_share": float(np.sum(n_re)) / max(1, args.panoramas * len(n_re)),
         "uncertain_after_step": [int((~c).sum()) for c in cert_all],
-        "uncertain_by_cause": _cause_counts([inf["cause"] for inf in info_by_step if inf is not None]),
-        "boundary_checked": bool(info_by_step and info_by_step[-1] is not None and info_by_step[-1].get("boundary_checked"))}
+        "uncertain_by_cause": _cause_counts([inf["cause"] for inf in info_by_step]),
+        "boundary_checked": bool(pipe.engine.boundary_checked),
+        "rows_that_did_not_fit_the_queue": pipe.engine.check_nothing_dropped()}
     if world == 1 and args.fast_steps > 0:
         try:
             model.exact_top1 = not headline_exact
@@ -1152,19 +1191,26 @@ def _worker(args, comm):
             pipe.step(pixel_batches[0], index)                    # warm-up of the other mode (workspaces, weight copies)
             torch.cuda.synchronize()
             n_re_o = []
+
+            def take_o(done):
+                for r in done:
+                    other_outs[r["meta"]] = r
+                    n_re_o.append(int(r["queued"][0]))
             te = time.perf_counter()
             for i in range(args.fast_steps):
-                other_outs[i % nb] = pipe.step(pixel_batches[i % nb], index)
-                n_re_o.append(pipe.last_info["reencoded"])
+                take_o(pipe.submit(pixel_batches[i % nb], index, meta=i % nb))
+            take_o(pipe.flush())
             torch.cuda.synchronize()
             te = (time.perf_counter() - te) / args.fast_steps
+            n_timed = len(n_re_o)
             for i in range(nb):                                    # the parity legs below want every resident batch (untimed)
                 if i not in other_outs:
-                    other_outs[i] = pipe.step(pixel_batches[i], index)
+                    take_o(pipe.submit(pixel_batches[i], index, meta=i))
+            take_o(pipe.flush())
             torch.cuda.synchronize()
             leg = {"value": args.panoramas * 4 / te, "unit": "images/s", "ms_per_step": te * 1e3, "steps": args.fast_steps,
                    "mfma_frac_end_to_end": args.panoramas * 4 / te * FLOP_PER_IMAGE / PEAK_MFMA,
-                   "reencoded_panoramas_per_step": [int(x.numel()) for x in n_re_o]}
+                   "reencoded_panoramas_per_step": n_re_o[:n_timed]}
             if headline_exact:
                 leg["what"] = ("SuperGuessr(exact_top1=False) / PIGEON_EXACT_TOP1=0: the 16-bit path alone -- embeddings within 1e-3, discrete "
                                "outputs NOT guaranteed (see the parity legs' `fast_mode` entries); timed after the timed region")

@@ -37,8 +37,9 @@ extern "C" {
 #define PG_DTYPE_F16     2
 #define PG_DTYPE_F64     3
 
-#define PG_ABI_VERSION   3   /* 2: pg_vit_cfg.precise, pg_vit_forward_precise, pg_head_margin (round 4); 3: pg_head_certainty, pg_refine_forward_ex,
-                              * pg_refine_certainty, pg_tune_gemm_raster (round 5) */
+#define PG_ABI_VERSION   4   /* 2: pg_vit_cfg.precise, pg_vit_forward_precise, pg_head_margin (round 4); 3: pg_head_certainty, pg_refine_forward_ex,
+                              * pg_refine_certainty, pg_tune_gemm_raster (round 5); 4: the deferred exact tier -- pg_requeue_append,
+                              * pg_rows_to_slots, pg_requeue_take, pg_scatter_rows, pg_head_wstats (round 6) */
 
 const char* pg_last_error(void);
 int pg_abi_version(void);
@@ -258,12 +259,50 @@ int pg_refine_forward_ex(const pg_bank* bank, const float* q, int B, int P, cons
  * for the refined and the finally chosen candidate the nearest-prototype and farthest-member picks.  The haversine veto compares
  * two discrete points and has no margin.   W (C,1024) = the head's weights (the candidates' log-probabilities move with the
  * embedding through them), wstats as above, refined / choice as pg_refine_forward_ex wrote them.
- *   tol DEVICE (B) fp32 out;  code DEVICE (B) int32 out: 1000 + j / 2000 + j / 2999 / 3000 + w / 4000 + w (see csrc/certainty.hip), -9 = the
- *   winning product underflows in fp32 (uncertain), -8 = refined / choice outside [0, topk) (tol 0), 0 = nothing can change the row.   Limits: topk <= 64, n_eval <= min(k, 96). */
+ *   tol DEVICE (B) fp32 out;  code DEVICE (B) int32 out: 1000 + j / 2000 + j / 2999 / 3000 + w / 4000 + w (see csrc/certainty.hip; w = 2, 3: the
+ *   prototypes / members the record does not name, bounded with |grad| <= 2 -- round 6), -9 = the winning product underflows in fp32, or
+ *   an empty cell wins a set that is not all empty (uncertain), -8 = refined / choice outside [0, topk) (tol 0), 0 = nothing can change
+ *   the row.   Limits: topk <= 64, n_eval <= min(k, 96). */
 int pg_refine_certainty(const pg_bank* bank, const float* q, int B, int P, const int64_t* cand, const float* cand_prob, int k,
                         int topk, int n_eval, const float* scratch12, const float* W, int C, const float* beta,
                         const float* wstats, float temperature, const int32_t* refined, const int32_t* choice,
                         float* tol, int32_t* code, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The deferred exact tier (round 6; csrc/requeue.hip).  The reference's discrete outputs are fp32 end to end
+ * (models/super_guessr.py:447-459, models/proto_refiner.py:176-222); a sample that pg_head_certainty / pg_refine_certainty cannot call
+ * certain is re-encoded by pg_vit_forward_precise.  These entry points keep that decision ON THE DEVICE: no `nonzero`, no host
+ * synchronisation per step.  The caller owns a circular queue of `cap` slots -- the pixels of the queued rows (cap x row_bytes) and, per
+ * slot, the row of its result ring the sample belongs to -- and a result ring that the exact tier's outputs are scattered into before
+ * the host collects anything (the reference concatenates at the end of its loop: training/train_eval_loop.py:98-112).
+ *
+ * pg_requeue_append: per row r < B
+ *     certain[r] = head_tol[r] > thr && (refine_tol == NULL || refine_tol[r] > thr) && !force_all     (a NaN tolerance is not certain)
+ *     cause[r]   = 0 certain | 1 the head's top-1 | else refine_code[r] (pg_refine_certainty's decision code; 2 when that is 0 / NULL)
+ *   and, for the rows that are not certain and while the queue has room (appended - flushed < cap), in row order:
+ *     slot = appended % cap;  slot_dst[slot] = dst_base + r;  row_slot[r] = slot;  ++appended
+ *   row_slot[r] = -1 for certain rows, -2 for rows that did not fit (counted in counters[1]; the host sizes the queue so that this
+ *   cannot happen and checks the counter).  counters DEVICE int64[2] = { rows ever appended, rows that did not fit }; `flushed` = rows
+ *   the host has already taken out (it knows: it enqueued those flushes).  cap = 0: flags and causes only (counters, slot_dst,
+ *   row_slot may be NULL) -- how the exact tier's own results are judged.   certain DEVICE uint8[B], cause DEVICE int32[B], may be NULL.
+ * pg_rows_to_slots:  dst + row_slot[r] * row_bytes <- src + r * row_bytes for every r < B with row_slot[r] >= 0 (the queued pixels).
+ * pg_requeue_take:   dst_out[i] = i < n_valid ? slot_dst[(head + i) % cap] : -1,  i < n_pad   (ring rows of the slots being flushed;
+ *                    the padding rows exist so that every rank of a data-parallel job runs the exact tier on the same batch size).
+ * pg_scatter_rows:   dst + d * row_bytes <- src + i * row_bytes, d = dst_row[i] >= 0, i < n.  remap_wb > 0: dst_row addresses the
+ *                    GATHERED ring (slabs of remap_wb rows, this rank's rows at [remap_off, remap_off + remap_b) of a slab) while dst is
+ *                    a local-only array with slabs of remap_b rows: d = (dst_row / remap_wb) * remap_b + dst_row % remap_wb - remap_off,
+ *                    rows of other ranks are skipped.  Rows with d >= dst_rows are skipped.
+ * pg_head_wstats:    out2 DEVICE float[2] = { max_c |W[c]|_2, max_c |W[c] . beta| } (beta DEVICE (1024), may be NULL -> 0): the bounds
+ *                    pg_head_certainty / pg_refine_certainty take for the cells they do not visit one by one.
+ * All asynchronous on `stream`. */
+int pg_requeue_append(const float* head_tol, const float* refine_tol, const int32_t* refine_code, int B, float thr, int force_all,
+                      int64_t dst_base, int64_t flushed, int64_t cap, int64_t* counters, int64_t* slot_dst, int32_t* row_slot,
+                      uint8_t* certain, int32_t* cause, void* stream);
+int pg_rows_to_slots(const void* src, int64_t row_bytes, const int32_t* row_slot, int B, void* dst, void* stream);
+int pg_requeue_take(const int64_t* slot_dst, int64_t cap, int64_t head, int n_valid, int n_pad, int64_t* dst_out, void* stream);
+int pg_scatter_rows(const void* src, int64_t row_bytes, const int64_t* dst_row, int n, void* dst, int64_t dst_rows,
+                    int64_t remap_wb, int64_t remap_b, int64_t remap_off, void* stream);
+int pg_head_wstats(const float* W, int C, const float* beta, float* out2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * CLIP image preprocessing (the step in front of the encoder): uint8 RGB -> pixel_values.

@@ -82,6 +82,11 @@ SIGNATURES = {
     "pg_refine_forward": (_I, [C.POINTER(Bank), _P, _I, _I, _P, _P, _P, _I, _I, _F, _D, _P, _P, _P, _P, _P]),
     "pg_refine_forward_ex": (_I, [C.POINTER(Bank), _P, _I, _I, _P, _P, _P, _I, _I, _I, _F, _D, _P, _P, _P, _P, _P, _P]),
     "pg_refine_certainty": (_I, [C.POINTER(Bank), _P, _I, _I, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _F, _P, _P, _P, _P, _P]),
+    "pg_requeue_append": (_I, [_P, _P, _P, _I, _F, _I, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P]),
+    "pg_rows_to_slots": (_I, [_P, _I64, _P, _I, _P, _P]),
+    "pg_requeue_take": (_I, [_P, _I64, _I64, _I, _I, _P, _P]),
+    "pg_scatter_rows": (_I, [_P, _I64, _P, _I, _P, _I64, _I64, _I64, _I64, _P]),
+    "pg_head_wstats": (_I, [_P, _I, _P, _P, _P]),
     "pg_op_gemm16": (_I, [_I, _P, _I64, _P, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _P, _I, _P]),
     "pg_op_gemm16_ld": (_I, [_I, _P, _I64, _P, _I64, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _P, _I, _P]),
     "pg_op_rowstat_cast": (_I, [_P, _P, _I, _P, _I64, _F, _P]),

@@ -15,6 +15,14 @@ the exact encoder.  A decision with margin m and gradient g then survives when
 
 (left side: what pg_head_certainty / pg_refine_certainty return per sample, the minimum over the sample's decisions; kappa: a z-score).
 The exact tier's own floor is `rel_tol_exact` (the reference's CPU result itself moves by ~1e-6 with the thread partition).
+
+What this buys is a STATISTICAL statement, not a bound: with kappa = 3.6 on 1.1 x the measured residual (z ~ 4) a sample called
+certain has its discrete outputs equal to the fp32 reference's with probability 1 - O(1e-5) per decision under the Gaussian error
+model -- which the audits support (profiles/r05/certainty_audit_*.txt, profiles/r06/: no wrong output among tens of thousands of
+samples called certain; the measured tail of the margin changes is no heavier than a unit Gaussian's) and which nothing proves.
+Which samples are re-encoded depends on the calibration samples (the first batch unless `calibrate_certainty` is called with a fixed
+set), so the returned embeddings of borderline samples can differ at the 3e-4 level between runs that calibrate on different data;
+their discrete outputs do not.
 """
 from __future__ import annotations
 
@@ -59,6 +67,7 @@ class Certainty:
         relative" per image; a tower on which the 16-bit path itself measures outside it (whole-sample error above 0.85 x, or the
         worst calibration image above 0.95 x the contract -- seen only on a synthetic extreme: every attention head at high q.k
         gain, tests/test_gpu_precise.py) sets `force_exact`: every sample is then encoded by the exact encoder."""
+        self.force_exact = False                      # a verdict of THIS calibration only (an earlier one's must not linger)
         rel = (fast.float() - exact.float()) / exact.float().norm(dim=1, keepdim=True).clamp_min(1e-30)
         n = int(rel.shape[0])
         if n == 0:

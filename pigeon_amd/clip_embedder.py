@@ -90,11 +90,12 @@ class HipCLIPVisionModel(torch.nn.Module):
             self._precise = bool(on)
             self._weights_changed()
 
-    def embed_precise(self, pixel_values: Tensor) -> Tensor:
-        """The exact mode of `embed`: near-fp32 arithmetic (pg_vit_forward_precise), ~5x the time per image."""
+    def embed_precise(self, pixel_values: Tensor, out: Optional[Tensor] = None) -> Tensor:
+        """The exact mode of `embed`: near-fp32 arithmetic (pg_vit_forward_precise), ~3x the time per image at 40+ images, more below.
+        `out` (N,1024) fp32: write there instead of a fresh tensor."""
         self.enable_precise(True)
         pixel_values = _to_device_pixels(pixel_values, self._dummy.device)
-        return self._encoder(pixel_values.device).forward_precise(pixel_values)
+        return self._encoder(pixel_values.device).forward_precise(pixel_values, out=out)
 
     def embed(self, pixel_values: Tensor) -> Tensor:
         pixel_values = _to_device_pixels(pixel_values, self._dummy.device)
@@ -231,7 +232,7 @@ def gpu_preprocess(images, device="cuda", out_dtype: torch.dtype = torch.float32
 class CLIPEmbedding(torch.nn.Module):
     def __init__(self, model_name: str, device: str = 'cuda', load_checkpoint: bool = False,
                  panorama: bool = False, state_dict: Optional[Dict[str, Tensor]] = None,
-                 clip_model: Optional[HipCLIPVisionModel] = None):
+                 clip_model: Optional[HipCLIPVisionModel] = None, contract_guard: Optional[str] = None):
         """CLIP embedding model (not trainable) -- reference models/clip_embedder.py:11-40.
 
         Args follow the reference.  The reference pulls the base weights from the HuggingFace hub
@@ -240,6 +241,14 @@ class CLIPEmbedding(torch.nn.Module):
         keyword arguments can supply the weights instead: `state_dict` (transformers CLIPVisionModel names) or a ready
         `clip_model`.  With `load_checkpoint=True`, `model_name` is a torch checkpoint copied over the weights by
         name with the leading `base_model.` component stripped, exactly as :30-32 does.
+
+        `contract_guard` (round 6; default env PIGEON_EMBED_GUARD, else 'exact'): what to do when THIS set of weights puts the 16-bit
+        encoder outside the embedding contract (1e-3 relative per image against the fp32 reference).  The first forward sends up to 32
+        of its images through the fast and the exact encoder (pg_vit_forward / pg_vit_forward_precise), prints the measured per-image
+        error and -- above 0.85e-3 overall or 0.95e-3 on the worst image, the rule `SuperGuessr` applies -- 'exact': encodes everything
+        in the exact mode from then on (~3x the time per image), 'raise': raises, 'off': no check.  The embeddings `run.py embed`
+        writes are what prototype banks are built from: a tower with large attention logits must not write them out of tolerance
+        silently.
         """
         super().__init__()
         self.device = device
@@ -263,6 +272,11 @@ class CLIPEmbedding(torch.nn.Module):
                         "point PIGEON_CLIP_MODEL at a directory written by save_pretrained (or have the hub id in the local HF cache), "
                         "pass state_dict=... / clip_model=..., or a checkpoint path with load_checkpoint=True.  " + str(why)) from why
         self.panorama = panorama
+        self.contract_guard = (contract_guard or os.environ.get('PIGEON_EMBED_GUARD', 'exact')).lower()
+        if self.contract_guard not in ('exact', 'raise', 'off'):
+            raise ValueError(f"contract_guard must be 'exact', 'raise' or 'off', got {self.contract_guard!r}")
+        self.guard_stats = None                  # what the first forward measured (None until then / with the guard off)
+        self.force_exact = False
 
         if load_checkpoint:
             sd = torch.load(model_name, map_location='cpu')
@@ -289,8 +303,32 @@ class CLIPEmbedding(torch.nn.Module):
                 pixel_values = pixel_values.to(self.device)
             else:
                 pixel_values = pixel_values.cuda(self.device)
+            base = self.clip_model.base_model
+            if self.contract_guard != 'off' and self.guard_stats is None and pixel_values.shape[0] > 0:
+                self._check_contract(base, pixel_values)
             # last_hidden_state.mean(dim=1), fused in the library (token_mean kernel)
-            return self.clip_model.base_model.embed(pixel_values)
+            return base.embed_precise(pixel_values) if self.force_exact else base.embed(pixel_values)
+
+    def _check_contract(self, base, pixel_values: Tensor, max_images: int = 32, contract: float = 1e-3) -> dict:
+        """Once per set of weights: the 16-bit encoder against the exact one on up to `max_images` images of the first batch."""
+        px = _to_device_pixels(pixel_values[:max_images], base._dummy.device)
+        fast, exact = base.embed(px), base.embed_precise(px)
+        err = (fast - exact).norm(dim=1) / exact.norm(dim=1).clamp_min(1e-30)
+        st = {'images': int(px.shape[0]), 'image_rel_err': float((fast - exact).norm() / exact.norm().clamp_min(1e-30)),
+              'worst_image_rel_err': float(err.max()), 'contract': contract}
+        st['outside'] = st['image_rel_err'] > 0.85 * contract or st['worst_image_rel_err'] > 0.95 * contract
+        self.guard_stats = st
+        print(f"pigeon_amd.CLIPEmbedding: 16-bit encoder vs exact encoder on {st['images']} images of the first batch: "
+              f"{st['image_rel_err']:.2e} relative overall, worst image {st['worst_image_rel_err']:.2e} (contract {contract:g})")
+        if st['outside']:
+            if self.contract_guard == 'raise':
+                raise RuntimeError('CLIPEmbedding: the 16-bit encoder is outside the 1e-3 embedding contract on these weights '
+                                   f"({st['image_rel_err']:.2e} overall, worst image {st['worst_image_rel_err']:.2e}); construct with "
+                                   "contract_guard='exact' to encode in the exact mode")
+            self.force_exact = True
+            print('pigeon_amd.CLIPEmbedding: outside the embedding contract on these weights -- every image will be encoded in the '
+                  'exact mode (about 3x the time per image).')
+        return st
 
     def _pixel_dtype(self) -> torch.dtype:
         mma = os.environ.get("PIGEON_MMA_DTYPE", "f16").lower()

@@ -118,8 +118,10 @@ __global__ __launch_bounds__(256) void head_certainty_kernel(const float* __rest
     const float* row = logits + (int64_t)b * C;
     const int64_t c0 = idx[0];
     MinTol best; best.t = INFINITY; best.code = 0;
-    if (c0 < 0 || c0 >= C) { best.t = 0.f; best.code = -2; }
-    else {
+    if (c0 < 0 || c0 >= C) {
+        best.t = 0.f; best.code = -2;
+        if (tid == 0) { if (margin) margin[b] = NAN; if (sens) sens[b] = 0.f; }     // never leave the report fields unwritten
+    } else {
         const float l0 = row[c0];
         for (int j = 1 + wave; j < kx; j += 4) {
             const int64_t cj = idx[j];
@@ -158,8 +160,10 @@ __global__ __launch_bounds__(256) void head_certainty_kernel(const float* __rest
 
 // ---- refiner: are the refined cell and point certain?  (scratch12: the records pg_refine_forward_ex left) ------------------------
 // code: 1000 + j  winner against candidate j of the set;  2000 + j  candidate j outside the set could enter and win;  2999 the cells
-// beyond the evaluated ones could enter;  3000 / 3001 nearest prototype of the refined / the chosen candidate;  4000 / 4001 farthest
-// member likewise;  -9 the winning product underflows in fp32;  -8 refined / choice out of range;  0 nothing can change it
+// beyond the evaluated ones could enter;  3000 / 3001 nearest prototype of the refined / the chosen candidate against the runner-up,
+// 3002 / 3003 against the prototypes the record does not name (bounded: |grad| <= 2);  4000 .. 4003 farthest member likewise;
+// -9 the winning product underflows in fp32 (or an empty cell wins a set that is not all empty);  -8 refined / choice out of range;
+// 0 nothing can change it
 __global__ __launch_bounds__(256) void refine_certainty_kernel(pg_bank bank, const float* __restrict__ q, int P,
                                                                const int64_t* __restrict__ cand, const float* __restrict__ cand_prob,
                                                                int k, int topk, int n_eval, const float* __restrict__ scratch12,
@@ -193,7 +197,11 @@ __global__ __launch_bounds__(256) void refine_certainty_kernel(pg_bank bank, con
         const float pr = cand_prob ? cand_prob[(int64_t)b * k + r] : (r == 0 ? 1.0f : 0.0f);
         const float fin = pr * (expf(rec0[12 * r] * invT) / sum);
         const bool empty_winner = __float_as_int(rec0[12 * r + 5]) < 0;
-        flag_under = (!(fin >= 1e-30f) && !empty_winner) ? 1 : (empty_winner ? 2 : 0);
+        // An empty cell (score -100000) wins only when every product of the set is 0 or NaN -- the underflow situation -- unless the
+        // whole set is empty cells, in which case no embedding error can change anything.
+        bool all_empty = true;
+        for (int j = 0; j < topk; ++j) all_empty = all_empty && __float_as_int(rec0[12 * j + 5]) < 0;
+        flag_under = (empty_winner && all_empty) ? 2 : ((!(fin >= 1e-30f) || empty_winner) ? 1 : 0);
     }
     __syncthreads();
     f32x4 ev[4], bv[4];
@@ -232,6 +240,7 @@ __global__ __launch_bounds__(256) void refine_certainty_kernel(pg_bank bank, con
 
     MinTol best; best.t = INFINITY; best.code = 0;
     int task = 0;
+    const float bn = beta ? sqrtf(dot16(bv, bv)) : 0.f;
     if (flag_under == 1) { best.t = 0.f; best.code = -9; }
     else if (flag_under == 0) {
         for (int j = 0; j < topk; ++j) {                     // the winner against the rest of the set
@@ -262,11 +271,21 @@ __global__ __launch_bounds__(256) void refine_certainty_kernel(pg_bank bank, con
             if (which == 1 && ch == r) break;
             const float* rx = rec0 + 12 * x;
             const int p1 = __float_as_int(rx[5]), p2 = __float_as_int(rx[6]);
-            if (p1 >= 0 && p2 >= 0 && (task++ & 3) == wave)
+            if (p1 >= 0 && p2 >= 0 && (task++ & 3) == wave) {
                 best.take(pair_d(bank.proto_emb, p1, p2, rx[4] - (-rx[0]), -rx[0], rx[4], 1.f), 3000 + which);
+                // The prototypes the record does not name are at least as far as the runner-up, but their direction is unknown: the
+                // gradient u_j - u_1 of two unit vectors has norm <= 2 (and (u_j - u_1).beta <= 2 |beta|), which can be a much
+                // smaller tolerance than the runner-up's when the runner-up lies almost in the winner's direction.
+                const int64_t cx = cd[x];
+                if (cx >= 0 && cx < bank.num_cells && bank.cell_off[cx + 1] - bank.cell_off[cx] > 2)
+                    best.take(tol_of(rx[4] - (-rx[0]), 4.f, 2.f * bn, en), 3002 + which);
+            }
             const int t1 = __float_as_int(rx[9]), t2 = __float_as_int(rx[10]);
-            if (t1 >= 0 && t2 >= 0 && (task++ & 3) == wave)
+            if (t1 >= 0 && t2 >= 0 && (task++ & 3) == wave) {
                 best.take(pair_d(bank.train_emb, t1, t2, rx[7] - rx[8], rx[7], rx[8], -1.f), 4000 + which);
+                if (__float_as_int(rx[11]) > 2)                  // members beyond the two farthest: the same bound
+                    best.take(tol_of(rx[7] - rx[8], 4.f, 2.f * bn, en), 4002 + which);
+            }
         }
     }
     const MinTol res = block_min(best, red_t, red_c);

@@ -103,17 +103,31 @@ class Communicator:
         """accelerate.Accelerator.gather: (n, ...) on every rank -> (world*n, ...) rank-major, on every rank."""
         return self.gather_many([t])[0]
 
-    def gather_many(self, tensors: List[torch.Tensor]) -> List[torch.Tensor]:
+    def gather_many(self, tensors: List[torch.Tensor], out: Optional[List[torch.Tensor]] = None) -> List[torch.Tensor]:
         """Gather several tensors (same leading dimension on every rank) in ONE grouped collective; every result is
-        rank-major and contiguous -- no packing, no unpacking copies."""
+        rank-major and contiguous -- no packing, no unpacking copies.  `out`: contiguous (world * n, ...) destinations (e.g. slabs of a
+        result ring) written in place of fresh tensors; with one rank and no forced RCCL they receive plain copies."""
+        if out is not None:
+            if len(out) != len(tensors):
+                raise ValueError("gather_many: `out` must hold one destination per tensor")
+            for t, o in zip(tensors, out):
+                if (o.shape[0] != self.world_size * t.shape[0] or tuple(o.shape[1:]) != tuple(t.shape[1:]) or o.dtype != t.dtype
+                        or o.device != t.device or not o.is_contiguous()):
+                    raise ValueError(f"gather_many: destination {tuple(o.shape)} {o.dtype} on {o.device} does not fit {self.world_size} x "
+                                     f"{tuple(t.shape)} {t.dtype} on {t.device} (contiguous)")
         if self.world_size == 1 and not (self.force_rccl and len(tensors) and all(t.is_cuda for t in tensors)):
-            return list(tensors)
+            if out is None:
+                return list(tensors)
+            for t, o in zip(tensors, out):
+                o.copy_(t)
+            return list(out)
         devs = {t.device for t in tensors}
         if len(devs) != 1:
             # a host tensor (or one on another GPU) among device tensors would hand RCCL a pointer it cannot read
             raise ValueError(f"gather_many: all tensors must live on ONE device, got {sorted(str(d) for d in devs)}")
         srcs = [t.contiguous() for t in tensors]
-        outs = [torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in srcs]
+        outs = list(out) if out is not None else [
+            torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in srcs]
         if srcs[0].is_cuda:
             import ctypes as C
             from . import _lib
@@ -126,6 +140,8 @@ class Communicator:
             _lib.check(_lib.load().pg_allgather_many(comm, n, send, recv, nbytes, stream), "pg_allgather_many")
         else:
             for t, o in zip(srcs, outs):                                      # gloo (CPU tests): list form
+                if t.shape[0] == 0:
+                    continue
                 dist.all_gather(list(o.chunk(self.world_size, dim=0)), t, group=self.group)
         return outs
 

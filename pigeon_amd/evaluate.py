@@ -64,45 +64,24 @@ def compute_geoguessr_metrics(results) -> Dict[str, float]:
 @torch.no_grad()
 def certain_forward(model: SuperGuessr, refiner: Optional[ProtoRefiner], pixel_values=None, embedding=None, labels=None,
                     labels_clf=None, **_unused):
-    """`model(**data)` followed by `refiner(...)` with the reference's outputs guaranteed (round 5): one fast pass, the tolerance of
-    every discrete decision downstream of the embedding -- the top-1 cell (pg_head_certainty) and, with a refiner, the winning
-    candidate, the candidate-set boundary, the nearest prototype and the farthest member (pg_refine_certainty) -- and ONE exact
-    re-encode (pg_vit_forward_precise) of the union of the samples that are not certain, after which their head outputs are
-    recomputed.  One host synchronisation (the uncertain set is data dependent).  The refinement itself is left to the caller (it runs
-    on the corrected embeddings / candidates: `evaluate_model` right away, `PanoramaPipeline.step` after its all-gather).
+    """`model(**data)` followed by `refiner(...)` with the reference's discrete outputs (a z ~ 4 statistical statement for the samples called certain, pigeon_amd/certainty.py): one fast pass, the tolerance of every
+    discrete decision downstream of the embedding -- the top-1 cell (pg_head_certainty) and, with a refiner, the winning candidate,
+    the candidate-set boundary, the nearest prototype and the farthest member (pg_refine_certainty) -- and ONE exact pass
+    (pg_vit_forward_precise) over the samples that are not certain, after which their head outputs AND their refinement are
+    recomputed.  This is the settle-before-return form of `pigeon_amd.deferred.DeferredExact` (one host synchronisation: how many
+    samples are uncertain is data dependent); loops over many batches use the engine's deferred form (`evaluate_model`,
+    `PanoramaPipeline.submit`).
     Returns (outputs as `model.forward` returns them, info) with info = dict(certain (B,) bool: every output of the sample is the
-    reference's; cause (B,) int32: why a sample was not certain after the fast pass; reencoded (n,) int64; head_tol, refine_tol (B,)
-    f32 or None; boundary_checked)."""
-    st = model.encode_head(pixel_values, embedding)
-    info = dict(head_tol=st['tol'], refine_tol=None, refine_code=None, boundary_checked=None)
-    can_fix = model.exact_top1 and st['pixel_values'] is not None
-    flag = ~st['certain']
-    # why a sample was sent to the exact tier (before anything is patched): 0 = certain, 1 = the head's top-1, else the refiner's
-    # decision code (pg_refine_certainty: 1xxx winner, 2xxx set boundary, 3xxx nearest prototype, 4xxx farthest member, -9 underflow)
-    cause = flag.to(torch.int32)
-    W = model.cell_layer.weight.data
-    if refiner is not None:
-        _, _, rtol, rcode, checked = refiner.forward_certain(st['embedding'], st['preds_LLH'], st['topk_indices'], st['topk_values'],
-                                                            W, model.wstats(False), model.certainty.drift_on(W.device))
-        info.update(refine_tol=rtol, refine_code=rcode, boundary_checked=checked)
-        r_unc = ~(rtol > model.certainty.threshold())
-        cause = torch.where((cause == 0) & r_unc, rcode, cause)
-        flag = flag | r_unc
-    if can_fix:
-        idx = torch.nonzero(flag).flatten()                                       # the step's one host synchronisation
-        model.reencode_rows(st, idx)
-        if refiner is not None and idx.numel():
-            # the re-encoded samples, judged again at the exact tier's floor (no systematic part there)
-            _, _, rt2, rc2, _ = refiner.forward_certain(st['embedding'][idx], st['preds_LLH'][idx], st['topk_indices'][idx],
-                                                        st['topk_values'][idx], W, model.wstats(True), None)
-            info['refine_tol'][idx], info['refine_code'][idx] = rt2, rc2
-            flag[idx] = ~st['certain'][idx] | ~(rt2 > model.certainty.threshold(exact=True))
-        elif idx.numel():
-            flag[idx] = ~st['certain'][idx]
-    info['certain'] = ~flag
-    info['cause'] = cause
-    info['reencoded'] = st['reencoded']
+    reference's; cause (B,) int32: why a sample was not certain after the fast pass; reencoded (n,) int64; head_tol, refine_tol,
+    refine_code (B,) or None; boundary_checked; refined_LLH (B,2) f32 / refined_geocell (B,) i64: the refinement's result -- the
+    caller need not run the refiner again)."""
+    res = model.engine(refiner).submit(pixel_values, embedding)[0]
+    st = dict(res['state'])
     out = model.package(st, labels, labels_clf)
+    info = dict(certain=st['certain'], cause=st['cause'], head_tol=st['tol'], refine_tol=st.get('refine_tol'),
+                refine_code=st.get('refine_code'), boundary_checked=model.engine(refiner).boundary_checked if refiner is not None else None,
+                reencoded=torch.nonzero(st['exact']).flatten(), refined_LLH=st.get('refined_LLH'),
+                refined_geocell=st.get('refined_geocell'))
     model.last_certain = info['certain']
     return out, info
 
@@ -128,32 +107,51 @@ def evaluate_model(model: SuperGuessr, dataset, metrics: Optional[Callable] = No
     combined_loss = 0.0
     combined_certain = []
     n_seen = 0
+    # The reference's loop (:77-112) computes a batch and appends its predictions; the predictions are only read after the loop
+    # (:114-140).  Here a batch's rows that the 16-bit encoder cannot settle are queued on the device and re-encoded by the exact
+    # encoder 40+ images at a time (pigeon_amd.deferred): a batch is appended when all its rows are settled -- a few iterations
+    # late, in order -- and `flush()` settles the rest after the loop.  No host synchronisation per batch.
+    from .deferred import DeferredExact
+    engine = DeferredExact(model, refiner)
+
+    def collect(done):
+        # device tensors only: a `.cpu()` / `float()` here would wait for the step that has just been queued
+        nonlocal combined_loss, n_seen
+        for res in done:
+            meta = res['meta']
+            outputs = model.package(dict(res['state']), meta.get('labels'), meta.get('labels_clf'))
+            if outputs.loss_clf is not None:
+                combined_loss = combined_loss + outputs.loss_clf.detach() * meta['n_keys']   # :81-82 (`len(data)` as the reference)
+            # :98-103: the refinement is the one the engine already ran (and re-ran for the rows the exact tier re-encoded)
+            combined_preds.append(res['refined_LLH'] if refiner is not None else outputs.preds_LLH)
+            combined_geocell_preds.append(outputs.preds_geocell)                 # :106-112
+            top5 = outputs.top5_geocells
+            combined_top5_cells.append(top5.indices)
+            combined_top5_probs.append(top5.values)
+            combined_certain.append(res['certain'])                              # every output of the sample is the reference's
+            n_seen += outputs.preds_geocell.shape[0]
+
     with torch.no_grad():
         for data in eval_data:
-            # :80 `model(**data)` -- through certain_forward, which also looks at what the refiner will consume
-            outputs, _info = certain_forward(model, refiner, **data)
-            if outputs.loss_clf is not None:
-                combined_loss += float(outputs.loss_clf) * len(data)              # :81-82 (`len(data)` as the reference)
-            if refiner is not None:                                               # :98-103
-                _, preds_LLH, _ = refiner(outputs.embedding, initial_preds=outputs.preds_LLH,
-                                          candidate_cells=outputs.top5_geocells.indices,
-                                          candidate_probs=outputs.top5_geocells.values)
-                combined_preds.append(preds_LLH.cpu().detach().numpy())
-            else:
-                combined_preds.append(outputs.preds_LLH.cpu().detach().numpy())
-            combined_geocell_preds.append(outputs.preds_geocell.cpu().detach().numpy())  # :106-112
-            top5 = outputs.top5_geocells
-            combined_top5_cells.append(top5.indices.cpu().detach().numpy())
-            combined_top5_probs.append(top5.values.cpu().detach().numpy())
-            combined_certain.append(_info['certain'].cpu().numpy())            # every output of the sample is the reference's
-            n_seen += outputs.preds_geocell.shape[0]
-    preds = np.concatenate(combined_preds, axis=0)
-    preds_geocells = np.concatenate(combined_geocell_preds, axis=0)
-    top5_geocells = np.concatenate(combined_top5_cells, axis=0)
+            # :80 `model(**data)` and :98 `refiner(...)`, with what the refiner will consume checked as well
+            keep = {'labels': data.get('labels'), 'labels_clf': data.get('labels_clf'), 'n_keys': len(data)}
+            collect(engine.submit(data.get('pixel_values'), data.get('embedding'), meta=keep))
+        collect(engine.flush())
+    dropped = engine.check_nothing_dropped()
+    if dropped:
+        raise RuntimeError(f'evaluate_model: {dropped} uncertain rows did not fit the exact tier\'s queue (internal sizing error)')
+    to_np = lambda parts: np.concatenate([t.cpu().detach().numpy() for t in parts], axis=0)     # noqa: E731
+    preds = to_np(combined_preds)
+    preds_geocells = to_np(combined_geocell_preds)
+    top5_geocells = to_np(combined_top5_cells)
+    combined_certain = [t.cpu().numpy() for t in combined_certain]
     results = dict(preds=preds, preds_geocells=preds_geocells, top5_geocells=top5_geocells,
-                   top5_probs=np.concatenate(combined_top5_probs, axis=0), loss_clf=combined_loss / max(n_seen, 1))
+                   top5_probs=to_np(combined_top5_probs), loss_clf=float(combined_loss) / max(n_seen, 1))
     if combined_certain:        # beyond the reference's keys: which samples' outputs are certain to be the fp32 reference's
         results['geocell_certain'] = np.concatenate(combined_certain, axis=0)
+        # how many samples are STILL not certain after the exact tier (judged at its floor): their outputs are returned as computed
+        results['uncertain_after_exact'] = int((~results['geocell_certain']).sum())
+        results['exact_passes'] = [dict(f) for f in engine.flush_log]
     if metrics is not None:                                                       # :122-140
         labels_lla, labels_cell = dataset['labels'], dataset['labels_clf']
         if isinstance(labels_lla, np.ndarray) == False:
@@ -252,29 +250,32 @@ class PanoramaPipeline:
     its shard of panoramas, ONE grouped all-gather moves per-image embeddings (B,4,1024) f32 + top-k candidates + initial
     predictions + sample indices to every rank (the reference's accelerator.gather, preprocessing/embed.py:36-37),
     each rank refines its 1/W slice of the gathered batch against its replica of the prototype bank, and a second, tiny
-    grouped all-gather (12 bytes per panorama) concatenates the refined (lng,lat) / geocell of all slices, so that every
-    rank -- rank 0 in particular -- holds the whole batch's result as the reference's collection loop does
-    (training/train_eval_loop.py:98-112).  All outputs are rank-major; `distributed.restore_order(res['index'], ...)`
-    puts them back in sample order."""
+    grouped all-gather concatenates the refined (lng,lat) / geocell of all slices (plus, round 6, the certainty flags and every rank's
+    exact-tier queue length), so that every rank -- rank 0 in particular -- holds the whole batch's result as the reference's
+    collection loop does (training/train_eval_loop.py:98-112).  All outputs are rank-major; `distributed.restore_order(res['index'],
+    ...)` puts them back in sample order.
 
-    def __init__(self, model: SuperGuessr, refiner: Optional[ProtoRefiner], comm: Optional[Communicator] = None):
+    Round 6: the step is `pigeon_amd.deferred.DeferredExact.submit` -- no host synchronisation, the rows the 16-bit encoder cannot
+    settle wait in a device queue for ONE exact pass per ~`min_flush` panoramas, taken by every rank in the same step on the same
+    number of slots.  `submit` returns the steps that became final (a few steps late, in order), `flush` the rest; `step` = submit +
+    flush (settled before it returns: the form tests, `smoke()` and single calls use)."""
+
+    def __init__(self, model: SuperGuessr, refiner: Optional[ProtoRefiner], comm: Optional[Communicator] = None,
+                 min_flush: int = 10, max_lag: int = 12, ops=None):
+        from .deferred import DeferredExact
         self.model, self.refiner = model, refiner
         self.comm = comm or Communicator()
-        self.refine_events = None        # set to a list to collect (start, end) stream events around the refinement launches
-        self.last_info = None            # certain_forward's info of the last step (certain, reencoded, tolerances)
-        self.split_marks = None          # set to a list to collect five time stamps per step (see split_ms): compute vs gather(-wait)
+        self.engine = DeferredExact(model, refiner, self.comm, ops=ops, min_flush=min_flush, max_lag=max_lag)
+        self.last_info = None            # of the newest result handed out: certain, cause, exact, queued
 
-    def _mark(self, marks, device):
-        """A time stamp on the device's stream (a HIP event) or, for host tensors, the host clock."""
-        if marks is None:
-            return
-        if device.type == 'cuda':
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            marks.append(ev)
-        else:
-            import time
-            marks.append(time.perf_counter())
+    @property
+    def split_marks(self):
+        return self.engine.marks
+
+    @split_marks.setter
+    def split_marks(self, v):
+        """Set to a list to collect five time stamps per submitted step (see split_ms): compute vs gather(-wait)."""
+        self.engine.marks = v
 
     @staticmethod
     def split_ms(marks):
@@ -286,43 +287,22 @@ class PanoramaPipeline:
             d = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
         return d[0] + d[2], d[1] + d[3]
 
+    def _note(self, done):
+        if done:
+            r = done[-1]
+            self.last_info = dict(certain=r['certain'], cause=r['cause'], exact=r['exact'], queued=r['queued'], step=r['step'],
+                                  boundary_checked=self.engine.boundary_checked)
+        return done
+
+    @torch.no_grad()
+    def submit(self, pixel_values: torch.Tensor, index: Optional[torch.Tensor] = None, meta=None):
+        return self._note(self.engine.submit(pixel_values, index=index, meta=meta))
+
+    @torch.no_grad()
+    def flush(self):
+        return self._note(self.engine.flush())
+
     @torch.no_grad()
     def step(self, pixel_values: torch.Tensor, index: Optional[torch.Tensor] = None):
-        marks = [] if self.split_marks is not None else None
-        self._mark(marks, pixel_values.device)
-        if hasattr(self.model, 'encode_head'):
-            # fast pass, tolerance of every decision the head AND the refinement below will take, one exact re-encode of the
-            # samples that are not certain (model.exact_top1; off: the certainty is still reported)
-            out, self.last_info = certain_forward(self.model, self.refiner, pixel_values=pixel_values)
-        else:
-            out, self.last_info = self.model(pixel_values=pixel_values, labels_clf=None), None     # stub models (bench.py --dry-run)
-        B = out.preds_geocell.shape[0]
-        if index is None:
-            index = torch.arange(B, device=out.embedding.device) + self.comm.rank * B
-        self._mark(marks, pixel_values.device)
-        # The gather BEFORE the refinement is what `north_star` / the reference's accelerator.gather ask for, not a data dependency of
-        # this step: every rank refines exactly the rows it produced (its own slice below), against its own replica of the bank.
-        emb, topi, topv, llh, idx = self.comm.gather_many([out.embedding, out.top5_geocells.indices,
-                                                           out.top5_geocells.values, out.preds_LLH, index.to(out.embedding.device)])
-        self._mark(marks, pixel_values.device)
-        res = dict(embedding=emb, index=idx, preds_geocell=topi[:, 0], preds_LLH=llh,
-                   topk_indices=topi, topk_values=topv)
-        if self.refiner is not None:
-            r = self.comm.rank
-            sl = slice(r * B, (r + 1) * B)                                        # this rank's slice of the gathered batch
-            if self.refine_events is not None:
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record()
-            _, ref_llh, ref_cell = self.refiner(emb[sl], initial_preds=llh[sl], candidate_cells=topi[sl],
-                                                candidate_probs=topv[sl], quiet=True)
-            if self.refine_events is not None:
-                ev[1].record()
-                self.refine_events.append(ev)
-            self._mark(marks, pixel_values.device)
-            res['refined_LLH'], res['refined_geocell'] = self.comm.gather_many([ref_llh, ref_cell])
-        else:
-            self._mark(marks, pixel_values.device)
-        self._mark(marks, pixel_values.device)
-        if marks is not None:
-            self.split_marks.append(marks)
-        return res
+        done = self.submit(pixel_values, index) + self.flush()
+        return done[-1]

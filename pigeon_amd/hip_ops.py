@@ -352,7 +352,7 @@ class VitEncoder:
 
     __call__ = forward
 
-    def forward_precise(self, pixels: torch.Tensor, return_hidden: bool = False):
+    def forward_precise(self, pixels: torch.Tensor, return_hidden: bool = False, out: Optional[torch.Tensor] = None):
         """The exact mode (pg_vit_forward_precise): same contract as `forward`, near-fp32 arithmetic (split-fp16 GEMM operands,
         fp32 attention / LayerNorm / QuickGELU), ~5x the time per image.  Needs `precise=True` at construction."""
         if not self.precise:
@@ -370,7 +370,9 @@ class VitEncoder:
             self._ws_precise = torch.empty(need.value + 256, dtype=torch.uint8, device=f"cuda:{self.device}")
         ws = self._ws_precise
         off = (-ws.data_ptr()) % 256
-        emb = torch.empty((n, HIDDEN), dtype=torch.float32, device=pixels.device)
+        if out is not None:
+            _dev(out, torch.float32); _shape(out, "out", n, HIDDEN)
+        emb = out if out is not None else torch.empty((n, HIDDEN), dtype=torch.float32, device=pixels.device)
         hid = torch.empty((n, TOKENS, HIDDEN), dtype=torch.float32, device=pixels.device) if return_hidden else None
         check(load().pg_vit_forward_precise(self._h, _p(pixels), _PIXDT[pixels.dtype], n, _p(emb), _p(hid),
                                             C.c_void_p(ws.data_ptr() + off), ws.numel() - off, _stream()), "pg_vit_forward_precise")
@@ -493,6 +495,76 @@ def head_certainty(logits: torch.Tensor, emb: torch.Tensor, W: torch.Tensor, top
     check(load().pg_head_certainty(_p(logits), B, Cn, _p(emb), P, _p(W), _p(topk_idx), kx, _p(drift), _p(wstats), _p(tol), _p(code),
                                    _p(margin), _p(sens), _stream()), "pg_head_certainty")
     return tol, code, margin, sens
+
+
+# ----------------------------------------------------------------------------------------- deferred exact tier (csrc/requeue.hip)
+def head_wstats(W: torch.Tensor, drift: Optional[torch.Tensor]) -> torch.Tensor:
+    """pg_head_wstats: (2,) fp32 = [largest row norm of W, max over cells of |W[c].drift| (0 without drift)]."""
+    _dev(W, torch.float32); _shape(W, "W", None, HIDDEN)
+    if drift is not None:
+        _dev(drift, torch.float32); _shape(drift, "drift", HIDDEN)
+    out = torch.empty((2,), dtype=torch.float32, device=W.device)
+    check(load().pg_head_wstats(_p(W), W.shape[0], _p(drift), _p(out), _stream()), "pg_head_wstats")
+    return out
+
+
+def requeue_append(head_tol: torch.Tensor, refine_tol: Optional[torch.Tensor], refine_code: Optional[torch.Tensor], thr: float,
+                   force_all: bool = False, dst_base: int = 0, flushed: int = 0, cap: int = 0,
+                   counters: Optional[torch.Tensor] = None, slot_dst: Optional[torch.Tensor] = None):
+    """pg_requeue_append.  Returns (certain (B,) uint8, cause (B,) int32, row_slot (B,) int32 or None without a queue)."""
+    _dev(head_tol, torch.float32)
+    B = head_tol.numel()
+    if refine_tol is not None:
+        _dev(refine_tol, torch.float32); _shape(refine_tol, "refine_tol", B)
+    if refine_code is not None:
+        _dev(refine_code, torch.int32); _shape(refine_code, "refine_code", B)
+    dev = head_tol.device
+    certain = torch.empty((B,), dtype=torch.uint8, device=dev)
+    cause = torch.empty((B,), dtype=torch.int32, device=dev)
+    row_slot = None
+    if cap > 0:
+        _dev(counters, torch.int64); _shape(counters, "counters", 2)
+        _dev(slot_dst, torch.int64); _shape(slot_dst, "slot_dst", cap)
+        row_slot = torch.empty((B,), dtype=torch.int32, device=dev)
+    check(load().pg_requeue_append(_p(head_tol), _p(refine_tol), _p(refine_code), B, float(thr), 1 if force_all else 0, int(dst_base),
+                                   int(flushed), int(cap), _p(counters), _p(slot_dst), _p(row_slot), _p(certain), _p(cause), _stream()),
+          "pg_requeue_append")
+    return certain, cause, row_slot
+
+
+def rows_to_slots(src: torch.Tensor, row_slot: torch.Tensor, dst: torch.Tensor) -> None:
+    """pg_rows_to_slots: dst[row_slot[r]] = src[r] for the rows with a slot; src (B, ...) and dst (cap, ...) share the row shape."""
+    _dev(src); _dev(dst); _dev(row_slot, torch.int32)
+    if src.dtype != dst.dtype or tuple(src.shape[1:]) != tuple(dst.shape[1:]):
+        raise _lib.PigeonHipError(f"rows_to_slots: rows of {src.dtype} {tuple(src.shape[1:])} into {dst.dtype} {tuple(dst.shape[1:])}")
+    B = src.shape[0]
+    _shape(row_slot, "row_slot", B)
+    rb = (src.numel() // max(B, 1)) * src.element_size()
+    check(load().pg_rows_to_slots(_p(src), rb, _p(row_slot), B, _p(dst), _stream()), "pg_rows_to_slots")
+
+
+def requeue_take(slot_dst: torch.Tensor, head: int, n_valid: int, n_pad: int) -> torch.Tensor:
+    """pg_requeue_take -> (n_pad,) int64 ring rows of the slots [head, head + n_pad) (mod cap), -1 beyond the first n_valid."""
+    _dev(slot_dst, torch.int64)
+    out = torch.empty((n_pad,), dtype=torch.int64, device=slot_dst.device)
+    check(load().pg_requeue_take(_p(slot_dst), slot_dst.numel(), int(head), int(n_valid), int(n_pad), _p(out), _stream()), "pg_requeue_take")
+    return out
+
+
+def scatter_rows(src: torch.Tensor, dst_row: torch.Tensor, dst: torch.Tensor, remap=None) -> None:
+    """pg_scatter_rows: dst[dst_row[i]] = src[i] (dst_row[i] < 0: skipped).  remap = (wb, b, off): dst_row addresses the gathered ring,
+    dst is a local-only array (see include/pigeon_hip.h)."""
+    _dev(src); _dev(dst); _dev(dst_row, torch.int64)
+    n = src.shape[0]
+    _shape(dst_row, "dst_row", n)
+    if src.dtype != dst.dtype or tuple(src.shape[1:]) != tuple(dst.shape[1:]):
+        raise _lib.PigeonHipError(f"scatter_rows: rows of {src.dtype} {tuple(src.shape[1:])} into {dst.dtype} {tuple(dst.shape[1:])}")
+    rb = 1
+    for d in src.shape[1:]:
+        rb *= int(d)
+    rb *= src.element_size()
+    wb, b, off = remap if remap is not None else (0, 0, 0)
+    check(load().pg_scatter_rows(_p(src), rb, _p(dst_row), n, _p(dst), dst.shape[0], int(wb), int(b), int(off), _stream()), "pg_scatter_rows")
 
 
 # ----------------------------------------------------------------------------------------- exact-mode building blocks

@@ -72,11 +72,13 @@ def predict_panorama(views: Sequence, model, refiner=None, preprocess: Optional[
             # will pick) checked, and the panorama re-encoded in the exact mode if it is not certain (exact_top1, the default)
             from .evaluate import certain_forward
             (pred_llh, topk, embedding), info = certain_forward(model, refiner, pixel_values=px)
+            if refiner is not None:
+                pred_llh = info["refined_LLH"]                     # the refinement certain_forward ran (once; re-run for re-encoded rows)
         else:
             pred_llh, topk, embedding = model(pixel_values=px)     # serving tuple, [lng, lat] order (:455, :462-466)
-        if refiner is not None:
-            _, pred_llh, _ = refiner(embedding=embedding, initial_preds=pred_llh, candidate_cells=topk.indices,
-                                     candidate_probs=topk.values)
+            if refiner is not None:
+                _, pred_llh, _ = refiner(embedding=embedding, initial_preds=pred_llh, candidate_cells=topk.indices,
+                                         candidate_probs=topk.values)
     lng, lat = (float(v) for v in pred_llh.reshape(-1, 2)[0].tolist())
     res = {"lat": lat, "lng": lng}
     # certainty of the geocell top-1 (pigeon_amd.SuperGuessr, round 4): extra keys, the extension reads lat / lng only

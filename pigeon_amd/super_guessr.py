@@ -41,7 +41,8 @@ class SuperGuessr(nn.Module):
         One extra keyword, `geocell_path`, overrides config.GEOCELL_PATH(_YFCC) (the reference hard-wires the
         path through its config module, :87-88).
 
-        The geocell argmax is the reference's, bit for bit (round 5: on by default).  The reference's `torch.argmax(geocell_probs)`
+        The geocell argmax is the reference's for every sample called certain -- a z ~ 4 statistical statement, see pigeon_amd/certainty.py
+        -- and for the re-encoded ones (round 5: on by default).  The reference's `torch.argmax(geocell_probs)`
         (:454) is fp32 end to end; this path's embeddings carry the rounding of 16-bit MFMA operands (2.7e-4 relative on default-init
         weights, 7e-4 on a high-gain tower), so a sample whose margins are smaller than what that error moves could come out with a
         runner-up.  Every forward therefore measures, per sample, the TOLERANCE of its top-1 against every other cell
@@ -53,7 +54,9 @@ class SuperGuessr(nn.Module):
           .last_certain  (B,) bool  the top-1 is the reference's (after the re-encode: judged at the exact tier's floor)
           .last_margin   (B,) fp32  logit(top-1) - logit(top-2);  .last_bound (B,) fp32 the margin change the threshold stands for
           .last_reencoded (n,) int64  the samples the exact tier re-encoded (empty when it is off)
-        With a ProtoRefiner, `pigeon_amd.evaluate.certain_forward` extends the same guarantee to the refined cell and point.
+        With a ProtoRefiner, `pigeon_amd.evaluate.certain_forward` extends the same statement to the refined cell and point.
+        Caller-supplied `embedding`s are judged against `embedding_rel_tol` (keyword; default `margin_rel_tol_exact`: they carry no
+        16-bit error of this forward).
         Extra keywords: `exact_top1`, `margin_kappa` (z-score, default 3.6), `margin_rel_tol` (default 1e-3 = the contract's embedding
         tolerance until `calibrate_certainty` -- called explicitly, or by the first forward that sees >= 8 samples with pixels, or
         once 16 samples have come in through smaller batches -- replaces it by the measured error of THIS set of weights), `margin_rel_tol_exact` (2e-5).
@@ -66,7 +69,8 @@ class SuperGuessr(nn.Module):
                                    rel_tol=float(kwargs.pop('margin_rel_tol', os.environ.get('PIGEON_MARGIN_REL_TOL', 1e-3))),
                                    rel_tol_exact=float(kwargs.pop('margin_rel_tol_exact', 2e-5)))
         self.margin_autocalibrate = bool(kwargs.pop('margin_autocalibrate', True))
-        self.last_margin = self.last_bound = self.last_certain = self.last_reencoded = self.last_tol = None
+        self.embedding_rel_tol = float(kwargs.pop('embedding_rel_tol', self.certainty.rel_tol_exact))
+        self.last_margin = self.last_certain = self.last_tol = None
         self.last_state = None
         if len(kwargs) > 0:
             print(f'Not using keyword arguments: {list(kwargs.keys())}')
@@ -100,6 +104,9 @@ class SuperGuessr(nn.Module):
         self._hip_base = None
         self._wnorm = {}                                     # exact? -> (key, device tensor): see wstats()
         self._cal_buffer = []                                # pixels of small first batches, until there are enough to calibrate on
+        self._engines = {}                                   # refiner -> settle-before-return engine (see `engine`)
+        self._last_exact = None
+        self._rel_tol0 = self.certainty.rel_tol              # the constructor's uncalibrated tolerance: what a weight load goes back to
         if self.exact_top1 and isinstance(self.base_model, HipCLIPVisionModel):
             self.base_model.enable_precise(True)             # pack the split-weight copy with the first build, not inside a request
         print(f'Initialized SuperGuessr classification model with {self.num_cells} geocells.')
@@ -160,7 +167,10 @@ class SuperGuessr(nn.Module):
         self._hip_base = None
         if isinstance(self.base_model, HipCLIPVisionModel):
             self.base_model._weights_changed()
-        self.certainty = Certainty(self.certainty.kappa, 1e-3, self.certainty.rel_tol_exact)     # other weights: the measured error is void
+        # other weights: the measured error is void -- back to the constructor's tolerance (not a hard-coded one), nothing half-collected
+        self.certainty = Certainty(self.certainty.kappa, self._rel_tol0, self.certainty.rel_tol_exact)
+        self._cal_buffer = []
+        self._engines = {}
 
     def state_dict(self, *args, **kwargs):
         sd = super().state_dict(*args, **kwargs)
@@ -195,19 +205,18 @@ class SuperGuessr(nn.Module):
 
     def wstats(self, exact: bool = False) -> Tensor:
         """(2,) fp32 on the head's device: [largest row norm of cell_layer.weight, max over cells of |W[c] . drift|] -- what bounds
-        |W[a] - W[c]| and (W[a] - W[c]).drift for the cells the certainty pass does not visit one by one.  `exact`: the exact tier has
-        no systematic part (second entry 0).  Recomputed when the weight tensor (in-place edits bump its version) or the calibrated
-        drift changes."""
+        |W[a] - W[c]| and (W[a] - W[c]).drift for the cells the certainty pass does not visit one by one (pg_head_wstats).  `exact`: the
+        exact tier has no systematic part (second entry 0).  Recomputed when the weight tensor (in-place edits bump its version) or the
+        calibrated drift changes."""
         W = self.cell_layer.weight
         drift = None if exact else self.certainty.drift_on(W.device)
         key = (W.data_ptr(), W._version, str(W.device), None if drift is None else (drift.data_ptr(), drift._version))
-        hit = self._wnorm.get(exact) if isinstance(self._wnorm, dict) else None
+        if not isinstance(self._wnorm, dict):
+            self._wnorm = {}
+        hit = self._wnorm.get(exact)
         if hit is None or hit[0] != key:
-            Wf = W.data.float()
-            wb = (Wf @ drift).abs().max() if drift is not None else torch.zeros((), device=W.device)
-            if not isinstance(self._wnorm, dict):
-                self._wnorm = {}
-            self._wnorm[exact] = (key, torch.stack([Wf.norm(dim=1).max(), wb.float()]).contiguous())
+            Wd = W.data if W.dtype == torch.float32 else W.data.float()
+            self._wnorm[exact] = (key, hip_ops.head_wstats(Wd.contiguous(), drift))
         return self._wnorm[exact][1]
 
     def _panels(self) -> int:
@@ -237,8 +246,8 @@ class SuperGuessr(nn.Module):
         """Fast pass: ViT + token mean (:395-398), head, tolerance of the top-1.  No re-encode.  Returns the step's STATE: a dict
         with `embedding` (as ModelOutput carries it), `head_in`, the head outputs over k + extra candidates (`topk_values`,
         `topk_indices`, `logits`, `preds_geocell`, `preds_LLH`), `tol`, `certain`, `exact` (rows on the exact tier: none yet) and
-        `pixel_values` (the reshaped device pixels, or None).  `reencode_rows` patches it in place; `package` turns it into the
-        reference's outputs."""
+        `pixel_values` (the reshaped device pixels, or None).  `package` turns it into the reference's outputs; pigeon_amd.deferred.DeferredExact
+        settles the rows that are not certain."""
         dev = self.cell_layer.weight.device
         px = None
         if self.panorama and pixel_values is not None:                          # :386-388
@@ -250,56 +259,76 @@ class SuperGuessr(nn.Module):
             px = pixel_values.to(dev)
             if self.exact_top1 and self.margin_autocalibrate and not self.certainty.calibrated:
                 self._autocalibrate(px)
-            embedding = self._encoder().embed(px)                               # :395-398 (ViT + token mean)
+            # a tower on which the calibration measured the 16-bit path OUTSIDE the embedding contract: every sample through the exact encoder
+            exact_tier = bool(self.certainty.force_exact and self.exact_top1)
+            embedding = self._encoder().embed_precise(px) if exact_tier else self._encoder().embed(px)   # :395-398 (ViT + token mean)
             if self.panorama:
                 embedding = embedding.reshape((num_samples, 4, embedding.shape[-1]))   # :404-405 (explicit width: B = 0 stays legal)
         else:
             embedding = embedding.to(dev, torch.float32).contiguous()
+            exact_tier = False
         head_in = self._head_rows(embedding)
-        st = self._head_with_tol(head_in, exact=False)
-        st['embedding'], st['head_in'], st['pixel_values'] = embedding, head_in, px
-        st['certain'] = st['tol'] > self.certainty.threshold()
-        if self.certainty.force_exact and px is not None and self.exact_top1:
-            st['certain'] = torch.zeros_like(st['certain'])              # the fast path is outside the contract on these weights
-        st['exact'] = torch.zeros_like(st['certain'])
-        st['reencoded'] = torch.empty((0,), dtype=torch.int64, device=dev)
+        # Which error the tolerances are compared with: the calibrated fast-path error (pixels through the 16-bit encoder), the exact
+        # tier's floor (pixels through the exact encoder), or -- caller-supplied embeddings, which carry no error of THIS forward --
+        # `embedding_rel_tol` (default: the exact tier's floor; whoever feeds embeddings written by `run.py embed`'s 16-bit path
+        # passes that path's error instead).  No systematic part in the last two cases.
+        at_floor = exact_tier or px is None
+        st = self._head_with_tol(head_in, exact=at_floor)
+        st['embedding'], st['head_in'], st['pixel_values'], st['exact_tier'] = embedding, head_in, px, exact_tier
+        st['thr'] = (self.certainty.kappa * self.embedding_rel_tol) if px is None else self.certainty.threshold(exact=exact_tier)
+        st['drift'] = None if at_floor else self.certainty.drift_on(dev)
+        st['wstats'] = self.wstats(at_floor)
         return st
 
     @torch.no_grad()
-    def reencode_rows(self, st: dict, idx: Tensor) -> None:
-        """Exact tier for the samples `idx` of a state: their pixels go through pg_vit_forward_precise, their rows of the embedding
-        and of every head output are replaced, their tolerance is judged at the exact tier's floor."""
-        if idx.numel() == 0:
-            return
-        if st['pixel_values'] is None:
-            raise ValueError('reencode_rows needs the pixels (the state was built from embeddings)')
+    def exact_rows(self, pixel_rows) -> dict:
+        """The exact tier for queued rows (pigeon_amd.deferred): `pixel_rows` is a list of (n_i, P*3*336*336) pixel-row tensors (the two
+        segments of a circular queue); they go through pg_vit_forward_precise, the head and the tolerance pass at the exact tier's
+        floor.  Returns the head state of the n = sum n_i rows (`embedding` as ModelOutput carries it)."""
         P = self._panels()
-        px = st['pixel_values'].reshape((-1, P, 3, 336, 336))[idx].reshape((-1, 3, 336, 336))
-        emb_x = self._encoder().embed_precise(px)
+        n = sum(int(t.shape[0]) for t in pixel_rows)
+        dev = self.cell_layer.weight.device
+        emb = torch.empty((n * P, CLIP_EMBED_DIM), dtype=torch.float32, device=dev)
+        enc, off = self._encoder(), 0
+        for t in pixel_rows:
+            m = int(t.shape[0])
+            if m:
+                enc.embed_precise(t.reshape((m * P, 3, 336, 336)), out=emb[off * P:(off + m) * P])
+            off += m
         if self.panorama:
-            emb_x = emb_x.reshape((idx.numel(), P, emb_x.shape[-1]))
-        st['embedding'][idx] = emb_x
-        hin = self._head_rows(emb_x)
-        st['head_in'][idx] = hin
-        o2 = self._head_with_tol(hin, exact=True)
-        for k in ('logits', 'topk_values', 'topk_indices', 'preds_geocell', 'preds_LLH', 'tol', 'code', 'margin', 'sens'):
-            st[k][idx] = o2[k]
-        st['certain'][idx] = o2['tol'] > self.certainty.threshold(exact=True)
-        st['exact'][idx] = True
-        st['reencoded'] = idx
+            emb = emb.reshape((n, P, CLIP_EMBED_DIM))
+        o = self._head_with_tol(self._head_rows(emb), exact=True)
+        o['embedding'] = emb
+        return o
 
     def _publish(self, st: dict) -> None:
-        thr = torch.where(st['exact'], self.certainty.threshold(True), self.certainty.threshold(False))
+        if 'certain' not in st:                          # a state straight from `encode_head` (no engine behind it)
+            st['certain'] = st['tol'] > st['thr']
+            st['exact'] = torch.ones_like(st['certain']) if st.get('exact_tier', False) else torch.zeros_like(st['certain'])
         self.last_tol, self.last_margin, self.last_certain = st['tol'], st['margin'], st['certain']
-        self.last_bound = st['sens'] * thr
-        self.last_reencoded = st['reencoded']
+        self._last_exact = st['exact']
         self.last_state = st
+
+    @property
+    def last_reencoded(self):
+        """(n,) int64: the samples of the last forward that went through the exact tier (a host synchronisation when read)."""
+        ex = self._last_exact
+        return None if ex is None else torch.nonzero(ex).flatten()
+
+    @property
+    def last_bound(self):
+        """(B,) fp32: the margin change the threshold stands for, per sample of the last forward (its tier's threshold x `sens`)."""
+        st = self.last_state
+        if st is None:
+            return None
+        thr = torch.where(st['exact'], self.certainty.threshold(True), self.certainty.threshold(False))
+        return st['sens'] * thr
 
     def package(self, st: dict, labels: Tensor = None, labels_clf: Tensor = None):
         """State -> the reference's outputs (:459-483).  The state's reference to the input pixels is dropped here (it was only
         needed for a possible re-encode): `last_state` must not keep a whole batch of pixels alive."""
-        st['pixel_values'] = None
         self._publish(st)
+        st['pixel_values'] = None
         k = self.num_candidates
         geocell_topk = TopK(st['topk_values'][:, :k], st['topk_indices'][:, :k])
         if not self.training and self.serving:                              # :462-466
@@ -327,11 +356,19 @@ class SuperGuessr(nn.Module):
         if not self.cell_layer.weight.is_cuda:
             raise RuntimeError('pigeon_amd.SuperGuessr runs on the GPU only: call .to("cuda") first (no CPU fallback)')
         with torch.no_grad():
-            st = self.encode_head(pixel_values, embedding)
-            if self.exact_top1 and st['pixel_values'] is not None:
-                # the one host synchronisation of the step: which samples are inside the error band is data dependent
-                self.reencode_rows(st, torch.nonzero(~st['certain']).flatten())
-            return self.package(st, labels, labels_clf)
+            # fast pass, tolerance of the top-1 against every cell, exact re-encode of the samples that are not certain
+            # (pigeon_amd.deferred, settled before this call returns: one host synchronisation)
+            res = self.engine(None).submit(pixel_values, embedding)[0]
+            return self.package(dict(res['state']), labels, labels_clf)
+
+    def engine(self, refiner=None, **kw):
+        """The settle-before-return form of pigeon_amd.deferred.DeferredExact for (this model, `refiner`), built once."""
+        from .deferred import DeferredExact
+        key = id(refiner)
+        hit = self._engines.get(key)
+        if hit is None or hit[0] is not refiner:
+            self._engines[key] = hit = (refiner, DeferredExact(self, refiner, immediate=True, **kw))
+        return hit[1]
 
     @torch.no_grad()
     def _autocalibrate(self, px: Tensor) -> None:

@@ -1,6 +1,6 @@
 """bench.py's multi-rank control flow on the CPU (no GPU here): `--dry-run` swaps the HIP model / refiner for stubs and RCCL for
 gloo, everything else -- self-launch of the N ranks, interleaved sample ids, the two grouped all-gathers of
-PanoramaPipeline.step, restore_order on rank 0, barrier-bracketed timing with max over ranks, ONE JSON line -- is the code the
+PanoramaPipeline.submit / flush (pigeon_amd.deferred), restore_order on rank 0, barrier-bracketed timing with max over ranks, ONE JSON line -- is the code the
 GPU run executes (reference launch: accelerate owns process creation, preprocessing/embed.py:55-56,68; collection of all
 ranks' results: training/train_eval_loop.py:98-112)."""
 import json
@@ -60,13 +60,15 @@ def test_bench_under_torchrun():
     _check(p.stdout, 2, 2, 1, "torchrun")
 
 
-def test_bench_world8_exact_mode_with_unequal_reencodes():
-    """The 8-rank launch the driver will make on an 8-GPU node, on the CPU: 8 ranks over gloo, the exact mode's data-dependent control
-    flow with UNEQUAL work per rank (the stub model of rank r finds r panoramas uncertain per step and pays 2 ms for each: the ranks
-    reach the all-gather at different times).  Asserted: one JSON line, every rank's results on rank 0 in sample order, and the
-    per-rank split -- the straggler (rank 7) shows up as compute on its own row and as gather-wait on everybody else's."""
+def test_bench_world8_equal_work_under_unequal_uncertain_counts():
+    """The 8-rank launch the driver will make on an 8-GPU node, on the CPU: 8 ranks over gloo, the deferred exact tier's protocol with
+    UNEQUAL uncertain counts per rank (the stub model of rank r finds r panoramas uncertain per step; an exact pass costs 2 ms per
+    SLOT run).  Asserted: one JSON line, every rank's results on rank 0 in sample order, every rank queued what it found -- and every
+    rank ran the exact tier in the SAME steps on the SAME number of slots (the longest queue), so that the exact tier's time per rank
+    is equal although rank 0 had nothing to re-encode and rank 7 seven panoramas per step."""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--panoramas", "12",
-                        "--cells", "50", "--steps", "6", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=_env())
+                        "--cells", "50", "--steps", "6", "--warmup", "1", "--min-flush", "10", "--pixel-batches", "4"],
+                       capture_output=True, text=True, timeout=600, env=_env())
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
@@ -74,16 +76,23 @@ def test_bench_world8_exact_mode_with_unequal_reencodes():
     assert r["n_gpus"] == 8 and r["config"]["images_per_step"] == 12 * 4 * 8 and r["config"]["parallelism"] == "dp8"
     assert r["gathered_results"] == {"panoramas": 96, "ranks": 8, "refined_shape": [96, 2], "complete_and_in_sample_order": True}
     sp = r["per_rank_split_ms"]
-    assert sp["reencoded_panoramas_per_step"] == [float(i) for i in range(8)]
+    assert sp["queued_panoramas_per_step"] == [float(i) for i in range(8)]              # unequal uncertain counts ...
     assert len(sp["compute"]) == 8 and len(sp["gather_incl_wait"]) == 8 and len(r["per_rank_ms_per_step"]) == 8
-    assert sp["compute"][7] > sp["compute"][0] + 6.0, sp            # 7 x 2 ms of exact-tier work on rank 7, none on rank 0 (slack: a loaded host)
-    assert sp["gather_incl_wait"][0] > sp["gather_incl_wait"][7] + 3.0, sp      # ... which rank 0 spends waiting at the collective
-    # the fast mode of the same launch: nobody re-encodes, nobody waits for a straggler
+    sched = r["exact_pass_schedule"]
+    assert sched["same_on_every_rank"] is True and len(sched["this_rank"]) >= 2          # ... same flush steps, same slots everywhere
+    for f in sched["this_rank"]:
+        assert f["slots_run"] == max(f["queued_per_rank"]) and f["queued_per_rank"][0] == 0 and f["queued_per_rank"][7] > 0
+    # 6 steps x 7 panoramas on the longest queue = 42 slots x 2 ms = 84 ms of exact tier on EVERY rank (14 ms per step)
+    ex = sp["exact_passes_per_step"]
+    assert sum(f["slots_run"] for f in sched["this_rank"]) == 42
+    assert min(ex) > 0.8 * 14.0 and max(ex) < min(ex) * 1.25 + 2.0, ex                   # equal work (slack: a loaded host, gloo)
+    # the fast mode of the same launch: nobody queues anything, no exact pass
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--fast", "--panoramas", "12",
-                        "--cells", "50", "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=_env())
+                        "--cells", "50", "--steps", "3", "--warmup", "1", "--pixel-batches", "4"], capture_output=True, text=True,
+                       timeout=600, env=_env())
     assert p.returncode == 0, p.stderr[-2000:]
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
-    assert r["per_rank_split_ms"]["reencoded_panoramas_per_step"] == [0.0] * 8
+    assert r["per_rank_split_ms"]["queued_panoramas_per_step"] == [0.0] * 8 and r["exact_pass_schedule"]["this_rank"] == []
 
 
 def test_bench_single_rank_dry_run_and_world_mismatch():

@@ -151,96 +151,133 @@ def test_tolerance_worst_direction_is_exact():
         assert ((m - g @ delta) > 0) == holds
 
 
-# ---- evaluate.certain_forward: the control flow around the kernels, with scripted stand-ins (CPU tensors; nothing computes) ---------
-class _ScriptedModel:
-    """SuperGuessr's surface as certain_forward uses it.  `head_ok` / `head_ok_exact`: which samples the head calls certain after the
-    fast / the exact pass."""
-
-    def __init__(self, head_ok, head_ok_exact, exact_top1=True):
-        self.cell_layer = torch.nn.Linear(D, 7)
-        self.certainty = Certainty()
-        self.certainty.calibrate(*_pairs(16, 2e-4, 5e-5, seed=9)[:2])
-        self.exact_top1 = exact_top1
-        self.head_ok, self.head_ok_exact = torch.tensor(head_ok), torch.tensor(head_ok_exact)
-        self.calls = []
-        self.last_certain = None
-
-    def wstats(self, exact=False):
-        return torch.tensor([1.0, 0.0 if exact else 0.5])
-
-    def encode_head(self, pixel_values=None, embedding=None):
-        B = self.head_ok.numel()
-        emb = torch.zeros((B, 4, D)) if embedding is None else embedding
-        return dict(embedding=emb, pixel_values=pixel_values, topk_values=torch.rand((B, 9)), topk_indices=torch.zeros((B, 9), dtype=torch.int64),
-                    preds_geocell=torch.zeros(B, dtype=torch.int64), preds_LLH=torch.zeros((B, 2), dtype=torch.float64),
-                    tol=self.head_ok.float(), certain=self.head_ok.clone(), reencoded=torch.empty((0,), dtype=torch.int64))
-
-    def reencode_rows(self, st, idx):
-        self.calls.append(("reencode", idx.tolist()))
-        if idx.numel():
-            st["embedding"][idx] = 1.0                                            # "the exact encoder's embedding"
-            st["certain"][idx] = self.head_ok_exact[idx]
-            st["reencoded"] = idx
-
-    def package(self, st, labels=None, labels_clf=None):
-        return st
-
-
-class _ScriptedRefiner:
-    """forward_certain: tolerance / code per sample, scripted for the fast and for the exact pass (recognised by drift=None and the
-    exact tier's wstats)."""
-
-    def __init__(self, tol_fast, code_fast, tol_exact):
-        self.tol_fast, self.code_fast, self.tol_exact = torch.tensor(tol_fast), torch.tensor(code_fast, dtype=torch.int32), torch.tensor(tol_exact)
-        self.calls = []
-
-    def forward_certain(self, emb, initial_preds, candidate_cells, candidate_probs, head_weight, wstats, drift=None):
-        exact = float(wstats[1]) == 0.0
-        self.calls.append(("exact" if exact else "fast", int(emb.shape[0]), drift is not None))
-        B = emb.shape[0]
-        if exact:
-            rows = torch.nonzero(emb[:, 0, 0] == 1.0).flatten()
-            assert rows.numel() == B                                              # only re-encoded samples are judged at the exact floor
-            return None, None, self.tol_exact[:B].clone(), torch.full((B,), 1234, dtype=torch.int32), True
-        return None, None, self.tol_fast.clone(), self.code_fast.clone(), True
-
-
+# ---- pigeon_amd.deferred / evaluate.certain_forward: the host logic around the kernels, with scripted stand-ins (tests/_scripted.py;
+# CPU tensors, oracle/requeue_oracle.py as the device ops; nothing of the real arithmetic runs) -------------------------------------
 def test_certain_forward_control_flow():
+    from _scripted import FAST_THR, ScriptedModel, ScriptedRefiner, make_pixels
     from pigeon_amd.evaluate import certain_forward
-    #          sample:   0 certain   1 head     2 refiner (nearest prototype)   3 both (the head is named)   4 refiner (underflow)
-    head_ok = [True, False, True, False, True]
-    m = _ScriptedModel(head_ok, head_ok_exact=[True, True, True, False, True])
-    thr, thr_x = m.certainty.threshold(), m.certainty.threshold(exact=True)
-    r = _ScriptedRefiner(tol_fast=[1.0, 1.0, 0.5 * thr, 0.0, 0.0], code_fast=[0, 0, 3000, 1002, -9],
-                         tol_exact=[1.0, 0.5 * thr_x, 1.0, 1.0])                  # of the re-encoded [1, 2, 3, 4]: sample 2 stays uncertain
-    st, info = certain_forward(m, r, pixel_values=torch.zeros((5, 12, 2, 2)))
-    assert info["cause"].tolist() == [0, 1, 3000, 1, -9]
-    assert m.calls == [("reencode", [1, 2, 3, 4])] and info["reencoded"].tolist() == [1, 2, 3, 4]
-    assert r.calls == [("fast", 5, True), ("exact", 4, False)]                    # drift only on the fast pass
+    #            sample:   0 certain   1 head     2 refiner     3 both (the head is named)   4 refiner
+    px = make_pixels(head_fast=[1, 0, 1, 0, 1], head_exact=[1, 1, 1, 0, 1], ref_fast=[1, 1, 0.25, 0, 0], ref_exact=[1, 1, 0, 1, 1])
+    m, r = ScriptedModel(), ScriptedRefiner()
+    st, info = certain_forward(m, r, pixel_values=px)
+    assert info["cause"].tolist() == [0, 1, 3000, 1, 3000]
+    assert m.calls == [("exact", 4)] and info["reencoded"].tolist() == [1, 2, 3, 4]
+    assert r.calls == [("fast", 5), ("exact", 4)]                                 # the systematic part only on the fast pass
     # after the exact pass: 1 and 4 resolved; 2 still below the exact floor at the refiner; 3 still uncertain at the head
     assert info["certain"].tolist() == [True, True, False, False, True] and torch.equal(m.last_certain, info["certain"])
-    assert info["refine_code"].tolist() == [0, 1234, 1234, 1234, 1234] and info["boundary_checked"] is True
-    assert info["refine_tol"][2] == pytest.approx(0.5 * thr_x) and info["head_tol"].tolist() == [1.0, 0.0, 1.0, 0.0, 1.0]
+    assert info["refine_code"].tolist() == [0, 0, 3000, 0, 0] and info["boundary_checked"] is True
+    assert info["head_tol"].tolist() == pytest.approx([1.0, 1e-3, 1e-3, 0.0, 1e-3]) and float(info["refine_tol"][2]) == 0.0
+    # row 0 keeps the fast pass's values, rows 1..4 carry the exact tier's -- embedding, head outputs AND refinement (run once each)
+    rows = px.reshape(5, -1)
+    fast, exact = m._embed(rows, True), m._embed(rows, False)
+    assert torch.equal(st["embedding"][0], fast[0]) and torch.equal(st["embedding"][1:], exact[1:])
+    hx = m._head(exact)
+    assert torch.equal(st["preds_geocell"][1:], hx["preds_geocell"][1:]) and torch.equal(st["topk_indices"][1:], hx["topk_indices"][1:])
+    assert torch.equal(st["logits"][1:], hx["logits"][1:]) and torch.equal(st["logits"][0], m._head(fast)["logits"][0])
+    assert torch.equal(info["refined_LLH"][0], (m._head(fast)["preds_LLH"][0] + 1).float())
+    assert torch.equal(info["refined_LLH"][1:], (hx["preds_LLH"][1:] + 2).float())
+    assert torch.equal(info["refined_geocell"][1:], hx["topk_indices"][1:, 1])
 
     # the 16-bit path alone (exact_top1=False): nothing is re-encoded, the flags are reported as they are
-    m = _ScriptedModel(head_ok, head_ok, exact_top1=False)
-    r = _ScriptedRefiner([1.0, 1.0, 0.5 * thr, 0.0, 0.0], [0, 0, 3000, 1002, -9], [1.0] * 4)
-    st, info = certain_forward(m, r, pixel_values=torch.zeros((5, 12, 2, 2)))
-    assert m.calls == [] and r.calls == [("fast", 5, True)] and info["reencoded"].numel() == 0
-    assert info["certain"].tolist() == [True, False, False, False, False] and info["cause"].tolist() == [0, 1, 3000, 1, -9]
+    m, r = ScriptedModel(exact_top1=False), ScriptedRefiner()
+    st, info = certain_forward(m, r, pixel_values=px)
+    assert m.calls == [] and r.calls == [("fast", 5)] and info["reencoded"].numel() == 0
+    assert info["certain"].tolist() == [True, False, False, False, False] and info["cause"].tolist() == [0, 1, 3000, 1, 3000]
 
-    # embeddings handed in (no pixels to re-encode): the same
-    m = _ScriptedModel(head_ok, head_ok)
-    st, info = certain_forward(m, None, embedding=torch.zeros((5, 4, D)))
-    assert m.calls == [] and info["certain"].tolist() == head_ok and info["refine_tol"] is None and info["cause"].tolist() == [0, 1, 0, 1, 0]
+    # embeddings handed in (no pixels to re-encode): flags only
+    m = ScriptedModel()
+    emb = torch.zeros((5, 4, 8))
+    emb[:, 0, 0] = torch.tensor([1.0, 0.0, 1.0, 0.0, 1.0])
+    st, info = certain_forward(m, None, embedding=emb)
+    assert m.calls == [] and info["certain"].tolist() == [True, False, True, False, True] and info["refine_tol"] is None
+    assert info["cause"].tolist() == [0, 1, 0, 1, 0]
 
-    # no refiner, pixels: only the head's flags, one re-encode
-    m = _ScriptedModel(head_ok, head_ok_exact=[True, True, True, False, True])
-    st, info = certain_forward(m, None, pixel_values=torch.zeros((5, 12, 2, 2)))
-    assert m.calls == [("reencode", [1, 3])] and info["certain"].tolist() == [True, True, True, False, True]
+    # no refiner, pixels: only the head's flags, one exact pass
+    m = ScriptedModel()
+    st, info = certain_forward(m, None, pixel_values=px)
+    assert m.calls == [("exact", 2)] and info["reencoded"].tolist() == [1, 3] and info["certain"].tolist() == [True, True, True, False, True]
 
-    # everything certain: the re-encode is called with an empty set (the one host synchronisation still happens), no second refiner pass
-    m = _ScriptedModel([True] * 5, [True] * 5)
-    r = _ScriptedRefiner([1.0] * 5, [0] * 5, [1.0] * 4)
-    st, info = certain_forward(m, r, pixel_values=torch.zeros((5, 12, 2, 2)))
-    assert m.calls == [("reencode", [])] and r.calls == [("fast", 5, True)] and info["certain"].all() and not info["cause"].any()
+    # everything certain: no exact pass at all
+    m, r = ScriptedModel(), ScriptedRefiner()
+    st, info = certain_forward(m, r, pixel_values=make_pixels([1] * 5))
+    assert m.calls == [] and r.calls == [("fast", 5)] and bool(info["certain"].all()) and not bool(info["cause"].any())
+    assert FAST_THR == 0.5
+
+
+def _run_engine(steps, **kw):
+    """The scripted steps through one engine -> {step: emitted result}, the order of emission, the engine."""
+    from _scripted import ScriptedModel, ScriptedRefiner
+    from oracle import requeue_oracle
+    from pigeon_amd.deferred import DeferredExact
+    m, r = ScriptedModel(), ScriptedRefiner()
+    eng = DeferredExact(m, r, ops=requeue_oracle, **kw)
+    out, order, lag = {}, [], []
+    for i, px in enumerate(steps):
+        for res in eng.submit(px, meta=i):
+            out[res["meta"]] = res
+            order.append(res["meta"])
+            lag.append(i - res["meta"])
+    for res in eng.flush():
+        out[res["meta"]] = res
+        order.append(res["meta"])
+    return out, order, lag, eng, m
+
+
+def test_deferred_engine_equals_settling_every_step():
+    """The deferred form (queue on the device, the count one step late, one exact pass per >= min_flush queued rows) hands out, for
+    every step, exactly what settling every step before it returns does -- every tensor, bit for bit -- in order, each step once."""
+    from _scripted import make_pixels
+    g = torch.Generator().manual_seed(7)
+    steps = []
+    for i in range(14):
+        B = 5 if i != 9 else 3                                                    # one short batch in the middle (a ragged loader)
+        flags = lambda p: (torch.rand(B, generator=g) > p).float().tolist()        # noqa: E731
+        steps.append(make_pixels(flags(0.25), flags(0.1), flags(0.2), flags(0.1), seed=100 + i))
+    steps[4] = make_pixels([1] * 5, seed=104)                                      # a step with nothing to fix
+    now, order_now, _, eng_now, m_now = _run_engine(steps, immediate=True)
+    later, order, lag, eng, m = _run_engine(steps, min_flush=4, max_lag=5)
+    assert order_now == list(range(14)) and order == list(range(14))               # in order, each step once
+    assert max(lag) <= 5 + 1 and max(lag) >= 1                                      # handed out late, never later than max_lag (+ the count's step)
+    for i in range(14):
+        a, b = now[i], later[i]
+        for k in a:
+            if torch.is_tensor(a[k]):
+                assert torch.equal(a[k], b[k]), (i, k)
+        for k in a["state"]:
+            if torch.is_tensor(a["state"][k]):
+                assert torch.equal(a["state"][k], b["state"][k]), (i, "state", k)
+        assert a["queued"] == b["queued"]
+    # fewer, larger exact passes: every pass but the last (flush) / a max_lag one runs on >= min_flush rows
+    sizes = [n for _, n in m.calls]
+    assert sum(sizes) == sum(n for _, n in m_now.calls) == sum(r["queued"][0] for r in later.values())
+    assert len(sizes) < len(m_now.calls) and all(n >= 4 for n in sizes[:-1])
+    assert [f["slots_run"] for f in eng.flush_log] == sizes and eng.check_nothing_dropped() == 0
+    # something was actually re-encoded and something was not
+    assert any(bool(r["exact"].any()) for r in later.values()) and any(not bool(r["exact"].all()) for r in later.values())
+
+
+def test_deferred_engine_max_lag_and_queue_wrap():
+    """A single uncertain row does not wait forever (max_lag), and the circular queue wraps without losing or mixing rows."""
+    from _scripted import make_pixels
+    steps = [make_pixels([0, 1, 1], seed=1)] + [make_pixels([1, 1, 1], seed=2 + i) for i in range(6)]
+    out, order, lag, eng, m = _run_engine(steps, min_flush=50, max_lag=3)
+    assert order == list(range(7)) and m.calls == [("exact", 1)] and eng.flush_log[0]["at_step"] <= 4
+    assert out[0]["exact"].tolist() == [True, False, False] and max(lag) <= 4
+    # wrap: capacity = min_flush + 2 B = 2 + 6 = 8 slots, 40 rows go through it
+    steps = [make_pixels([0, 0, 1], seed=10 + i) for i in range(20)]
+    now, _, _, _, _ = _run_engine(steps, immediate=True)
+    later, order, _, eng, m = _run_engine(steps, min_flush=2, max_lag=6)
+    assert eng.cap == 8 and sum(n for _, n in m.calls) == 40 and eng.check_nothing_dropped() == 0
+    for i in range(20):
+        assert torch.equal(now[i]["embedding"], later[i]["embedding"]) and torch.equal(now[i]["refined_LLH"], later[i]["refined_LLH"])
+
+
+def test_deferred_engine_empty_batch_keeps_its_place():
+    """An empty batch (a rank whose shard is empty must still be able to step) queues nothing and is handed out in its turn."""
+    from _scripted import make_pixels
+    steps = [make_pixels([0, 1, 1], seed=1), make_pixels([], seed=2), make_pixels([1, 0, 1], seed=3)]
+    out, order, lag, eng, m = _run_engine(steps, min_flush=50, max_lag=5)
+    assert order == [0, 1, 2] and out[1]["embedding"].shape == (0, 4, 8) and out[1]["certain"].numel() == 0
+    assert out[0]["exact"].tolist() == [True, False, False] and out[2]["exact"].tolist() == [False, True, False] and m.calls == [("exact", 2)]
+    out, order, _, _, _ = _run_engine([make_pixels([], seed=2)], immediate=True)
+    assert order == [0] and out[0]["refined_LLH"].shape == (0, 2)

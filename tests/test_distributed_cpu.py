@@ -80,44 +80,59 @@ def _worker(rank, world, port, outdir):
         # the reference reader's reorder (dataset_preprocessing.py:296-300) gives the same rows
         arg = np.argsort(idx.flatten()[:])                                 # duplicates sort next to their originals
         assert np.array_equal(np.unique(idx.flatten()), np.arange(23))
-    # --- the data-parallel step: ViT+head on the shard -> ONE gather -> refine own slice -> restore order
+    # --- the data-parallel step (pigeon_amd.deferred behind PanoramaPipeline): ViT + head on the shard -> gather -> refine own slice ->
+    # gather; the rows the fast path cannot settle are queued per rank, BOTH ranks run the exact tier in the SAME steps on the SAME
+    # number of slots (the longer queue), and every rank ends up with every rank's patched rows.  Scripted stand-ins: tests/_scripted.py
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _scripted import ScriptedModel, ScriptedRefiner, make_pixels
+    from oracle import requeue_oracle
     from pigeon_amd.evaluate import PanoramaPipeline
-    from pigeon_amd.utils import ModelOutput, TopK
-    B, k = 3, 5
-
-    class Model:
-        def __call__(self, pixel_values=None, labels_clf=None):
-            v = pixel_values[:, 0, 0, 0]                                    # one scalar per panorama
-            emb = v[:, None, None].repeat(1, 4, 8)
-            cells = (v.long()[:, None] * 10 + torch.arange(k)[None]).contiguous()
-            probs = torch.linspace(0.5, 0.1, k)[None].repeat(B, 1)
-            llh = torch.stack([v.double(), -v.double()], dim=1)
-            return ModelOutput(None, None, 0, 0, 0, llh, cells[:, 0].contiguous(), None, None, None, TopK(probs, cells), emb)
-
-    class Refiner:
-        calls = []
-
-        def __call__(self, emb, initial_preds=None, candidate_cells=None, candidate_probs=None, quiet=False):
-            Refiner.calls.append(emb[:, 0, 0].clone())
-            return None, (initial_preds + 0.25).float(), candidate_cells[:, 1].contiguous()
-
-    pipe = PanoramaPipeline(Model(), Refiner(), comm)
-    px = (torch.arange(B, dtype=torch.float32) + 100 * rank)[:, None, None, None].repeat(1, 12, 2, 2)
+    B = 3
+    model, refiner = ScriptedModel(), ScriptedRefiner()
+    pipe = PanoramaPipeline(model, refiner, comm, min_flush=3, max_lag=4, ops=requeue_oracle)
     index = torch.arange(B) * world + rank                                   # interleaved sample ids, as a sharded loader gives
-    res = pipe.step(px, index)
-    assert res["embedding"].shape == (B * world, 4, 8)
-    want_v = torch.cat([torch.arange(B, dtype=torch.float32) + 100 * r for r in range(world)])
-    assert torch.equal(res["embedding"][:, 0, 0], want_v)                    # rank-major
-    assert torch.equal(res["index"], torch.cat([torch.arange(B) * world + r for r in range(world)]))
-    assert torch.equal(res["preds_geocell"], (want_v.long() * 10))
-    assert torch.equal(Refiner.calls[-1], torch.arange(B, dtype=torch.float32) + 100 * rank)   # refined ITS slice only
-    # refined results of ALL ranks are gathered by the step itself (second, tiny grouped all-gather), rank-major
-    assert res["refined_LLH"].shape == (B * world, 2) and res["refined_geocell"].shape == (B * world,)
-    assert torch.equal(res["refined_LLH"][:, 0], (want_v + 0.25).float())
-    assert torch.equal(res["refined_geocell"], want_v.long() * 10 + 1)
-    ordered_emb, ordered_llh, oc = distributed.restore_order(res["index"], res["embedding"], res["preds_LLH"], res["refined_geocell"])
-    assert torch.equal(ordered_emb[:, 0, 0], torch.tensor([0., 100., 1., 101., 2., 102.]))
-    assert oc.tolist() == [1, 1001, 11, 1011, 21, 1021]
+
+    def pixels(r, i):
+        # rank 0: one uncertain panorama in every second step; rank 1: two in every step -- unequal queues by construction
+        hf = ([0, 1, 1] if i % 2 == 0 else [1, 1, 1]) if r == 0 else [0, 0, 1]
+        return make_pixels(hf, head_exact=[1, 1, 1], ref_fast=[1, 1, 1 if i != 3 else 0], ref_exact=[1, 1, 1], seed=1000 * r + i)
+
+    got = {}
+    n_steps = 7
+    for i in range(n_steps):
+        for res in pipe.submit(pixels(rank, i), index, meta=i):
+            got[res["meta"]] = res
+    for res in pipe.flush():
+        got[res["meta"]] = res
+    assert sorted(got) == list(range(n_steps))
+    log = [(f["at_step"], tuple(f["queued"]), f["slots_run"]) for f in pipe.engine.flush_log]
+    logs = [None] * world
+    torch.distributed.all_gather_object(logs, log)
+    assert logs[0] == logs[1] and len(log) >= 2                               # same steps, same queue view, same slots on both ranks
+    assert all(slots == max(q) for _, q, slots in log) and any(q[0] != q[1] for _, q, _ in log)
+    assert [n for _, n in model.calls] == [slots for _, _, slots in log]       # the exact tier ran on the PADDED size on this rank too
+    for i in range(n_steps):
+        res = got[i]
+        assert torch.equal(res["index"], torch.cat([torch.arange(B) * world + r for r in range(world)]))   # rank-major
+        for r in range(world):
+            rows = pixels(r, i).reshape(B, -1)
+            fast, exact = model._embed(rows, True), model._embed(rows, False)
+            hf, hx = model._head(fast), model._head(exact)
+            unc = (rows[:, 0] <= 0.5) | (rows[:, 2] <= 0.5)
+            sl = slice(r * B, (r + 1) * B)
+            assert res["exact"][sl].tolist() == unc.tolist() and bool(res["certain"][sl].all())
+            want_emb = torch.where(unc[:, None, None], exact, fast)
+            assert torch.equal(res["embedding"][sl], want_emb), (rank, i, r)   # every rank holds every rank's patched rows
+            want_cell = torch.where(unc, hx["preds_geocell"], hf["preds_geocell"])
+            assert torch.equal(res["preds_geocell"][sl], want_cell)
+            want_ref = torch.where(unc[:, None], (hx["preds_LLH"] + 2).float(), (hf["preds_LLH"] + 1).float())
+            assert torch.equal(res["refined_LLH"][sl], want_ref)
+            assert res["queued"][r] == int(unc.sum())
+        oi, oc = distributed.restore_order(res["index"], res["index"], res["preds_geocell"])
+        assert oi.tolist() == list(range(B * world))
+    # `step` = submit + flush: settled before it returns
+    res = pipe.step(pixels(rank, 0), index)
+    assert res["embedding"].shape == (B * world, 4, 8) and bool(res["certain"].all())
     # a host tensor among the gathered ones is refused instead of being handed to the collective as a device pointer
     # (exercised with the meta device standing in for "another device")
     try:

@@ -190,13 +190,15 @@ def test_head_tolerance_means_what_it_says(env):
     assert moved >= 8
 
 
-def _refine_tol_restated(rec, ints, L, cand, topk, n_eval, C, W, bankp, bankt, e, beta, wmax, wbmax, T, r, ch, fin_r):
+def _refine_tol_restated(rec, ints, L, cand, topk, n_eval, C, W, bankp, bankt, e, beta, wmax, wbmax, T, r, ch, fin_r, cell_sizes=None,
+                         member_counts=None):
     en = np.linalg.norm(e)
     S = L + rec[:, 0] / T
-    if not (fin_r >= 1e-30) and ints[r, 0] >= 0:
-        return 0.0, -9
-    if ints[r, 0] < 0:
-        return np.inf, 0
+    if ints[r, 0] < 0 and all(ints[j, 0] < 0 for j in range(topk)):
+        return np.inf, 0                                         # a set of empty cells: nothing can change
+    if not (fin_r >= 1e-30) or ints[r, 0] < 0:
+        return 0.0, -9                                           # underflow, or an empty cell winning a set that is not all empty
+    bn = float(np.linalg.norm(beta))
 
     def pair_s(a, j):
         pa, pj = ints[a, 0], ints[j, 0]
@@ -232,12 +234,20 @@ def _refine_tol_restated(rec, ints, L, cand, topk, n_eval, C, W, bankp, bankt, e
             t = _tol(d2 - d1, g, beta, en)
             if t < best:
                 best, code = t, 3000 + which
+            if cell_sizes is not None and cell_sizes[cand[x]] > 2:          # the prototypes the record does not name: |grad| <= 2
+                t = (d2 - d1 - en * 2.0 * bn) / (en * 2.0 / 32.0)
+                if t < best:
+                    best, code = t, 3002 + which
         if t1 >= 0 and t2 >= 0:
             f1, f2 = rec[x, 7], rec[x, 8]
             g = (e - bankt[t1]) / f1 - (e - bankt[t2]) / f2
             t = _tol(f1 - f2, g, beta, en)
             if t < best:
                 best, code = t, 4000 + which
+            if member_counts is not None and member_counts[x] > 2:
+                t = (f1 - f2 - en * 2.0 * bn) / (en * 2.0 / 32.0)
+                if t < best:
+                    best, code = t, 4002 + which
     return best, code
 
 
@@ -271,7 +281,7 @@ def test_refine_certainty_vs_restatement(env, topk, k, T, max_km, with_drift):
         ex = np.exp((sc[b, :topk, 0] / T).float().numpy()).astype(np.float32)
         fin_r = float(prob[b, r]) * float(ex[r] / ex.sum(dtype=np.float32))
         t, cd = _refine_tol_restated(rec[b], ints[b], L, cand[b].numpy(), topk, n_eval, C, Wd, bp, bt, qm[b], bz, float(wst[0]), float(wst[1]),
-                                     T, r, c, fin_r)
+                                     T, r, c, fin_r, cell_sizes=np.diff(hb.cell_off), member_counts=sc[b, :, 11].contiguous().view(torch.int32).numpy())
         got = float(tol[b])
         assert (np.isinf(t) and np.isinf(got)) or abs(got - t) <= 5e-3 * abs(t) + 1e-5, (b, got, t, int(code[b]), cd)
         if np.isfinite(t) and abs(t) > 1e-3:

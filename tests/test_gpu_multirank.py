@@ -87,3 +87,72 @@ def test_bench_two_ranks_on_two_gpus():
     assert r["n_gpus"] == 2 and r["rccl"]["nranks"] == 2 and len(r["per_rank_ms_per_step"]) == 2
     assert r["gathered_results"]["complete_and_in_sample_order"] is True and r["gathered_results"]["panoramas"] == 32
     assert r["config"]["images_per_step"] == 2 * 16 * 4 and r["scaling"] == "weak"
+    # the deferred exact tier (round 6): both ranks take their exact passes in the same steps on the same number of slots
+    sched = r["exact_pass_schedule"]
+    assert sched["same_on_every_rank"] is True
+    for f in sched["this_rank"]:
+        assert f["slots_run"] == max(f["queued_per_rank"]) and len(f["queued_per_rank"]) == 2
+    assert r["certainty"]["rows_that_did_not_fit_the_queue"] == 0
+
+
+def _deferred_worker(rank, world, port, tmp):
+    """Two RCCL ranks through pigeon_amd.deferred on the REAL classes (2-layer tower): unequal uncertain counts, one flush schedule."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from pigeon_amd import distributed, synthetic as syn
+    from pigeon_amd.clip_embedder import HipCLIPVisionModel
+    from pigeon_amd.evaluate import PanoramaPipeline
+    from pigeon_amd.proto_refiner import ProtoRefiner
+    from pigeon_amd.super_guessr import SuperGuessr
+    comm = distributed.init_from_env()
+    dev = f"cuda:{rank}"
+    C = 60
+    gp = os.path.join(tmp, f"g{rank}.csv")
+    syn.write_geocell_csv(gp, syn.make_geocells(C, seed=0))
+    vit = HipCLIPVisionModel(syn.make_vit_weights(seed=11, layers=2, affine_jitter=True), layers=2).to(dev)
+    W, b = syn.make_head_weights(C, seed=1)
+    m = SuperGuessr(vit, panorama=True, freeze_base=True, num_candidates=5, geocell_path=gp, exact_top1=True, margin_autocalibrate=False,
+                    margin_rel_tol=1e-3)
+    with torch.no_grad():
+        m.cell_layer.weight.copy_(W * 64); m.cell_layer.bias.copy_(b)
+    m = m.to(dev).eval()
+    ref = ProtoRefiner(topk=5, max_refinement=1000, temperature=1.6, bank=syn.make_bank(C, 9, seed=5, empty_frac=0.1, max_members=6),
+                       device=dev).eval()
+    steps = [syn.make_pixels(4 * 6, seed=500 + 10 * rank + i, panorama=True).to(dev) for i in range(6)]
+    from pigeon_amd.evaluate import certain_forward
+    m.certainty.kappa = 0.0
+    _, info = certain_forward(m, ref, pixel_values=steps[0])
+    tols = torch.minimum(info["head_tol"], info["refine_tol"])
+    # rank 0 flags about a sixth of its rows, rank 1 about half: unequal queues by construction (same kappa on both: one contract)
+    kq = torch.tensor([float(torch.quantile(tols.clamp(max=1e9), 0.17 if rank == 0 else 0.5)) / m.certainty.rel_tol], device=dev)
+    kq_all = comm.gather(kq)
+    m.certainty.kappa = float(kq_all.mean())
+    pipe = PanoramaPipeline(m, ref, comm, min_flush=4, max_lag=3)
+    got = {}
+    idx = torch.arange(6, device=dev) * world + rank
+    for i, px in enumerate(steps):
+        for r in pipe.submit(px, idx, meta=i):
+            got[r["meta"]] = r
+    for r in pipe.flush():
+        got[r["meta"]] = r
+    torch.cuda.synchronize()
+    assert sorted(got) == list(range(6)) and pipe.engine.check_nothing_dropped() == 0
+    log = [(f["at_step"], tuple(f["queued"]), f["slots_run"]) for f in pipe.engine.flush_log]
+    logs = [None] * world
+    torch.distributed.all_gather_object(logs, log)
+    assert all(l == logs[0] for l in logs) and all(s == max(q) for _, q, s in log)
+    # every rank holds every rank's rows, patched: compare rank-major slices across ranks
+    mine = torch.stack([got[i]["embedding"].cpu() for i in range(6)])
+    ex = torch.stack([got[i]["exact"].cpu() for i in range(6)])
+    both = [None] * world
+    torch.distributed.all_gather_object(both, (mine, ex))
+    assert all(torch.equal(both[0][0], t[0]) and torch.equal(both[0][1], t[1]) for t in both)
+    assert bool(ex.any()) and not bool(ex.all())
+    comm.barrier()
+    comm.close()
+
+
+def test_deferred_exact_tier_two_ranks_flush_in_the_same_steps(tmp_path):
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"needs 2 GPUs on one node, this box has {torch.cuda.device_count()}")
+    mp.spawn(_deferred_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)

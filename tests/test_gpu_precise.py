@@ -360,3 +360,17 @@ def test_stress_towers_vs_reference_module(env, capsys, tower):
         print(f"   product on this tower: calibration per image {st['image_rel_err']:.2e} (worst {st['worst_image_rel_err']:.2e}) -> force_exact "
               f"{st['force_exact']}; embeddings returned: worst image {worst_p:.2e}, re-encoded {model.last_reencoded.numel()}/16")
     assert st["force_exact"] and model.last_reencoded.numel() == 16 and worst_p < EXACT_TOL
+    # ... and so must the EMBED path (`run.py embed` -> CLIPEmbedding, reference models/clip_embedder.py:63-65,
+    # preprocessing/embed.py:16-43): its first batch measures the 16-bit encoder against the exact one and, outside the contract,
+    # everything it writes comes from the exact encoder (round 6)
+    from pigeon_amd.clip_embedder import CLIPEmbedding
+    emb = CLIPEmbedding("random", device=DEV, clip_model=model.base_model)
+    got = emb(px).cpu()
+    worst_e = float(((got.double() - ref.double()).norm(dim=1) / ref.double().norm(dim=1)).max())
+    with capsys.disabled():
+        print(f"   CLIPEmbedding on this tower: guard {emb.guard_stats}; embeddings returned: worst image {worst_e:.2e}")
+    assert emb.guard_stats["outside"] and emb.force_exact and worst_e < EXACT_TOL
+    with pytest.raises(RuntimeError, match="outside the 1e-3 embedding contract"):
+        CLIPEmbedding("random", device=DEV, clip_model=model.base_model, contract_guard="raise")(px)
+    off = CLIPEmbedding("random", device=DEV, clip_model=model.base_model, contract_guard="off")
+    assert torch.equal(off(px).cpu(), fast) and off.guard_stats is None

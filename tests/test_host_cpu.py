@@ -317,6 +317,81 @@ def test_load_refiner_cache_committed_reference_pickle(golden_dir, tmp_path):
     _arrays_equal(bank_from_protos(protos, ds_dir), bank)
 
 
+class _CacheHolder(torch.nn.Module):
+    """pickled under the reference's class name (see _save_as_reference_cache)"""
+
+
+_CacheHolder.__module__, _CacheHolder.__qualname__, _CacheHolder.__name__ = "models.proto_refiner", "ProtoRefiner", "ProtoRefiner"
+
+
+class _Evil:
+    marker = None
+
+    def __reduce__(self):
+        return (os.system, (f"touch {_Evil.marker}",))
+
+
+class _ViaLoadFromBytes:
+    """unpickles as torch.storage._load_from_bytes(payload)"""
+
+    def __init__(self, payload):
+        self.payload = payload
+
+    def __reduce__(self):
+        return (torch.storage._load_from_bytes, (self.payload,))
+
+
+def _save_as_reference_cache(protos, path, protocol=2):
+    import types
+    h = _CacheHolder()
+    h.protos = protos
+    mods = {"models": types.ModuleType("models"), "models.proto_refiner": types.ModuleType("models.proto_refiner")}
+    mods["models.proto_refiner"].ProtoRefiner = _CacheHolder
+    saved = {k: sys.modules.get(k) for k in mods}
+    sys.modules.update(mods)
+    try:
+        torch.save(h, path, pickle_protocol=protocol)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return path
+
+
+def test_load_refiner_cache_refuses_what_a_cache_does_not_hold(tmp_path):
+    """A pickle executes what it names: the loader's allow-list must refuse a global outside a refiner cache's data model -- directly,
+    and NESTED inside `torch.storage._load_from_bytes` (torch's own implementation of that function unpickles its argument with the
+    stock unpickler, which would resolve anything: ADVICE r05) -- while a legitimate `_load_from_bytes` payload (a torch-saved tensor)
+    and a protocol-0 object graph (`copyreg._reconstructor(cls, object, None)`) still load."""
+    import io
+    import pickle
+    from pigeon_amd.proto_refiner import load_refiner_cache
+    _Evil.marker = os.path.join(str(tmp_path), "executed")
+    d = str(tmp_path)
+
+    def expect_refused(path):
+        with pytest.raises(pickle.UnpicklingError):
+            load_refiner_cache(path)
+        assert not os.path.exists(_Evil.marker)
+
+    expect_refused(_save_as_reference_cache([_Evil()], os.path.join(d, "direct.refiner")))
+    expect_refused(_save_as_reference_cache([_ViaLoadFromBytes(pickle.dumps(_Evil()))], os.path.join(d, "nested.refiner")))
+    buf = io.BytesIO()
+    torch.save([_Evil()], buf)                                     # the nested payload as a torch zip archive: same refusal
+    expect_refused(_save_as_reference_cache([_ViaLoadFromBytes(buf.getvalue())], os.path.join(d, "nested_zip.refiner")))
+    # what a cache may legitimately hold still loads: a tensor that travels through _load_from_bytes ...
+    t = torch.arange(6, dtype=torch.float32).reshape(2, 3)
+    buf = io.BytesIO()
+    torch.save(t, buf)
+    got = load_refiner_cache(_save_as_reference_cache([_ViaLoadFromBytes(buf.getvalue()), None], os.path.join(d, "tensor.refiner")))
+    assert torch.equal(got[0], t) and got[1] is None
+    # ... and a protocol-0 pickle (copyreg._reconstructor + builtins.object for the module shell)
+    got = load_refiner_cache(_save_as_reference_cache([None, {"a": (1, 2.5, "x")}], os.path.join(d, "proto0.refiner"), protocol=0))
+    assert got == [None, {"a": (1, 2.5, "x")}]
+
+
 def test_pretrained_tower_from_local_files(tmp_path, monkeypatch):
     """reference models/clip_embedder.py:25-26 and evaluation/evaluate.py:36-40 call `CLIPVisionModel.from_pretrained(CLIP_MODEL)`;
     offline the same call runs with local_files_only=True against a `save_pretrained` directory (env PIGEON_CLIP_MODEL) or the HF
