@@ -601,6 +601,70 @@ def ingest_leg(args, dev, pipe, index, resident_ms):
     return res
 
 
+def spread_tower_leg(args, dev, bank_t, pixel_batches, index):
+    """The same step on the tower whose embeddings spread like a trained one's (synthetic.make_vit_weights_spread(seed 31): a quarter of
+    the heads at high q.k gain, image cos-sim 0.4 .. 0.75, 16-bit embedding error 7e-4 = the closest stand-in for a trained CLIP this
+    box can build), with the head centred on the mean embedding and the refiner ON: the product (deferred exact tier) and the 16-bit
+    path alone, 8 + 3 steps on the resident pixel batches.  Not the BASELINE line (other weights): an `other_configs` entry."""
+    import torch
+    from pigeon_amd import synthetic
+    from pigeon_amd.clip_embedder import HipCLIPVisionModel
+    from pigeon_amd.deferred import LocalComm
+    from pigeon_amd.evaluate import PanoramaPipeline
+    from pigeon_amd.proto_refiner import ProtoRefiner
+    from pigeon_amd.super_guessr import SuperGuessr
+    nb = len(pixel_batches)
+    sd = synthetic.make_vit_weights_spread(seed=31, layers=args.layers)
+    base = HipCLIPVisionModel(sd, layers=args.layers)
+    geo_csv = os.path.join(tempfile.mkdtemp(prefix="pigeon_bench_spread_"), "geocells.csv")
+    synthetic.write_geocell_csv(geo_csv, synthetic.make_geocells(args.cells, seed=0))
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = SuperGuessr(base, panorama=True, freeze_base=True, num_candidates=args.topk, geocell_path=geo_csv, exact_top1=True,
+                            margin_autocalibrate=False)
+    W, b = synthetic.make_head_weights(args.cells, seed=0)
+    with torch.no_grad():
+        model.cell_layer.weight.copy_(W)
+        model.cell_layer.bias.copy_(b)
+    model.to(dev).eval()
+    refiner = ProtoRefiner(topk=args.topk, max_refinement=1000, temperature=1.6, bank=bank_t, device=str(dev)).eval()
+    pipe = PanoramaPipeline(model, refiner, LocalComm(), min_flush=args.min_flush, max_lag=args.max_lag)
+    model.exact_top1 = False
+    out = pipe.step(pixel_batches[0], index)
+    with torch.no_grad():                                           # centre the head (its natural scale is kept: these embeddings spread)
+        center = out["embedding"].mean(dim=1).mean(dim=0)
+        model.cell_layer.bias.copy_(b.to(dev) - model.cell_layer.weight.data @ center)
+    model.exact_top1 = True
+    model.calibrate_certainty(pixel_batches[nb - 1], max_samples=args.panoramas)
+
+    def run(steps):
+        pipe.submit(pixel_batches[0], index)
+        pipe.flush()
+        torch.cuda.synchronize()
+        n_re, cells = [], []
+        t0 = time.perf_counter()
+        for i in range(steps):
+            for r in pipe.submit(pixel_batches[i % nb], index):
+                n_re.append(int(r["queued"][0])); cells.append(r["preds_geocell"])      # device tensors: nothing here waits for the GPU
+        for r in pipe.flush():
+            n_re.append(int(r["queued"][0])); cells.append(r["preds_geocell"])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        return dt, n_re, int(torch.unique(torch.cat(cells)).numel())
+    t_x, n_re, n_cells = run(8)
+    model.exact_top1 = False
+    t_f, _, _ = run(3)
+    st = model.certainty.stats
+    return {"workload": "NOT the BASELINE line: configs[3] on synthetic.make_vit_weights_spread(seed 31) -- embeddings spread like a trained tower's "
+                        "-- head centred on the mean embedding (natural scale), ProtoRefiner top-5 over the same 1Mx1024 bank",
+            "value": args.panoramas * 4 / t_x, "unit": "images/s", "ms_per_step": t_x * 1e3, "steps": 8,
+            "mfma_frac": args.panoramas * 4 / t_x * FLOP_PER_IMAGE / PEAK_MFMA,
+            "fast_mode": {"value": args.panoramas * 4 / t_f, "ms_per_step": t_f * 1e3, "steps": 3}, "exact_cost_vs_fast": t_x / t_f,
+            "reencoded_panoramas_per_step": n_re, "reencoded_share": float(np.sum(n_re)) / max(1, args.panoramas * len(n_re)),
+            "distinct_argmax_cells": n_cells,
+            "calibration": {k: st.get(k) for k in ("fast_vs_exact_rms", "drift_norm", "residual_rms", "image_rel_err", "worst_image_rel_err",
+                                                  "force_exact", "rel_tol")}}
+
+
 def secondary_baseline(dev, vit_sd, layers):
     """Stock PyTorch-ROCm on the same GPU, same run -- NOT the product path, never imported by pigeon_amd:
     (a) transformers.CLIPVisionModel (the module the reference calls at models/clip_embedder.py:63 /
@@ -1163,6 +1227,12 @@ def _worker(args, comm):
                        "mfma_frac": 4 * args.panoramas / t * FLOP_PER_IMAGE / PEAK_MFMA})
         except Exception as e:  # noqa
             oc.append({"error": repr(e)})
+        if refiner is not None and args.weights == "default":
+            try:
+                oc.append(spread_tower_leg(args, dev, bank_t, pixel_batches, index))
+            except Exception as e:  # noqa
+                import traceback
+                oc.append({"workload": "spread tower", "error": repr(e), "trace": traceback.format_exc()[-600:]})
         result["other_configs"] = oc
 
     # ---- the two modes next to each other.  The timed region ran the PRODUCT configuration: exact_top1 (every discrete output --

@@ -146,9 +146,18 @@ int pg_tune_gemm_tail_shape(int min_k, int min_n);
  * (each activation panel crosses the fabric once, the weight panels are re-streamed per XCD), 1..64 = explicit (honoured for a GEMM only when it divides that
  * GEMM's count of 256-column tiles, or is at least that count; otherwise the default stays).  Timing only, never results. */
 int pg_tune_gemm_raster(int gn);
+/* Small batches (round 6; also env PIGEON_GEMM_MID=0): GEMMs whose tiles do not fill one round of the persistent kernels -- one or two
+ * panoramas -- go to a 128 x 128 one-tile-per-block kernel (csrc/gemm_mid.hip) when a cost model of the shape says it is faster; 0 = never.
+ * All GEMM kernels produce the same bits for a row: timing only, never results. */
+int pg_tune_gemm_mid(int on);
 /* Exact mode's attention (also env PIGEON_EXACT_ATTN=f32): 0 = split-fp16 operands on v_mfma_f32_32x32x16_f16 (default, round 5),
  * 1 = plain fp32 on v_mfma_f32_32x32x2_f32 (round 4's kernel; the A/B arm).  Both are fp32-grade (6e-7 / 8e-7 against fp64). */
 int pg_tune_exact_attention(int use_f32_mfma);
+/* Exact mode's weight GEMMs (round 6, experimental): 3 = all three partial products hi.Wh + lo.Wh + hi.Wl (default: the exact tier), 2 = the
+ * first two (both halves of the activations, the weights at their fp16 value: K' = 2K on the same operands) -- what remains is the
+ * weights' rounding, a systematic embedding error the same for every image up to its dependence on the activations; 2/3 of the GEMM
+ * work.  Process-wide; anything else is PG_EINVAL. */
+int pg_tune_exact_products(int n);
 int pg_vit_saturation_check(pg_vit* h, int on);
 int pg_vit_saturation_read(pg_vit* h, int64_t* count, int reset);
 /* Always-on range alarm of the fp16 operand path (no scan, no cost worth naming): the kernel that turns the residual GEMMs' row
@@ -259,8 +268,8 @@ int pg_refine_forward_ex(const pg_bank* bank, const float* q, int B, int P, cons
  * for the refined and the finally chosen candidate the nearest-prototype and farthest-member picks.  The haversine veto compares
  * two discrete points and has no margin.   W (C,1024) = the head's weights (the candidates' log-probabilities move with the
  * embedding through them), wstats as above, refined / choice as pg_refine_forward_ex wrote them.
- *   tol DEVICE (B) fp32 out;  code DEVICE (B) int32 out: 1000 + j / 2000 + j / 2999 / 3000 + w / 4000 + w (see csrc/certainty.hip; w = 2, 3: the
- *   prototypes / members the record does not name, bounded with |grad| <= 2 -- round 6), -9 = the winning product underflows in fp32, or
+ *   tol DEVICE (B) fp32 out;  code DEVICE (B) int32 out: 1000 + j / 2000 + j / 2999 / 3000 + w / 4000 + w (see csrc/certainty.hip; round 6: the nearest
+ *   prototype / farthest member are checked against EVERY other prototype of the cell / member of the cluster, whose rows are streamed again), -9 = the winning product underflows in fp32, or
  *   an empty cell wins a set that is not all empty (uncertain), -8 = refined / choice outside [0, topk) (tol 0), 0 = nothing can change
  *   the row.   Limits: topk <= 64, n_eval <= min(k, 96). */
 int pg_refine_certainty(const pg_bank* bank, const float* q, int B, int P, const int64_t* cand, const float* cand_prob, int k,

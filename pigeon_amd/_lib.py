@@ -56,7 +56,9 @@ SIGNATURES = {
     "pg_tune_gemm_tail_rows": (_I, [_I]),
     "pg_tune_gemm_tail_shape": (_I, [_I, _I]),
     "pg_tune_gemm_raster": (_I, [_I]),
+    "pg_tune_gemm_mid": (_I, [_I]),
     "pg_tune_exact_attention": (_I, [_I]),
+    "pg_tune_exact_products": (_I, [_I]),
     "pg_vit_saturation_check": (_I, [_P, _I]),
     "pg_vit_saturation_read": (_I, [_P, C.POINTER(_I64), _I]),
     "pg_vit_range_alarm_read": (_I, [_P, C.POINTER(_I64), _I]),

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libpigeon_hip.so")
 # the product library: production kernels only
-SOURCES = ["vit.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_pp6.hip", "gemm_tail.hip", "attention.hip", "rowops.hip", "precise.hip",
+SOURCES = ["vit.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_pp6.hip", "gemm_tail.hip", "gemm_mid.hip", "attention.hip", "rowops.hip", "precise.hip",
            "preprocess.hip", "geo_proto.hip", "head.hip", "refine.hip", "certainty.hip", "requeue.hip", "comm.hip"]
 # additionally in the tools build (--dev), from tools/csrc/: kernel generations the product superseded, kept for A/B work
 # (gemm variant 64 = gemm_w4.hip; attention variants 1, 4..15 = attention_old.hip)

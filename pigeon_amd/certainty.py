@@ -14,7 +14,9 @@ the exact encoder.  A decision with margin m and gradient g then survives when
     (m - |e| g.beta) / (|e| |g| / 32)  >  kappa * rel_tol
 
 (left side: what pg_head_certainty / pg_refine_certainty return per sample, the minimum over the sample's decisions; kappa: a z-score).
-The exact tier's own floor is `rel_tol_exact` (the reference's CPU result itself moves by ~1e-6 with the thread partition).
+The exact tier's own floor is `rel_tol_exact`: 5e-6 = 3 x the exact encoder's measured error against the real reference (1.6e-6 at 24
+layers, 1.7e-6 on the stress towers; the reference's CPU result itself moves by ~1e-6 with the thread partition).  Until round 6 it was
+2e-5, which left a third of the re-encoded samples `uncertain` although nothing more exact exists to send them to.
 
 What this buys is a STATISTICAL statement, not a bound: with kappa = 3.6 on 1.1 x the measured residual (z ~ 4) a sample called
 certain has its discrete outputs equal to the fp32 reference's with probability 1 - O(1e-5) per decision under the Gaussian error
@@ -32,7 +34,7 @@ import torch
 
 
 class Certainty:
-    def __init__(self, kappa: float = 3.6, rel_tol: float = 1e-3, rel_tol_exact: float = 2e-5):
+    def __init__(self, kappa: float = 3.6, rel_tol: float = 1e-3, rel_tol_exact: float = 5e-6):
         self.kappa = float(kappa)
         self.rel_tol = float(rel_tol)                 # uncalibrated default: the contract's embedding tolerance
         self.rel_tol_exact = float(rel_tol_exact)

@@ -160,8 +160,8 @@ __global__ __launch_bounds__(256) void head_certainty_kernel(const float* __rest
 
 // ---- refiner: are the refined cell and point certain?  (scratch12: the records pg_refine_forward_ex left) ------------------------
 // code: 1000 + j  winner against candidate j of the set;  2000 + j  candidate j outside the set could enter and win;  2999 the cells
-// beyond the evaluated ones could enter;  3000 / 3001 nearest prototype of the refined / the chosen candidate against the runner-up,
-// 3002 / 3003 against the prototypes the record does not name (bounded: |grad| <= 2);  4000 .. 4003 farthest member likewise;
+// beyond the evaluated ones could enter;  3000 / 3001 nearest prototype of the refined / the chosen candidate against every other
+// prototype of the cell;  4000 / 4001 farthest member against every other member of the cluster;
 // -9 the winning product underflows in fp32 (or an empty cell wins a set that is not all empty);  -8 refined / choice out of range;
 // 0 nothing can change it
 __global__ __launch_bounds__(256) void refine_certainty_kernel(pg_bank bank, const float* __restrict__ q, int P,
@@ -226,21 +226,36 @@ __global__ __launch_bounds__(256) void refine_certainty_kernel(pg_bank bank, con
         axpy16r(g, ev, ij - ia);
         return tol_of(S[a] - S[j], dot16(g, g), dot16(g, bv), en);
     };
-    // tolerance of an argmin / argmax between two rows of `base` at distances dwin (the one taken: smaller if nearest) and dlose
-    auto pair_d = [&](const float* base, int win, int lose, float m, float dwin, float dlose, float sign) -> float {
-        // nearest (sign +1): m = dlose - dwin, grad = u_lose - u_win;  farthest (sign -1): m = dwin - dlose, grad = u_win - u_lose
-        const float iw = dwin > 0.f ? 1.0f / dwin : 0.f, il = dlose > 0.f ? 1.0f / dlose : 0.f;
-        f32x4 g[4];
-        zero16(g);
-        axpy16(g, base + (int64_t)lose * CT_DIM, -sign * il, lane);
-        axpy16(g, base + (int64_t)win * CT_DIM, sign * iw, lane);
-        axpy16r(g, ev, sign * (il - iw));
-        return tol_of(m, dot16(g, g), dot16(g, bv), en);
+    // every alternative to an argmin (sign +1: nearest prototype) / argmax (sign -1: farthest member) over rows [lo, hi) of `base`
+    // (through `index` if given): the pick `win` against row j has margin m = sign (d_j - d_win) and gradient sign (u_j - u_win), u =
+    // unit vector from the row to the query; |grad|^2 = 2 - 2 u_j.u_win, grad.beta = sign (u_j.beta - u_win.beta).  Distances are
+    // recomputed here (the record holds the winner's and the runner-up's only); a NaN anywhere makes the pick uncertain.
+    auto scan_alternatives = [&](const float* base, const int64_t* index, int64_t lo, int64_t hi, int64_t win, float sign, int cd_,
+                                 MinTol& acc) {
+        f32x4 w[4];
+        ld16(base + win * CT_DIM, lane, w);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = ev[i] - w[i];
+        const float dw = sqrtf(dot16(w, w));
+        const float iw = dw > 0.f ? 1.0f / dw : 0.f;
+        const float wb = dot16(w, bv) * iw;
+        for (int64_t j = lo + wave; j < hi; j += 4) {
+            const int64_t row = index ? index[j] : j;
+            if (row == win) continue;
+            f32x4 l[4];
+            ld16(base + row * CT_DIM, lane, l);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) l[i] = ev[i] - l[i];
+            const float dl = sqrtf(dot16(l, l));
+            const float il = dl > 0.f ? 1.0f / dl : 0.f;
+            const float g2 = (dl > 0.f ? 1.f : 0.f) + (dw > 0.f ? 1.f : 0.f) - 2.f * dot16(l, w) * il * iw;
+            const float gb = sign * (dot16(l, bv) * il - wb);
+            acc.take(tol_of(sign * (dl - dw), fmaxf(g2, 0.f), gb, en), cd_);
+        }
     };
 
     MinTol best; best.t = INFINITY; best.code = 0;
     int task = 0;
-    const float bn = beta ? sqrtf(dot16(bv, bv)) : 0.f;
     if (flag_under == 1) { best.t = 0.f; best.code = -9; }
     else if (flag_under == 0) {
         for (int j = 0; j < topk; ++j) {                     // the winner against the rest of the set
@@ -270,22 +285,17 @@ __global__ __launch_bounds__(256) void refine_certainty_kernel(pg_bank bank, con
             const int x = which == 0 ? r : ch;
             if (which == 1 && ch == r) break;
             const float* rx = rec0 + 12 * x;
-            const int p1 = __float_as_int(rx[5]), p2 = __float_as_int(rx[6]);
-            if (p1 >= 0 && p2 >= 0 && (task++ & 3) == wave) {
-                best.take(pair_d(bank.proto_emb, p1, p2, rx[4] - (-rx[0]), -rx[0], rx[4], 1.f), 3000 + which);
-                // The prototypes the record does not name are at least as far as the runner-up, but their direction is unknown: the
-                // gradient u_j - u_1 of two unit vectors has norm <= 2 (and (u_j - u_1).beta <= 2 |beta|), which can be a much
-                // smaller tolerance than the runner-up's when the runner-up lies almost in the winner's direction.
-                const int64_t cx = cd[x];
-                if (cx >= 0 && cx < bank.num_cells && bank.cell_off[cx + 1] - bank.cell_off[cx] > 2)
-                    best.take(tol_of(rx[4] - (-rx[0]), 4.f, 2.f * bn, en), 3002 + which);
-            }
-            const int t1 = __float_as_int(rx[9]), t2 = __float_as_int(rx[10]);
-            if (t1 >= 0 && t2 >= 0 && (task++ & 3) == wave) {
-                best.take(pair_d(bank.train_emb, t1, t2, rx[7] - rx[8], rx[7], rx[8], -1.f), 4000 + which);
-                if (__float_as_int(rx[11]) > 2)                  // members beyond the two farthest: the same bound
-                    best.take(tol_of(rx[7] - rx[8], 4.f, 2.f * bn, en), 4002 + which);
-            }
+            // Round 6: the pick is checked against EVERY alternative -- all prototypes of the cell, all members of the
+            // cluster -- not only against the runner-up of the record: a third prototype with a slightly larger margin whose
+            // direction differs more from the winner's can have the smaller tolerance.  The rows are streamed again (<= 2 cells and
+            // 2 clusters per query: a fraction of the refinement pass that just read them), one alternative per wave at a time.
+            const int p1 = __float_as_int(rx[5]);
+            const int64_t cx = cd[x];
+            if (p1 >= 0 && cx >= 0 && cx < bank.num_cells)
+                scan_alternatives(bank.proto_emb, nullptr, bank.cell_off[cx], bank.cell_off[cx + 1], p1, 1.f, 3000 + which, best);
+            const int t1 = __float_as_int(rx[9]);
+            if (t1 >= 0 && p1 >= 0)
+                scan_alternatives(bank.train_emb, bank.member_idx, bank.member_off[p1], bank.member_off[p1 + 1], t1, -1.f, 4000 + which, best);
         }
     }
     const MinTol res = block_min(best, red_t, red_c);

@@ -448,6 +448,10 @@ static bool resid6_enabled(int K) {
     if (mask < 0) { const char* e = getenv("PIGEON_GEMM_RESID6"); mask = e ? atoi(e) : PG_DEFAULT_GEMM_RESID6; if (mask < 0) mask = 0; }
     return (mask & (K >= 2048 ? 1 : 2)) != 0;
 }
+// cost model of the small-batch choice (pg_gemm_launch): microseconds per 64-wide K tile of one tile period
+#define PG_MID_US_KT_P6 1.75     // 384 x 256 persistent tile on a mostly idle chip (2.4 GHz)
+#define PG_MID_US_KT_PP 1.25     // 256 x 256
+#define PG_MID_US_KT_MID 0.60    // 128 x 128 through the 3-stage ring (measured 0.58 - 0.62: profiles/r06/gemm_mid_sweep.txt)
 static bool use_pp6(int variant, int epi, int N, int K) {
     return variant == 56 && pg_gemm_pp6_supported(epi, N, K) && (epi != EPI_RESID_STAT || resid6_enabled(K));
 }
@@ -519,9 +523,37 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
     if (g_dbg_ts && epi != EPI_PATCH) { g.aux = (const float*)g_dbg_ts; g.stagger = -7; }
     else if (epi == EPI_RESID_STAT) { static const bool abl = getenv("PIGEON_EPI_ABL") != nullptr; if (abl) g.stagger = -11; }
 #endif
+    if (variant == 71) {                                     // the whole problem through the 128 x 128 kernel of small batches (tests, tools)
+        if (!pg_gemm_mid_supported(epi, N, K)) { pg_set_error("gemm: variant 71 (gemm_mid) does not support epi=%d N=%d K=%d", epi, N, K); return PG_EINVAL; }
+        return pg_gemm_mid_launch(dtype, g, epi, s);
+    }
     if (variant == 70) {                                     // the whole problem through the small-tile tail kernel (tests, tools)
         if (!pg_gemm_tail_supported(epi, N, K)) { pg_set_error("gemm: variant 70 (gemm_tail) does not support epi=%d N=%d K=%d", epi, N, K); return PG_EINVAL; }
         return pg_gemm_tail_launch(dtype, g, epi, 0, s);
+    }
+    {
+        // Small batches (gemm_mid.hip, round 6): when the persistent kernel's tiles do not even fill ONE round -- a panorama or two:
+        // serving, calibration, a settled-at-once exact pass -- its launch takes one whole tile period with most CUs idle; the
+        // 128 x 128 one-tile-per-block kernel puts 2 - 4.5 x as many blocks on the chip.  Both produce the same bits for a row: the
+        // choice is a timing decision, taken by a two-line cost model of the shape (constants measured on MI355X,
+        // profiles/r06/gemm_mid_sweep.txt; pg_tune_gemm_mid(0) / PIGEON_GEMM_MID=0: never).
+        const bool six = use_pp6(variant, epi, N, K);
+        const bool pp = !six && (variant == 56 || (variant >= 30 && variant < 50)) && N % 256 == 0 && K % 128 == 0;
+        if ((six || pp) && pg_gemm_mid_on() && pg_gemm_mid_supported(epi, N, K)) {
+            int ncu = pg_num_cus();
+            if (pg_gemm_block_cap() > 0 && pg_gemm_block_cap() < ncu) ncu = pg_gemm_block_cap();
+            const int bm = six ? 384 : 256;
+            const int64_t tiles_p = (int64_t)((M + bm - 1) / bm) * (N / 256);
+            if (tiles_p < ncu) {
+                const bool resid = epi == EPI_RESID || epi == EPI_RESID_STAT;
+                const double kt = K / 64;
+                const double t_p = six ? kt * PG_MID_US_KT_P6 + (resid ? 14.0 : 9.0) : kt * PG_MID_US_KT_PP + (resid ? 20.0 : 8.0);
+                const int64_t tiles_m = (int64_t)((M + 127) / 128) * (N / 128);
+                const double rounds_m = (double)((tiles_m + ncu - 1) / ncu);
+                const double t_m = rounds_m * (kt * PG_MID_US_KT_MID + (resid ? 6.0 : 5.0));
+                if (t_m < t_p) return pg_gemm_mid_launch(dtype, g, epi, s);
+            }
+        }
     }
     {
         // Tail split (gemm_tail.hip): if the tiles do not fill the persistent kernel's last round and the rows beyond the last

@@ -112,6 +112,15 @@ extern "C" int pg_tune_gemm_tail_shape(int min_k, int min_n) {
     g_tail_min_k = min_k; g_tail_min_n = min_n; ++g_tune_epoch;
     return PG_OK;
 }
+static int g_gemm_mid = -1;
+bool pg_gemm_mid_on() {
+    if (g_gemm_mid < 0) { const char* e = getenv("PIGEON_GEMM_MID"); g_gemm_mid = (e && e[0] == '0') ? 0 : 1; }
+    return g_gemm_mid != 0;
+}
+extern "C" int pg_tune_gemm_mid(int on) {
+    g_gemm_mid = on ? 1 : 0; ++g_tune_epoch;
+    return PG_OK;
+}
 static float g_stagger = -1.f;
 float pg_gemm_stagger_fraction() {
     if (g_stagger < 0.f) {
@@ -711,6 +720,17 @@ extern "C" int pg_vit_forward(pg_vit* h, const void* pixels, int pix_dtype, int 
 // model (precise_parts).  (First tried as S concurrent launches on side streams: the launches did not overlap -- 4 images 15.9
 // against 14.3 ms, 52 images 112 against 76 ms, gpurun_out/r05/exact_small_batches_ksplit.txt -- hence the in-kernel form.)
 #define PG_PRECISE_CHUNK 64
+// pg_tune_exact_products (round 6): how many of the three partial products hi.Wh | lo.Wh | hi.Wl the exact mode's weight GEMMs run.
+// 3 = all (the exact tier).  2 = the first two: the activations keep both halves, the weights only their fp16 value -- K' = 2K on the
+// SAME triple operands (the third K-third of A' / W' is simply not visited).  What is left is the weights' rounding, identical for
+// every token of every image: a systematic embedding error that a calibration can measure (pigeon_amd/certainty.py), at 2/3 of the
+// exact tier's GEMM work.  The attention (activation x activation) keeps its three products.
+static int g_exact_products = 3;
+extern "C" int pg_tune_exact_products(int n) {
+    if (n != 2 && n != 3) { pg_set_error("pg_tune_exact_products: 2 or 3"); return PG_EINVAL; }
+    g_exact_products = n;
+    return PG_OK;
+}
 static size_t precise_ws_bytes_for(int chunk) {
     const size_t M = (size_t)chunk * VIT_TOKENS;
     return align_up(M * VIT_HIDDEN * 4, 256) + align_up(M * 3 * VIT_HIDDEN * 2, 256) + align_up(M * VIT_MLP * 4, 256) +
@@ -729,7 +749,7 @@ extern "C" int pg_vit_precise_workspace_bytes(const pg_vit* h, int n_images, siz
 // order, ~1e-7 relative, two orders below the exact tier's own floor).  Measured on MI355X (gpurun_out/r05/exact8_kernel_stats.csv,
 // 8 images): out-projection 107 -> 54 us, fc2 351 -> 158 us with S = 3 / 6; QKV and fc1 (216 / 288 tiles of 48 K tiles) gain nothing
 // from a split at that size and lose at larger ones, which the model reproduces.
-static int precise_parts(int M, int N, int Ktot, bool resid, const int* cand, int ncand) {
+static int precise_parts(int M, int N, int Ktot, bool resid, const int* cand, int ncand, double* best_us_out = nullptr) {
     const double ncu = (double)pg_num_cus();
     const double tiles = (double)((M + 255) / 256) * (N / 256);
     int best = 1; double best_us = 1e30;
@@ -742,6 +762,7 @@ static int precise_parts(int M, int N, int Ktot, bool resid, const int* cand, in
         if (S > 1) us += 4.0 + (double)(S + (resid ? 2 : 1)) * M * N * 4.0 / 4.0e6;
         if (us < best_us) { best_us = us; best = S; }
     }
+    if (best_us_out) *best_us_out = best_us;
     return best;
 }
 
@@ -752,7 +773,17 @@ static int precise_parts(int M, int N, int Ktot, bool resid, const int* cand, in
 static int precise_gemm(pg_vit* h, const uint16_t* A3, int64_t lda, const uint16_t* W3, int64_t ldw, const float* bias, float* parts,
                         float* dst, bool resid, int M, int N, int Ktot, const int* cand, int ncand, hipStream_t s) {
     (void)h;
-    const int S = precise_parts(M, N, Ktot, resid, cand, ncand);
+    double parts_us = 0.0;
+    const int S = precise_parts(M, N, Ktot, resid, cand, ncand, &parts_us);
+    // Round 6: a handful of images (a settled-at-once exact pass: serving, certain_forward) -- the 128 x 128 one-tile-per-block kernel
+    // (gemm_mid.hip) keeps the whole K' in one chain like S = 1 and still fills the chip; same cost model as pg_gemm_launch
+    // (0.6 us per K tile of a round + epilogue).  Bit-identical to the S = 1 persistent launch.
+    if (pg_gemm_mid_on() && N % 128 == 0) {
+        const double rounds_m = ceil((double)((M + 127) / 128) * (N / 128) / (double)pg_num_cus());
+        const double mid_us = rounds_m * ((Ktot / 64) * 0.6 + (resid ? 6.0 : 5.0));
+        if (mid_us < parts_us)
+            return pg_gemm_launch(PG_DTYPE_F16, A3, lda, W3, ldw, bias, dst, N, M, N, Ktot, resid ? EPI_RESID : EPI_F32, 1.f, 0, nullptr, 71, s);
+    }
     if (S == 1)
         return pg_gemm_launch(PG_DTYPE_F16, A3, lda, W3, ldw, bias, dst, N, M, N, Ktot, resid ? EPI_RESID : EPI_F32, 1.f, 0, nullptr, 36, s);
     const int Kp = Ktot / S;
@@ -776,21 +807,24 @@ static int vit_precise_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n
     const float eps = h->cfg.ln_eps;
     const int dt = PG_DTYPE_F16, V = 36;                      // the 256 x 256 persistent kernel takes every epilogue used here
     static const int S3[2] = {1, 3}, S6[4] = {1, 2, 3, 6};    // K-part counts precise_parts may choose from (K' = 3072 / 12288)
+    static const int S2[2] = {1, 2}, S4[3] = {1, 2, 4};       // ... with two products (K' = 2048 / 8192)
+    const int np = g_exact_products;                          // partial products per weight GEMM (3; 2: pg_tune_exact_products)
+    const int* c1 = np == 3 ? S3 : S2; const int* c2 = np == 3 ? S6 : S4; const int n2 = np == 3 ? 4 : 3;
     RC(pg_x3_im2col_launch(pixels, pix_dtype, G3, n, s));
-    RC(pg_gemm_launch(dt, G3, 3 * VIT_PATCH_KPAD, h->wpatch3, 3 * VIT_PATCH_KPAD, nullptr, X, D, n * VIT_PATCHES, D, 3 * VIT_PATCH_KPAD,
+    RC(pg_gemm_launch(dt, G3, 3 * VIT_PATCH_KPAD, h->wpatch3, 3 * VIT_PATCH_KPAD, nullptr, X, D, n * VIT_PATCHES, D, np * VIT_PATCH_KPAD,
                       EPI_PATCH, 1.f, 0, h->pos, V, s));
     RC(pg_preln_launch(X, h->cls, h->pos, h->preg, h->preb, M, eps, s));
     for (int l = 0; l < h->cfg.layers; ++l) {
         const LayerW& L = h->layers[l];
         RC(pg_x3_ln_launch(X, L.ln1g, L.ln1b, T3, M, eps, s));
-        RC(precise_gemm(h, T3, 3 * D, L.wqkv3, 3 * D, L.bqkv_raw, PP, Fb, false, (int)M, 3 * D, 3 * D, S3, 2, s));
+        RC(precise_gemm(h, T3, 3 * D, L.wqkv3, 3 * D, L.bqkv_raw, PP, Fb, false, (int)M, 3 * D, np * D, c1, 2, s));
         RC(pg_attention_f32_launch(Fb, O, n, s));
         RC(pg_x3_split_launch(O, T3, M, D, 0, s));
-        RC(precise_gemm(h, T3, 3 * D, L.wo3, 3 * D, L.bo, PP, X, true, (int)M, D, 3 * D, S3, 2, s));
+        RC(precise_gemm(h, T3, 3 * D, L.wo3, 3 * D, L.bo, PP, X, true, (int)M, D, np * D, c1, 2, s));
         RC(pg_x3_ln_launch(X, L.ln2g, L.ln2b, T3, M, eps, s));
-        RC(precise_gemm(h, T3, 3 * D, L.w13, 3 * D, L.b1_raw, PP, Fb, false, (int)M, F, 3 * D, S3, 2, s));
+        RC(precise_gemm(h, T3, 3 * D, L.w13, 3 * D, L.b1_raw, PP, Fb, false, (int)M, F, np * D, c1, 2, s));
         RC(pg_x3_split_launch(Fb, G3, M, F, 1, s));
-        RC(precise_gemm(h, G3, 3 * F, L.w23, 3 * F, L.b2, PP, X, true, (int)M, D, 3 * F, S6, 4, s));
+        RC(precise_gemm(h, G3, 3 * F, L.w23, 3 * F, L.b2, PP, X, true, (int)M, D, np * F, c2, n2, s));
     }
     RC(pg_token_mean_launch(X, emb_out, n, s));
     if (hidden_out) PG_HIP(hipMemcpyAsync(hidden_out, X, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s));

@@ -731,3 +731,8 @@ def refine_certainty(bank: DeviceBank, q: torch.Tensor, cand: torch.Tensor, cand
 def tune_gemm_raster(gn: int) -> None:
     """pg_tune_gemm_raster: N tiles per raster group of the 384 x 256 GEMM (0 default, -1 all).  Timing only."""
     check(load().pg_tune_gemm_raster(int(gn)), "pg_tune_gemm_raster")
+
+
+def tune_gemm_mid(on: bool) -> None:
+    """pg_tune_gemm_mid: small batches through the 128 x 128 kernel when the cost model says so (default on).  Timing only."""
+    check(load().pg_tune_gemm_mid(1 if on else 0), "pg_tune_gemm_mid")

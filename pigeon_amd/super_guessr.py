@@ -59,7 +59,7 @@ class SuperGuessr(nn.Module):
         16-bit error of this forward).
         Extra keywords: `exact_top1`, `margin_kappa` (z-score, default 3.6), `margin_rel_tol` (default 1e-3 = the contract's embedding
         tolerance until `calibrate_certainty` -- called explicitly, or by the first forward that sees >= 8 samples with pixels, or
-        once 16 samples have come in through smaller batches -- replaces it by the measured error of THIS set of weights), `margin_rel_tol_exact` (2e-5).
+        once 16 samples have come in through smaller batches -- replaces it by the measured error of THIS set of weights), `margin_rel_tol_exact` (5e-6).
         """
         super(SuperGuessr, self).__init__()
         geocell_path = kwargs.pop('geocell_path', None)
@@ -67,7 +67,7 @@ class SuperGuessr(nn.Module):
         self.exact_top1 = (os.environ.get('PIGEON_EXACT_TOP1', '1') not in ('', '0')) if exact_top1 is None else bool(exact_top1)
         self.certainty = Certainty(kappa=float(kwargs.pop('margin_kappa', os.environ.get('PIGEON_MARGIN_KAPPA', 3.6))),
                                    rel_tol=float(kwargs.pop('margin_rel_tol', os.environ.get('PIGEON_MARGIN_REL_TOL', 1e-3))),
-                                   rel_tol_exact=float(kwargs.pop('margin_rel_tol_exact', 2e-5)))
+                                   rel_tol_exact=float(kwargs.pop('margin_rel_tol_exact', 5e-6)))
         self.margin_autocalibrate = bool(kwargs.pop('margin_autocalibrate', True))
         self.embedding_rel_tol = float(kwargs.pop('embedding_rel_tol', self.certainty.rel_tol_exact))
         self.last_margin = self.last_certain = self.last_tol = None

@@ -145,7 +145,13 @@ def _dispatch(args, comm):
         results = evaluate(args.name, dataset, yfcc=args.yfcc, base_model=_vision_model(args), refine=True,
                            landmarks=args.landmarks, geocell_path=geocell_path, bank=bank)
         if comm.is_main_process:
-            print({k: (v if not hasattr(v, 'shape') or v.shape == () else tuple(v.shape)) for k, v in results.items()})
+            print({k: (v if not hasattr(v, 'shape') or v.shape == () else tuple(v.shape)) for k, v in results.items() if k != 'exact_passes'})
+            if 'geocell_certain' in results:
+                # beyond the reference's output: how many samples' discrete outputs are certain to be the fp32 reference's (a z ~ 4
+                # statistical statement, pigeon_amd/certainty.py), and how many are near-ties of the reference itself
+                cert = results['geocell_certain']
+                print(f"certain: {int(cert.sum())}/{cert.size} samples; still uncertain after the exact tier (returned as computed): "
+                      f"{results.get('uncertain_after_exact', 0)}; exact passes: {[f['slots_run'] for f in results.get('exact_passes', [])]} panoramas")
         return results
 
 

@@ -96,7 +96,7 @@ class ScriptedModel:
             import time
             time.sleep(self.exact_cost_s * rows.shape[0])
         st = self._head(self._embed(rows, fast=False))
-        st['tol'] = rows[:, 1].clone() * 1e-3              # 1.0 -> certain (> 7.2e-5), 0.0 -> still not
+        st['tol'] = rows[:, 1].clone() * 1e-3              # 1.0 -> certain (> 1.8e-5), 0.0 -> still not
         return st
 
     def package(self, st, labels=None, labels_clf=None):
@@ -121,5 +121,5 @@ class ScriptedRefiner:
         exact = drift is None
         self.calls.append(('exact' if exact else 'fast', int(emb.shape[0])))
         tol = emb[:, 0, -1].clone() * (1e-3 if exact else 1.0)
-        code = torch.where(tol > (7.2e-5 if exact else FAST_THR), 0, 3000).to(torch.int32)
+        code = torch.where(tol > (1.8e-5 if exact else FAST_THR), 0, 3000).to(torch.int32)
         return ((initial_preds + (2.0 if exact else 1.0)).float(), candidate_cells[:, 1].contiguous(), tol, code, True)

@@ -39,7 +39,7 @@ def test_calibrate_recovers_systematic_part_and_residual():
     assert abs(st["residual_rms"] - 5e-5 * math.sqrt(1 + 1 / 32)) < 0.05 * 5e-5
     assert c.rel_tol == pytest.approx(1.1 * st["residual_rms"])
     assert float((c.drift - beta).norm()) < 0.2 * 5e-5 * 2                       # the mean over 64 samples: eps / 8 off
-    assert c.threshold() == pytest.approx(3.6 * c.rel_tol) and c.threshold(exact=True) == pytest.approx(3.6 * 2e-5)
+    assert c.threshold() == pytest.approx(3.6 * c.rel_tol) and c.threshold(exact=True) == pytest.approx(3.6 * 5e-6)
     assert not c.force_exact and "calibrated on 64 samples" in c.describe()
 
 

@@ -190,15 +190,14 @@ def test_head_tolerance_means_what_it_says(env):
     assert moved >= 8
 
 
-def _refine_tol_restated(rec, ints, L, cand, topk, n_eval, C, W, bankp, bankt, e, beta, wmax, wbmax, T, r, ch, fin_r, cell_sizes=None,
-                         member_counts=None):
+def _refine_tol_restated(rec, ints, L, cand, topk, n_eval, C, W, bankp, bankt, e, beta, wmax, wbmax, T, r, ch, fin_r, cell_off=None,
+                         member_off=None, member_idx=None):
     en = np.linalg.norm(e)
     S = L + rec[:, 0] / T
     if ints[r, 0] < 0 and all(ints[j, 0] < 0 for j in range(topk)):
         return np.inf, 0                                         # a set of empty cells: nothing can change
     if not (fin_r >= 1e-30) or ints[r, 0] < 0:
         return 0.0, -9                                           # underflow, or an empty cell winning a set that is not all empty
-    bn = float(np.linalg.norm(beta))
 
     def pair_s(a, j):
         pa, pj = ints[a, 0], ints[j, 0]
@@ -227,27 +226,31 @@ def _refine_tol_restated(rec, ints, L, cand, topk, n_eval, C, W, bankp, bankt, e
     for which, x in enumerate((r, ch)):
         if which == 1 and ch == r:
             break
-        p1, p2, t1, t2 = ints[x, 0], ints[x, 1], ints[x, 2], ints[x, 3]
-        if p1 >= 0 and p2 >= 0:
-            d1, d2 = -rec[x, 0], rec[x, 4]
-            g = (e - bankp[p2]) / d2 - (e - bankp[p1]) / d1
-            t = _tol(d2 - d1, g, beta, en)
-            if t < best:
-                best, code = t, 3000 + which
-            if cell_sizes is not None and cell_sizes[cand[x]] > 2:          # the prototypes the record does not name: |grad| <= 2
-                t = (d2 - d1 - en * 2.0 * bn) / (en * 2.0 / 32.0)
+        p1, t1 = ints[x, 0], ints[x, 2]
+        if p1 >= 0:                                              # nearest prototype against EVERY other prototype of the cell
+            lo, hi = cell_off[cand[x]], cell_off[cand[x] + 1]
+            w = e - bankp[p1]
+            dw = np.linalg.norm(w)
+            for j in range(lo, hi):
+                if j == p1:
+                    continue
+                l = e - bankp[j]
+                dl = np.linalg.norm(l)
+                t = _tol(dl - dw, l / dl - w / dw, beta, en)
                 if t < best:
-                    best, code = t, 3002 + which
-        if t1 >= 0 and t2 >= 0:
-            f1, f2 = rec[x, 7], rec[x, 8]
-            g = (e - bankt[t1]) / f1 - (e - bankt[t2]) / f2
-            t = _tol(f1 - f2, g, beta, en)
-            if t < best:
-                best, code = t, 4000 + which
-            if member_counts is not None and member_counts[x] > 2:
-                t = (f1 - f2 - en * 2.0 * bn) / (en * 2.0 / 32.0)
+                    best, code = t, 3000 + which
+        if t1 >= 0 and p1 >= 0:                                  # farthest member against every other member of the cluster
+            w = e - bankt[t1]
+            dw = np.linalg.norm(w)
+            for jj in range(member_off[p1], member_off[p1 + 1]):
+                j = member_idx[jj]
+                if j == t1:
+                    continue
+                l = e - bankt[j]
+                dl = np.linalg.norm(l)
+                t = _tol(dw - dl, w / dw - l / dl, beta, en)
                 if t < best:
-                    best, code = t, 4002 + which
+                    best, code = t, 4000 + which
     return best, code
 
 
@@ -281,7 +284,7 @@ def test_refine_certainty_vs_restatement(env, topk, k, T, max_km, with_drift):
         ex = np.exp((sc[b, :topk, 0] / T).float().numpy()).astype(np.float32)
         fin_r = float(prob[b, r]) * float(ex[r] / ex.sum(dtype=np.float32))
         t, cd = _refine_tol_restated(rec[b], ints[b], L, cand[b].numpy(), topk, n_eval, C, Wd, bp, bt, qm[b], bz, float(wst[0]), float(wst[1]),
-                                     T, r, c, fin_r, cell_sizes=np.diff(hb.cell_off), member_counts=sc[b, :, 11].contiguous().view(torch.int32).numpy())
+                                     T, r, c, fin_r, cell_off=hb.cell_off, member_off=hb.member_off, member_idx=hb.member_idx)
         got = float(tol[b])
         assert (np.isinf(t) and np.isinf(got)) or abs(got - t) <= 5e-3 * abs(t) + 1e-5, (b, got, t, int(code[b]), cd)
         if np.isfinite(t) and abs(t) > 1e-3:

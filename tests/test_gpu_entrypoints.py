@@ -617,3 +617,7 @@ def test_run_py_evaluate_exact_top1(env, monkeypatch, capsys):
     assert np.array_equal(results["preds_geocells"], o["preds_geocell"].numpy())
     assert model.last_reencoded.numel() == 16, "the exact pass did not run on every panorama"
     assert results["geocell_certain"].dtype == np.bool_
+    # what stays uncertain after the exact tier is counted and printed; all 16 went through ONE exact pass
+    assert results["uncertain_after_exact"] == int((~results["geocell_certain"]).sum())
+    assert [f["slots_run"] for f in results["exact_passes"]] == [16]
+    assert "still uncertain after the exact tier" in capsys.readouterr().out

@@ -174,6 +174,24 @@ def test_gemm_tail_kernel_bit_identical_to_persistent(env, dt):
         assert bool((o[M:].float() == 7.0).all())
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_gemm_mid_kernel_bit_identical_to_persistent(env, dt):
+    """gemm_mid.hip (round 6; variant 71 = a whole problem through it): 128 x 128 one-tile-per-block tiles through a 3-stage LDS
+    ring, the kernel of batches too small to fill the persistent kernels.  Same MFMA chain over k, same slab geometry, same
+    gemm_epi.h expressions: every epilogue must come out BIT-identical to the persistent kernel -- ragged M (a last row tile of 13
+    rows), one K tile, two, three (the ring's wrap) and 64 of them (fc2's K), guard rows untouched."""
+    ops, L = env["ops"], env["lib"]
+    names = ("qkv", "gelu", "resid", "f32", "qkv_ln", "gelu_ln", "resid_stat.X", "resid_stat.x16", "resid_stat.part")
+    for M, N, K, seed in ((1000 + 13, 1024, 512, 21), (2308, 3072, 1024, 22), (577, 1024, 4096, 23), (130, 1024, 128, 24), (64, 1024, 384, 25)):
+        A, W, bias, X0, cs, rs = _tail_problem(M, N, K, seed, dt)
+        ref = _gemm_all_epilogues(ops, L, A, W, bias, X0, cs, rs, M, 36)
+        got = _gemm_all_epilogues(ops, L, A, W, bias, X0, cs, rs, M, 71)
+        for n, a, b in zip(names, ref, got):
+            assert torch.equal(a, b), (n, M, N, K)
+        for o in got[:4]:
+            assert bool((o[M:].float() == 7.0).all())
+
+
 def test_gemm_tail_split_changes_nothing(env):
     """pg_gemm_launch cuts a problem whose tiles do not fill the persistent kernel's last round: whole rounds to the persistent
     kernel, the few rows beyond them to gemm_tail.hip.  With the split switched off (tail rows 0) the same call must give the
