@@ -200,7 +200,7 @@ class DeferredExact:
             self.local['refine_tol'][lbase:lbase + b].copy_(rtol)
             self.local['refine_code'][lbase:lbase + b].copy_(rcode)
         if can_fix:
-            px_rows = px.reshape((b, -1))
+            px_rows = px.reshape((b, -1)).contiguous()            # (a strided view handed in by the caller: one copy; else free)
             if self.q_pixels is None or self.px_shape != (tuple(px_rows.shape[1:]), px_rows.dtype):
                 if self.q_pixels is not None:
                     raise RuntimeError('DeferredExact: the pixel geometry changed while rows are queued; call flush() first')
