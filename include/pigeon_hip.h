@@ -99,7 +99,7 @@ int pg_vit_forward_hidden(pg_vit* h, const void* pixels, int pix_dtype, int n_im
  * split into two fp16 halves (x = hi + lo, W = Wh + Wl) and the products hi.Wh + lo.Wh + hi.Wl are accumulated in fp32 by the same
  * persistent MFMA kernels over a 3x longer K; LayerNorm, attention (fp32 MFMA), QuickGELU (expf, IEEE division) and the residual
  * stream are fp32.  Measured against the fp32 reference: embeddings to ~1e-6 relative (fast path: 2.7e-4), at ~5x the time per
- * image.  Needs cfg.precise at creation.  Workspace from pg_vit_precise_workspace_bytes (50 KB per token row, chunks of 64 images).
+ * image.  Needs cfg.precise at creation.  Workspace from pg_vit_precise_workspace_bytes (98 KB per token row, equal chunks of at most 128 images).
  * hidden_out (DEVICE (n_images,577,1024) fp32, may be NULL) receives last_hidden_state. */
 int pg_vit_precise_workspace_bytes(const pg_vit* h, int n_images, size_t* bytes);
 int pg_vit_forward_precise(pg_vit* h, const void* pixels, int pix_dtype, int n_images, float* emb_out, float* hidden_out,

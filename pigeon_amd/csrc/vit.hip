@@ -710,7 +710,7 @@ extern "C" int pg_vit_forward(pg_vit* h, const void* pixels, int pix_dtype, int 
 // kernels, fp32 LayerNorm / attention / QuickGELU / residual), for the panoramas whose top-1 margin the 16-bit path cannot decide.
 // Workspace per token row: X fp32 4 KB | T3 triple of a 1024-wide row 6 KB | F fp32 QKV (12 KB) / fc1 (16 KB) | G3 triple of the
 // 4096-wide activation 24 KB (the im2col triple and the fp32 attention output live there too) | (round 5) PP, the K-split partial
-// products of one GEMM, 48 KB (fc1: 3 x 4096 fp32) = 98 KB; chunks of <= 64 images.
+// products of one GEMM, 48 KB (fc1: 3 x 4096 fp32) = 98 KB; equal chunks of <= 128 images.
 //
 // Round 5: a GEMM of the layer loop whose tiles would not fill the chip is cut along K' into S parts (the products hi.Wh | lo.Wh |
 // hi.Wl, or halves of them) that run as ONE persistent launch over S x tilesM x tilesN tiles (PgGemmExtra::parts) into fp32 partial
@@ -719,7 +719,7 @@ extern "C" int pg_vit_forward(pg_vit* h, const void* pixels, int pix_dtype, int 
 // layer for fc2 alone: latency, not work); 240 tiles of 32 K tiles fill the chip instead.  S is chosen per shape by a small cost
 // model (precise_parts).  (First tried as S concurrent launches on side streams: the launches did not overlap -- 4 images 15.9
 // against 14.3 ms, 52 images 112 against 76 ms, gpurun_out/r05/exact_small_batches_ksplit.txt -- hence the in-kernel form.)
-#define PG_PRECISE_CHUNK 64
+#define PG_PRECISE_CHUNK 128   // images per internal pass (98 KB of workspace per token row: 7.2 GB at 128); a longer batch is cut into EQUAL chunks
 // pg_tune_exact_products (round 6): how many of the three partial products hi.Wh | lo.Wh | hi.Wl the exact mode's weight GEMMs run.
 // 3 = all (the exact tier).  2 = the first two: the activations keep both halves, the weights only their fp16 value -- K' = 2K on the
 // SAME triple operands (the third K-third of A' / W' is simply not visited).  What is left is the weights' rounding, identical for
@@ -846,8 +846,11 @@ extern "C" int pg_vit_forward_precise(pg_vit* h, const void* pixels, int pix_dty
     if (((uintptr_t)workspace & 255) != 0) { pg_set_error("vit_forward_precise: workspace must be 256-byte aligned"); return PG_EINVAL; }
     const size_t esz = pix_dtype == PG_DTYPE_F32 ? 4 : 2;
     const size_t img_elems = (size_t)3 * VIT_IMG * VIT_IMG;
-    for (int s0 = 0; s0 < n_images; s0 += PG_PRECISE_CHUNK) {
-        const int n = (n_images - s0) < PG_PRECISE_CHUNK ? (n_images - s0) : PG_PRECISE_CHUNK;
+    // equal chunks (130 images: 65 + 65, not 128 + 2 -- a two-image pass costs as much as a sixteen-image one)
+    const int nchunks = (n_images + PG_PRECISE_CHUNK - 1) / PG_PRECISE_CHUNK;
+    const int per = (n_images + nchunks - 1) / nchunks;
+    for (int s0 = 0; s0 < n_images; s0 += per) {
+        const int n = (n_images - s0) < per ? (n_images - s0) : per;
         RC(vit_precise_chunk(h, (const char*)pixels + (size_t)s0 * img_elems * esz, pix_dtype, n, emb_out + (size_t)s0 * VIT_HIDDEN,
                              hidden_out ? hidden_out + (size_t)s0 * VIT_TOKENS * VIT_HIDDEN : nullptr, (char*)workspace, (hipStream_t)stream));
     }
