@@ -316,7 +316,17 @@ class CLIPEmbedding(torch.nn.Module):
         err = (fast - exact).norm(dim=1) / exact.norm(dim=1).clamp_min(1e-30)
         st = {'images': int(px.shape[0]), 'image_rel_err': float((fast - exact).norm() / exact.norm().clamp_min(1e-30)),
               'worst_image_rel_err': float(err.max()), 'contract': contract}
-        st['outside'] = st['image_rel_err'] > 0.85 * contract or st['worst_image_rel_err'] > 0.95 * contract
+        # one verdict for a data-parallel job (`run.py embed` under torchrun): every rank measures its own first batch; all ranks act on
+        # the worst measurement, so that the files they write together do not mix encoders
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            every = [None] * dist.get_world_size()
+            dist.all_gather_object(every, (st['image_rel_err'], st['worst_image_rel_err']))
+            st['image_rel_err_all_ranks'] = max(e[0] for e in every)
+            st['worst_image_rel_err_all_ranks'] = max(e[1] for e in every)
+        overall = st.get('image_rel_err_all_ranks', st['image_rel_err'])
+        worst = st.get('worst_image_rel_err_all_ranks', st['worst_image_rel_err'])
+        st['outside'] = overall > 0.85 * contract or worst > 0.95 * contract
         self.guard_stats = st
         print(f"pigeon_amd.CLIPEmbedding: 16-bit encoder vs exact encoder on {st['images']} images of the first batch: "
               f"{st['image_rel_err']:.2e} relative overall, worst image {st['worst_image_rel_err']:.2e} (contract {contract:g})")

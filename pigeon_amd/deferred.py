@@ -143,6 +143,7 @@ class DeferredExact:
         plus `step`, `meta` (what the caller passed), `state` (this rank's rows in the form `SuperGuessr.package` takes)."""
         model, comm, ops = self.model, self.comm, self.ops
         marks = [] if self.marks is not None else None
+        settled = []
         self.dev = getattr(self, 'dev', None) or model.cell_layer.weight.device
         self._mark(marks)
         st = model.encode_head(pixel_values, embedding)
@@ -199,12 +200,21 @@ class DeferredExact:
                 st['wstats'], st.get('drift'))
             self.local['refine_tol'][lbase:lbase + b].copy_(rtol)
             self.local['refine_code'][lbase:lbase + b].copy_(rcode)
-        if can_fix:
+        wants_queue = bool(getattr(model, 'exact_top1', False)) and px is not None
+        if wants_queue:
+            # (also a rank whose whole batch went through the exact encoder -- `exact_tier`: it queues nothing, but in a data-parallel job
+            # it still runs the padded exact passes the other ranks' queues ask for)
             px_rows = px.reshape((b, -1)).contiguous()            # (a strided view handed in by the caller: one copy; else free)
             if self.q_pixels is None or self.px_shape != (tuple(px_rows.shape[1:]), px_rows.dtype):
                 if self.q_pixels is not None:
-                    raise RuntimeError('DeferredExact: the pixel geometry changed while rows are queued; call flush() first')
+                    # another pixel dtype / geometry (e.g. fp16 pixels from the GPU preprocessing after fp32 tensors): settle what is
+                    # queued in the old one, then start a new queue (every rank sees the same change in the same step)
+                    settled = self.flush()
+                    self.counters.zero_()
+                    self.flushed = [0] * comm.world_size
+                    self._prev_appended = [0] * comm.world_size
                 self._alloc_queue(px_rows)
+        if can_fix:
             certain, cause, row_slot = ops.requeue_append(st['tol'], rtol, rcode, thr, False, dst_base=gbase + rank * b,
                                                           flushed=self.flushed[rank], cap=self.cap, counters=self.counters,
                                                           slot_dst=self.slot_dst)
@@ -227,7 +237,7 @@ class DeferredExact:
         self.pending.append(dict(step=step, slot=slot, b=b, meta=meta, appended=None, can_fix=can_fix))
         self.n_submitted += 1
         st['pixel_values'] = None                                # the queue holds what it needs; do not keep a batch of pixels alive
-        return self._advance(final=False)
+        return settled + self._advance(final=False)
 
     def flush(self) -> List[dict]:
         """Settle everything that is pending (one host synchronisation) and hand it out."""

@@ -281,3 +281,21 @@ def test_deferred_engine_empty_batch_keeps_its_place():
     assert out[0]["exact"].tolist() == [True, False, False] and out[2]["exact"].tolist() == [False, True, False] and m.calls == [("exact", 2)]
     out, order, _, _, _ = _run_engine([make_pixels([], seed=2)], immediate=True)
     assert order == [0] and out[0]["refined_LLH"].shape == (0, 2)
+
+
+def test_deferred_engine_pixel_dtype_change_settles_and_restarts_the_queue():
+    """fp32 pixel tensors, then fp16 ones (what the GPU preprocessing hands over): the rows queued in the old geometry are settled
+    first, the queue restarts, every step is handed out once and in order (bench.py's ingest leg did exactly this and failed)."""
+    from _scripted import ScriptedModel, ScriptedRefiner, make_pixels
+    from oracle import requeue_oracle
+    from pigeon_amd.deferred import DeferredExact
+    m, r = ScriptedModel(), ScriptedRefiner()
+    eng = DeferredExact(m, r, ops=requeue_oracle, min_flush=50, max_lag=6)
+    steps = [make_pixels([0, 1, 1], seed=1), make_pixels([1, 0, 1], seed=2), make_pixels([1, 1, 0], seed=3).half(), make_pixels([0, 1, 1], seed=4).half()]
+    order = []
+    for i, px in enumerate(steps):
+        order += [res["meta"] for res in eng.submit(px, meta=i)]
+    assert order[:2] == [0, 1] and m.calls[0] == ("exact", 2)              # the dtype change settled the two fp32 rows at once
+    order += [res["meta"] for res in eng.flush()]
+    assert order == [0, 1, 2, 3] and m.calls == [("exact", 2), ("exact", 2)] and eng.q_pixels.dtype == torch.float16
+    assert eng.check_nothing_dropped() == 0
