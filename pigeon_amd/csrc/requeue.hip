@@ -170,6 +170,7 @@ extern "C" int pg_rows_to_slots(const void* src, int64_t row_bytes, const int32_
     if (B < 0 || row_bytes < 0) { pg_set_error("rows_to_slots: bad size"); return PG_EINVAL; }
     if (B == 0 || row_bytes == 0) return PG_OK;
     if (!src || !row_slot || !dst) { pg_set_error("rows_to_slots: null argument"); return PG_EINVAL; }
+    if (B > 65535) { pg_set_error("rows_to_slots: B = %d rows exceed the launch grid (65535)", B); return PG_EINVAL; }
     const int vb = vec_bytes(src, dst, row_bytes);
     const dim3 g = row_grid(row_bytes, vb, B);
     hipStream_t s = (hipStream_t)stream;
@@ -185,6 +186,7 @@ extern "C" int pg_scatter_rows(const void* src, int64_t row_bytes, const int64_t
     if (n < 0 || row_bytes < 0 || dst_rows < 0) { pg_set_error("scatter_rows: bad size"); return PG_EINVAL; }
     if (n == 0 || row_bytes == 0) return PG_OK;
     if (!src || !dst_row || !dst) { pg_set_error("scatter_rows: null argument"); return PG_EINVAL; }
+    if (n > 65535) { pg_set_error("scatter_rows: n = %d rows exceed the launch grid (65535)", n); return PG_EINVAL; }
     const int vb = vec_bytes(src, dst, row_bytes);
     const dim3 g = row_grid(row_bytes, vb, n);
     hipStream_t s = (hipStream_t)stream;

@@ -71,6 +71,7 @@ class DeferredExact:
         self.dropped_checked = 0
         self.boundary_checked = None
         self.marks = None                         # set to a list: submit() appends [start, before gather 1, after, before gather 2, end]
+        self.dev = None                           # the model's device, known at the first submit
 
     # ------------------------------------------------------------------------------------------------ storage
     def _alloc(self, st: dict, B: int, index_dtype=torch.int64):
@@ -144,7 +145,8 @@ class DeferredExact:
         model, comm, ops = self.model, self.comm, self.ops
         marks = [] if self.marks is not None else None
         settled = []
-        self.dev = getattr(self, 'dev', None) or model.cell_layer.weight.device
+        if self.dev is None:
+            self.dev = model.cell_layer.weight.device
         self._mark(marks)
         st = model.encode_head(pixel_values, embedding)
         b = int(st['tol'].shape[0])
