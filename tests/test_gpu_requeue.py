@@ -235,3 +235,51 @@ def test_evaluate_model_runs_deferred_and_equals_the_chain(env, tmp_path):
     assert np.array_equal(res["geocell_certain"], np.concatenate(want_cert))
     assert res["uncertain_after_exact"] == int((~np.concatenate(want_cert)).sum())
     assert 1 <= len(res["exact_passes"]) < 6 and sum(f["slots_run"] for f in res["exact_passes"]) >= 3
+
+
+def test_deferred_engine_random_stress(env, tmp_path):
+    """40 steps of random size (1 .. 6 panoramas; the largest first so that the ring is sized once), a pixel dtype that flips between
+    fp32 and fp16 twice, a small queue (min_flush 3: it wraps many times), about a third of the rows uncertain: every step is handed out
+    once, in order; its discrete outputs, flags and re-encoded set equal those of settling every step at once; nothing is dropped."""
+    from pigeon_amd.deferred import DeferredExact
+    from pigeon_amd.evaluate import certain_forward
+    syn = env["syn"]
+    m, ref, vit = _small_setup(env, tmp_path, rel_tol=1e-3)
+    g = torch.Generator().manual_seed(99)
+    sizes = [6] + torch.randint(1, 7, (39,), generator=g).tolist()
+    steps = []
+    for i, b in enumerate(sizes):
+        px = syn.make_pixels(4 * b, seed=700 + i, panorama=True).to(DEV)
+        steps.append(px.half() if 12 <= i < 25 else px)
+    m.certainty.kappa = 0.0
+    tols = []
+    for px in steps[:4]:
+        _, info = certain_forward(m, ref, pixel_values=px)
+        tols.append(torch.minimum(info["head_tol"], info["refine_tol"]).clamp(max=1e9))
+    m.certainty.kappa = float(torch.quantile(torch.cat(tols), 0.33)) / m.certainty.rel_tol
+
+    def run(**kw):
+        eng = DeferredExact(m, ref, **kw)
+        got, order = {}, []
+        for i, px in enumerate(steps):
+            for r in eng.submit(px, meta=i):
+                got[r["meta"]] = r; order.append(r["meta"])
+        for r in eng.flush():
+            got[r["meta"]] = r; order.append(r["meta"])
+        return got, order, eng
+    now, order_now, _ = run(immediate=True)
+    later, order, eng = run(min_flush=3, max_lag=5)
+    assert order_now == list(range(40)) and order == list(range(40)) and eng.check_nothing_dropped() == 0
+    n_exact = 0
+    for i in range(40):
+        a, b = now[i], later[i]
+        for k in ("preds_geocell", "topk_indices", "refined_geocell", "refined_LLH", "preds_LLH", "exact", "certain", "cause", "index"):
+            assert torch.equal(a[k], b[k]), (i, k)
+        ex = b["exact"]
+        assert torch.equal(a["embedding"][~ex], b["embedding"][~ex])
+        if bool(ex.any()):
+            assert float((a["embedding"][ex] - b["embedding"][ex]).norm() / a["embedding"][ex].norm()) < 2e-6
+        n_exact += int(ex.sum())
+    total = sum(sizes)
+    assert 0.1 * total < n_exact < 0.7 * total, (n_exact, total)
+    assert len(eng.flush_log) < sum(1 for i in range(40) if bool(now[i]["exact"].any()))       # fewer, larger exact passes
