@@ -2,6 +2,7 @@
 symbols include/pigeon_hip.h declares.  No compute calls (there is no GPU here)."""
 import os
 import re
+import sys
 
 import pytest
 
@@ -78,3 +79,16 @@ def test_header_is_plain_c():
     r = subprocess.run([cc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "pigeon_hip.h")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check (`__graft_entry__.build()`, run on a box without a GPU every round): compiles / reuses the in-tree
+    library, imports the package, checks the ABI version against the header's -- it must not lag behind a version bump."""
+    import re
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.build()
+    header = open(os.path.join(ROOT, "include", "pigeon_hip.h")).read()
+    want = int(re.search(r"#define PG_ABI_VERSION\s+(\d+)", header).group(1))
+    from pigeon_amd import _lib
+    assert _lib.load().pg_abi_version() == want
