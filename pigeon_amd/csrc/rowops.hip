@@ -260,12 +260,22 @@ int pg_im2col_launch(const void* pixels, int pix_dtype, void* out, int out_dtype
 
 // ---- token mean: (n,577,1024) fp32 -> (n,1024) ---------------------------------------------------------
 // Block = (image, 256-column slab); a thread owns one column and walks the 577 rows (coalesced across threads).
-// 4 independent partial sums keep 4 loads in flight.
+// Four partial sums, rows dealt round-robin: s_(t mod 4) += x[t] -- that order is part of the result.  Round 6: 16 rows are LOADED
+// before they are added (16 loads in flight instead of 4; the kernel is latency-bound at small batches: one block per 256 columns of an
+// image).  The additions and their order are unchanged -- bit-identical, pinned by test_token_mean_summation_order_is_pinned; the
+// encoder's latency at one panorama did not move (3.86 ms), the launch is 1 % of it.
 __global__ __launch_bounds__(256) void token_mean_kernel(const float* __restrict__ x, float* __restrict__ out) {
     const int img = blockIdx.x >> 2, col = (blockIdx.x & 3) * 256 + threadIdx.x;
     const float* p = x + (int64_t)img * VIT_TOKENS * VIT_HIDDEN + col;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int t = 0;
+    for (; t + 16 <= VIT_TOKENS; t += 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = p[(int64_t)(t + i) * VIT_HIDDEN];
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) { s0 += v[i]; s1 += v[i + 1]; s2 += v[i + 2]; s3 += v[i + 3]; }
+    }
     for (; t + 4 <= VIT_TOKENS; t += 4) {
         s0 += p[(int64_t)(t + 0) * VIT_HIDDEN];
         s1 += p[(int64_t)(t + 1) * VIT_HIDDEN];

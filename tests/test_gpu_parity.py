@@ -860,3 +860,21 @@ def test_serve_predict_panorama(env, vit2, tmp_path):
     (llh, topk, emb), _ = certain_forward(model, refiner, pixel_values=px)
     _, want, _ = refiner(embedding=emb, initial_preds=llh, candidate_cells=topk.indices, candidate_probs=topk.values)
     assert {k: got_r[k] for k in ("lat", "lng")} == {"lat": float(want[0, 1]), "lng": float(want[0, 0])}
+
+
+def test_token_mean_summation_order_is_pinned(env):
+    """pg_op_token_mean (reference models/clip_embedder.py:64-65 `last_hidden_state.mean(dim=1)`): four partial sums, rows dealt
+    round-robin, ((s0 + s1) + (s2 + s3)) / 577 in fp32 -- restated in numpy float32 and compared BIT FOR BIT, so that a faster kernel
+    (round 6: 16 loads in flight instead of 4) cannot change an embedding's bits; and within fp32 rounding of torch's own mean."""
+    ops = env["ops"]
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn((3, 577, 1024), generator=g) * 3 + 0.5).contiguous()
+    got = ops.token_mean(x.to(DEV)).cpu().numpy()
+    xn = x.numpy()
+    s = [np.zeros((3, 1024), dtype=np.float32) for _ in range(4)]
+    for t in range(577):
+        j = t % 4 if t < 576 else 0
+        s[j] = (s[j] + xn[:, t, :]).astype(np.float32)
+    want = (((s[0] + s[1]).astype(np.float32) + (s[2] + s[3]).astype(np.float32)).astype(np.float32) / np.float32(577)).astype(np.float32)
+    assert np.array_equal(got, want)
+    assert np.allclose(got, xn.mean(axis=1, dtype=np.float64), rtol=0, atol=2e-6)
