@@ -94,7 +94,9 @@ def parse(argv=None):
     ap.add_argument("--layers", type=int, default=24)
     ap.add_argument("--pixel-batches", type=int, default=16, help="distinct resident pixel batches used in turn (16 x 694 MB: the share of "
                     "panoramas the exact tier re-encodes is then that of fresh data, ~2.2 %%, not that of 4 lucky batches)")
-    ap.add_argument("--min-flush", type=int, default=10, help="queued panoramas that trigger one exact pass (pigeon_amd.deferred)")
+    ap.add_argument("--min-flush", type=int, default=0, help="queued panoramas that trigger one exact pass (pigeon_amd.deferred); 0 = one pass quantum")
+    ap.add_argument("--pass-quantum", type=int, default=-1,
+                    help="an exact pass takes a multiple of this many panoramas (-1 = what fills one round of the CUs: 7 on 256 CUs; 0 = all queued)")
     ap.add_argument("--max-lag", type=int, default=12, help="steps a queued panorama may wait for the exact pass")
     ap.add_argument("--cpu-images", type=int, default=64, help="images in the bounded CPU-baseline / CPU-oracle parity sample (0 = skip); 64 = 16 panoramas")
     ap.add_argument("--cpu-port-images", type=int, default=16, help="images through the oracle restatement (kind 'port') on the CPU (0 = skip)")
@@ -627,7 +629,8 @@ def spread_tower_leg(args, dev, bank_t, pixel_batches, index):
         model.cell_layer.bias.copy_(b)
     model.to(dev).eval()
     refiner = ProtoRefiner(topk=args.topk, max_refinement=1000, temperature=1.6, bank=bank_t, device=str(dev)).eval()
-    pipe = PanoramaPipeline(model, refiner, LocalComm(), min_flush=args.min_flush, max_lag=args.max_lag)
+    pipe = PanoramaPipeline(model, refiner, LocalComm(), min_flush=args.min_flush or None, max_lag=args.max_lag,
+                            pass_quantum=None if args.pass_quantum < 0 else args.pass_quantum)
     model.exact_top1 = False
     out = pipe.step(pixel_batches[0], index)
     with torch.no_grad():                                           # centre the head (its natural scale is kept: these embeddings spread)
@@ -888,7 +891,8 @@ def _worker(args, comm):
         except Exception as e:  # noqa
             rccl_error = repr(e)
             comm.force_rccl = False
-    pipe = PanoramaPipeline(model, refiner, comm, min_flush=args.min_flush, max_lag=args.max_lag, ops=dry_ops)
+    pipe = PanoramaPipeline(model, refiner, comm, min_flush=args.min_flush or None, max_lag=args.max_lag, ops=dry_ops,
+                            pass_quantum=None if args.pass_quantum < 0 else args.pass_quantum)
     # sample ids as a sharded DataLoader deals them (batch i -> rank i % world, preprocessing/embed.py:68): interleaved, so the
     # gathered results really need restore_order
     index = (torch.arange(args.panoramas, device=dev) * world + rank)
@@ -1070,10 +1074,10 @@ def _worker(args, comm):
                               "queued_panoramas_per_step": [round(x, 2) for x in rank_reenc],
                               "what": "stream time stamps around the two grouped all-gathers of every timed step: compute = encoder + head + "
                                       "certainty + refinement + queueing of the uncertain rows; gather = both collectives including the wait "
-                                      "for the slowest rank; exact_passes = the exact tier's passes (one per ~min_flush queued panoramas, "
+                                      "for the slowest rank; exact_passes = the exact tier's passes (one per min_flush queued panoramas, a whole number of pass quanta each, "
                                       "same steps and same slot count on every rank), averaged over the steps"},
         "exact_pass_schedule": {"this_rank": flush_sched, "same_on_every_rank": bool(all(sc == all_sched[0] for sc in all_sched)),
-                                "min_flush": args.min_flush, "max_lag": args.max_lag},
+                                "min_flush": pipe.engine.min_flush, "pass_quantum": pipe.engine.pass_quantum, "max_lag": args.max_lag},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32-stub" if dry else enc.mma_dtype, "data": "synthetic",
         "config": {"workload": "BASELINE configs[3]: SuperGuessr 4-panorama ViT-L/14-336 + 10k-geocell head + ProtoRefiner "

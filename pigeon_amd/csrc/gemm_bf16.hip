@@ -451,6 +451,7 @@ static bool resid6_enabled(int K) {
 // cost model of the small-batch choice (pg_gemm_launch): microseconds per 64-wide K tile of one tile period
 #define PG_MID_US_KT_P6 1.75     // 384 x 256 persistent tile on a mostly idle chip (2.4 GHz)
 #define PG_MID_US_KT_PP 1.25     // 256 x 256
+#define PG_TAIL_US 36.0          // gemm_tail.hip on a <= 768-row tail, either shape (profiles/r02/gemm_tail.txt, profiles/r06/step_kernel_stats.csv)
 #define PG_MID_US_KT_MID 0.60    // 128 x 128 through the 3-stage ring (measured 0.58 - 0.62: profiles/r06/gemm_mid_sweep.txt)
 static bool use_pp6(int variant, int epi, int N, int K) {
     return variant == 56 && pg_gemm_pp6_supported(epi, N, K) && (epi != EPI_RESID_STAT || resid6_enabled(K));
@@ -556,13 +557,19 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
         }
     }
     {
-        // Tail split (gemm_tail.hip): if the tiles do not fill the persistent kernel's last round and the rows beyond the last
-        // whole round are few, the persistent kernel gets the rows that make whole rounds and the small-tile kernel the rest.
-        // Both produce the same bits for a row, so the cut changes timing only.
+        // Tail split: if the tiles do not fill the persistent kernel's last round and the rows beyond the last whole round are
+        // few, the persistent kernel gets the rows that make whole rounds and a small-tile kernel the rest.  All three produce
+        // the same bits for a row, so the cut changes timing only.  WHERE to cut is round 2's measurement (vit.hip, the MIN_K /
+        // MIN_N thresholds: fc2 and fc1; for out-projection and QKV the extra launch costs what the 8-tile last round did --
+        // measured again in round 6 with the cheaper tail kernel below, profiles/r06/tail_mid_ab.txt: still nothing end to end).
+        // WHICH kernel takes the tail is a cost model: gemm_tail.hip (32 x 64 one-wave tiles) needs ~36 us for the benchmark
+        // batch's 512 rows whatever the shape; gemm_mid.hip (round 6) does a K = 1024 tail in 15 - 19 us
+        // (profiles/r06/gemm_mid_sweep.txt, the n = 1 column) and a K = 4096 one in 44: fc1's tail goes through it (the fc1
+        // launch pair 2.257 -> 2.237 ms, 0.4347 -> 0.4384 of the MFMA peak on one box), fc2's stays.
         const bool six = use_pp6(variant, epi, N, K);
         const bool pp = !six && (variant == 56 || (variant >= 30 && variant < 50)) && N % 256 == 0 && K % 128 == 0;
         const int tail_max = pg_gemm_tail_rows();
-        if ((six || pp) && tail_max > 0 && (K >= pg_gemm_tail_min_k() || N >= pg_gemm_tail_min_n()) && pg_gemm_tail_supported(epi, N, K)) {
+        if ((six || pp) && tail_max > 0) {
             const int bm = six ? 384 : 256;
             int ncu = pg_num_cus();
             if (pg_gemm_block_cap() > 0 && pg_gemm_block_cap() < ncu) ncu = pg_gemm_block_cap();
@@ -572,11 +579,22 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
             if (rounds >= 1 && ntiles % ncu != 0) {
                 const int64_t m_main = (rounds * ncu / tilesN) * bm;         // row panels that fit into `rounds` whole rounds
                 if (m_main > 0 && m_main < M && M - m_main <= tail_max) {
-                    GemmArgs gm = g;
-                    gm.M = (int)m_main;
-                    const int rc = six ? pg_gemm_pp6_launch(dtype, gm, epi, s) : pg_gemm_pp_launch(dtype, gm, epi, variant == 56 ? 36 : variant, s);
-                    if (rc != PG_OK) return rc;
-                    return pg_gemm_tail_launch(dtype, g, epi, (int)m_main, s);
+                    const bool resid = epi == EPI_RESID || epi == EPI_RESID_STAT;
+                    const double kt = K / 64;
+                    // the round the cut removes (constants of the small-batch model above: a lower bound on a busy chip)
+                    const double t_round = six ? kt * PG_MID_US_KT_P6 + (resid ? 14.0 : 9.0) : kt * PG_MID_US_KT_PP + (resid ? 20.0 : 8.0);
+                    const int64_t tiles_m = (int64_t)((M - m_main + 127) / 128) * (N / 128);
+                    const double t_mid = (double)((tiles_m + ncu - 1) / ncu) * (kt * PG_MID_US_KT_MID + (resid ? 6.0 : 5.0)) + 3.0;   // + a launch
+                    const bool cut = K >= pg_gemm_tail_min_k() || N >= pg_gemm_tail_min_n();
+                    const bool by_mid = cut && pg_gemm_mid_on() && pg_gemm_mid_supported(epi, N, K) && t_mid < PG_TAIL_US && t_mid < t_round;
+                    const bool by_tail = cut && !by_mid && pg_gemm_tail_supported(epi, N, K);
+                    if (by_mid || by_tail) {
+                        GemmArgs gm = g;
+                        gm.M = (int)m_main;
+                        const int rc = six ? pg_gemm_pp6_launch(dtype, gm, epi, s) : pg_gemm_pp_launch(dtype, gm, epi, variant == 56 ? 36 : variant, s);
+                        if (rc != PG_OK) return rc;
+                        return by_mid ? pg_gemm_mid_launch(dtype, g, epi, s, (int)m_main) : pg_gemm_tail_launch(dtype, g, epi, (int)m_main, s);
+                    }
                 }
             }
         }

@@ -58,7 +58,7 @@ int pg_gemm_tail_launch(int dtype, GemmArgs g, int epi, int m_begin, hipStream_t
 // gemm_mid.hip (round 6): a whole problem in 128 x 128 one-tile-per-block tiles through a 3-stage LDS ring, bit-identical to the
 // persistent kernels (variant 71 forces it; pg_gemm_launch picks it for batches too small to fill the persistent kernels' first round)
 bool pg_gemm_mid_supported(int epi, int N, int K);
-int pg_gemm_mid_launch(int dtype, GemmArgs g, int epi, hipStream_t s);
+int pg_gemm_mid_launch(int dtype, GemmArgs g, int epi, hipStream_t s, int m_begin = 0);
 
 // Tools build only: wall-clock stamps (100 MHz) from inside the persistent kernels, blocks 0 and 100, every wave, first 16 tiles:
 // buf[((blk * 16 + tile) * 8 + wave) * 12 + slot].  Armed by pg_dbg_timestamps(buf) (gemm_bf16.hip), read by tools/epi_timeline.py.

@@ -242,9 +242,23 @@ bool pg_gemm_mid_supported(int epi, int N, int K) {
     return epi != EPI_PATCH && epi >= EPI_QKV && epi <= EPI_GELU_LN && N % MD_BN == 0 && K % BK == 0 && K >= BK;
 }
 
-int pg_gemm_mid_launch(int dtype, GemmArgs g, int epi, hipStream_t s) {
+// rows [m_begin, g.M) of the problem; every pointer in g is that of row 0 (m_begin > 0: the rows a persistent launch left over,
+// pg_gemm_launch's tail split)
+int pg_gemm_mid_launch(int dtype, GemmArgs g, int epi, hipStream_t s, int m_begin) {
     if (!pg_gemm_mid_supported(epi, g.N, g.K)) { pg_set_error("gemm_mid: unsupported epilogue / shape (epi=%d N=%d K=%d)", epi, g.N, g.K); return PG_EINVAL; }
     if (g.ex.parts > 1) { pg_set_error("gemm_mid: several products in one launch exist in gemm_pp.hip only"); return PG_EINVAL; }
+    if (m_begin < 0 || m_begin >= g.M) return m_begin == g.M ? PG_OK : (pg_set_error("gemm_mid: m_begin = %d outside [0, %d)", m_begin, g.M), PG_EINVAL);
+    if (m_begin > 0) {
+        // the kernel indexes every row-major buffer by the row number: move the bases instead of teaching it an offset
+        const bool out16 = epi == EPI_QKV || epi == EPI_GELU || epi == EPI_QKV_LN || epi == EPI_GELU_LN;
+        if (g.ex.stat_rows <= 0) g.ex.stat_rows = g.M;       // the slices of statpart keep the stride of the WHOLE problem
+        g.A += (int64_t)m_begin * g.lda;
+        g.out = (char*)g.out + (int64_t)m_begin * g.ldc * (out16 ? 2 : 4);
+        if (g.ex.rowstat) g.ex.rowstat += (int64_t)m_begin * 2;
+        if (g.ex.x16) g.ex.x16 = (uint16_t*)g.ex.x16 + (int64_t)m_begin * g.ldc;
+        if (g.ex.statpart) g.ex.statpart += (int64_t)m_begin * 2;
+        g.M -= m_begin;
+    }
     if ((int64_t)g.lda * 2 * MD_BM >= (1ll << 31) || (int64_t)g.ldw * 2 * MD_BN >= (1ll << 31)) {
         pg_set_error("gemm_mid: operand panel exceeds the 2 GB buffer-descriptor range");
         return PG_EINVAL;

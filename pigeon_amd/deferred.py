@@ -12,8 +12,11 @@ for 1.8 % of the work.  Here
     (pg_requeue_append + pg_rows_to_slots); the queue's running count reaches the host ONE STEP LATE through pinned memory and an event
     the GPU passed a whole step ago -- the launch thread never waits for the step it has just queued;
   * when the longest queue of any rank holds `min_flush` panoramas (or a step has waited `max_lag` steps, or at `flush()`), the exact
-    tier runs ONCE over the queued rows -- 40+ images, a batch size at which its GEMMs fill the chip -- and its results are scattered
-    into the ring (pg_scatter_rows), judged again at the exact tier's floor;
+    tier runs ONCE over queued rows and its results are scattered into the ring (pg_scatter_rows), judged again at the exact tier's
+    floor.  A pass takes a whole number of `pass_quantum`s from the head of the queue and leaves the rest for the next one: the exact
+    encoder's GEMMs work in 256-row panels, 64 of which (x 4 column tiles at N = 1024) are one round of the 256 CUs -- 16 384 rows = 28
+    images = 7 panoramas.  Measured (profiles/r06/exact_sweep.txt): 28 / 56 / 84 / 112 images cost 1.19-1.21 ms per image, 32-44
+    images 1.32-1.40, 60 images 1.33: a pass of "whatever is queued" (10-12 panoramas) pays for rounds it leaves half empty;
   * a step is handed out only when all its rows are settled.  The reference's loops collect at the end
     (training/train_eval_loop.py:98-112, preprocessing/embed.py:36-43): handing results out a few steps late changes nothing for them.
 
@@ -51,16 +54,21 @@ class LocalComm:
 
 
 class DeferredExact:
-    def __init__(self, model, refiner=None, comm=None, ops=None, min_flush: int = 10, max_lag: int = 12, immediate: bool = False,
-                 keep_logits: bool = True):
-        """min_flush: queued panoramas (on the rank with the longest queue) that trigger an exact pass; max_lag: steps a queued row may
-        wait; immediate: settle every step before `submit` returns (one host synchronisation per step: the serving / single-call
-        form).  keep_logits: carry the (B, C) logits through the ring (the loss `package` computes needs them)."""
+    def __init__(self, model, refiner=None, comm=None, ops=None, min_flush: Optional[int] = None, max_lag: int = 12,
+                 immediate: bool = False, keep_logits: bool = True, pass_quantum: Optional[int] = None):
+        """min_flush: queued panoramas (on the rank with the longest queue) that trigger an exact pass (None: one quantum, or 10 where
+        there is no quantum); max_lag: steps a queued row may wait; immediate: settle every step before `submit` returns (one host
+        synchronisation per step: the serving / single-call form).  keep_logits: carry the (B, C) logits through the ring (the loss
+        `package` computes needs them).  pass_quantum: rows a min_flush pass takes are a multiple of it (0: everything queued; None:
+        what fills one round of the device's CUs with the exact encoder's 256-row panels -- `round_quantum`, known at the first
+        step with pixels)."""
         if ops is None:
             from . import hip_ops as ops
         self.model, self.refiner, self.ops = model, refiner, ops
         self.comm = comm if comm is not None else LocalComm()
-        self.min_flush, self.max_lag, self.immediate = int(min_flush), int(max_lag), bool(immediate)
+        self._min_flush_arg, self.max_lag, self.immediate = min_flush, int(max_lag), bool(immediate)
+        self.pass_quantum = pass_quantum if pass_quantum is None else int(pass_quantum)
+        self.min_flush = int(min_flush) if min_flush is not None else (self.pass_quantum or 10)
         self.keep_logits = bool(keep_logits)
         self.R = (2 if immediate else self.max_lag + 4)
         self.ring: Optional[Dict[str, torch.Tensor]] = None
@@ -118,6 +126,10 @@ class DeferredExact:
         self.px_shape = None
 
     def _alloc_queue(self, px_rows: torch.Tensor):
+        if self.pass_quantum is None:
+            self.pass_quantum = round_quantum(px_rows)
+            if self._min_flush_arg is None:
+                self.min_flush = self.pass_quantum or 10
         self.cap = (self.B if self.immediate else self.min_flush + 2 * self.B)
         self.q_pixels = torch.zeros((self.cap,) + tuple(px_rows.shape[1:]), dtype=px_rows.dtype, device=px_rows.device)
         self.slot_dst = torch.zeros((self.cap,), dtype=torch.int64, device=px_rows.device)
@@ -292,8 +304,12 @@ class DeferredExact:
             if max(lens) > 0:
                 first_waiting = next((r for r in known if any(a > f for a, f in zip(r['appended'], self.flushed))), None)
                 waited = last - first_waiting['step'] if first_waiting is not None else 0
-                if final or self.immediate or max(lens) >= self.min_flush or waited >= self.max_lag:
+                if final or self.immediate or waited >= self.max_lag:
                     self._exact_pass(lens, at_step=last)
+                elif max(lens) >= self.min_flush:
+                    q = self.pass_quantum or 0
+                    take = (max(lens) // q) * q if q and max(lens) >= q else max(lens)
+                    self._exact_pass([min(n, take) for n in lens], at_step=last)   # the head of every queue; the rest waits
         done = []
         while self.pending and self.pending[0]['appended'] is not None and \
                 all(f >= a for a, f in zip(self.pending[0]['appended'], self.flushed)):
@@ -302,6 +318,7 @@ class DeferredExact:
 
     @torch.no_grad()
     def _exact_pass(self, lens: List[int], at_step: int):
+        """One exact pass over the first lens[r] queued rows of every rank r (every rank runs max(lens) slots)."""
         model, comm, ops = self.model, self.comm, self.ops
         rank, W = comm.rank, comm.world_size
         n_own, n_pad = lens[rank], max(lens)
@@ -383,9 +400,21 @@ class DeferredExact:
         return int(self.counters[1].item()) if self.ring is not None else 0
 
 
+def round_quantum(px_rows: torch.Tensor, tokens: int = 577, panel_rows: int = 256, n_tiles: int = 4) -> int:
+    """Queue rows (panoramas, or single images) whose token rows fill ONE round of the device's CUs with the exact encoder's 256-row
+    panels at N = 1024 (pg_vit_forward_precise runs the 256 x 256 persistent kernel: 4 column tiles per panel): 256 CUs -> 64 panels =
+    16 384 token rows = 28 images = 7 four-view panoramas.  0 (no quantum) off the GPU."""
+    if px_rows.device.type != 'cuda':
+        return 0
+    cus = torch.cuda.get_device_properties(px_rows.device).multi_processor_count
+    images = (cus // n_tiles) * panel_rows // tokens
+    views = max(1, int(px_rows.shape[1]) // (3 * 336 * 336))
+    return max(1, images // views)
+
+
 def as_model_output(model, res: dict, labels=None, labels_clf=None):
     """One emitted result -> what `SuperGuessr.forward` returns for this rank's rows (ModelOutput or the serving tuple)."""
     return model.package(dict(res['state']), labels, labels_clf)
 
 
-__all__ = ['DeferredExact', 'LocalComm', 'as_model_output', 'TopK']
+__all__ = ['DeferredExact', 'LocalComm', 'as_model_output', 'round_quantum', 'TopK']

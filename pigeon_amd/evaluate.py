@@ -256,16 +256,18 @@ class PanoramaPipeline:
     ...)` puts them back in sample order.
 
     Round 6: the step is `pigeon_amd.deferred.DeferredExact.submit` -- no host synchronisation, the rows the 16-bit encoder cannot
-    settle wait in a device queue for ONE exact pass per ~`min_flush` panoramas, taken by every rank in the same step on the same
+    settle wait in a device queue for ONE exact pass per `min_flush` panoramas (default: what fills one round of the CUs with the
+    exact encoder's panels -- 7 panoramas on 256 CUs, `deferred.round_quantum`), taken by every rank in the same step on the same
     number of slots.  `submit` returns the steps that became final (a few steps late, in order), `flush` the rest; `step` = submit +
     flush (settled before it returns: the form tests, `smoke()` and single calls use)."""
 
     def __init__(self, model: SuperGuessr, refiner: Optional[ProtoRefiner], comm: Optional[Communicator] = None,
-                 min_flush: int = 10, max_lag: int = 12, ops=None):
+                 min_flush: Optional[int] = None, max_lag: int = 12, ops=None, pass_quantum: Optional[int] = None):
         from .deferred import DeferredExact
         self.model, self.refiner = model, refiner
         self.comm = comm or Communicator()
-        self.engine = DeferredExact(model, refiner, self.comm, ops=ops, min_flush=min_flush, max_lag=max_lag)
+        self.engine = DeferredExact(model, refiner, self.comm, ops=ops, min_flush=min_flush, max_lag=max_lag,
+                                    pass_quantum=pass_quantum)
         self.last_info = None            # of the newest result handed out: certain, cause, exact, queued
 
     @property

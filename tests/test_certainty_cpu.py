@@ -256,6 +256,41 @@ def test_deferred_engine_equals_settling_every_step():
     assert any(bool(r["exact"].any()) for r in later.values()) and any(not bool(r["exact"].all()) for r in later.values())
 
 
+def test_deferred_engine_pass_quantum_takes_whole_rounds_and_leaves_the_rest_queued():
+    """With a pass quantum a min_flush pass takes a whole number of quanta from the HEAD of the queue (the size at which the exact
+    encoder's row panels fill whole rounds of the CUs: pigeon_amd.deferred.round_quantum) and leaves the rest for the next pass;
+    what is handed out is still, bit for bit, what settling every step gives -- in order, each step once, nothing dropped."""
+    from _scripted import make_pixels
+    g = torch.Generator().manual_seed(11)
+    steps = []
+    for i in range(18):
+        flags = lambda p: (torch.rand(6, generator=g) > p).float().tolist()        # noqa: E731
+        steps.append(make_pixels(flags(0.3), flags(0.15), flags(0.2), flags(0.1), seed=300 + i))
+    now, order_now, _, _, m_now = _run_engine(steps, immediate=True)
+    later, order, lag, eng, m = _run_engine(steps, min_flush=3, max_lag=8, pass_quantum=3)
+    assert order == order_now == list(range(18)) and eng.check_nothing_dropped() == 0
+    for i in range(18):
+        for k in now[i]:
+            if torch.is_tensor(now[i][k]):
+                assert torch.equal(now[i][k], later[i][k]), (i, k)
+        for k in now[i]["state"]:
+            if torch.is_tensor(now[i]["state"][k]):
+                assert torch.equal(now[i]["state"][k], later[i]["state"][k]), (i, "state", k)
+    sizes = [n for _, n in m.calls]
+    assert sum(sizes) == sum(n for _, n in m_now.calls) and eng.cap == 3 + 2 * 6
+    # every pass but the closing flush (and a max_lag one, which takes everything) is a whole number of quanta; some pass left rows behind
+    assert all(n % 3 == 0 for n in sizes[:-1]) and len(sizes) >= 4
+    assert max(lag) <= 8 + 1
+    # default (no quantum off the GPU): min_flush falls back to 10 and a pass takes all that is queued
+    _, _, _, eng0, _ = _run_engine(steps[:3])
+    assert eng0.pass_quantum == 0 and eng0.min_flush == 10
+    # min_flush below the quantum: a pass that cannot fill one quantum takes what there is
+    later2, order2, _, eng2, m2 = _run_engine(steps, min_flush=2, max_lag=8, pass_quantum=5)
+    assert order2 == list(range(18)) and sum(n for _, n in m2.calls) == sum(sizes)
+    for i in range(18):
+        assert torch.equal(now[i]["embedding"], later2[i]["embedding"]) and torch.equal(now[i]["refined_geocell"], later2[i]["refined_geocell"])
+
+
 def test_deferred_engine_max_lag_and_queue_wrap():
     """A single uncertain row does not wait forever (max_lag), and the circular queue wraps without losing or mixing rows."""
     from _scripted import make_pixels

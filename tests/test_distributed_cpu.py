@@ -89,7 +89,7 @@ def _worker(rank, world, port, outdir):
     from pigeon_amd.evaluate import PanoramaPipeline
     B = 3
     model, refiner = ScriptedModel(), ScriptedRefiner()
-    pipe = PanoramaPipeline(model, refiner, comm, min_flush=3, max_lag=4, ops=requeue_oracle)
+    pipe = PanoramaPipeline(model, refiner, comm, min_flush=3, max_lag=4, ops=requeue_oracle, pass_quantum=2)   # passes of 2, 4 .. slots; the rest stays queued
     index = torch.arange(B) * world + rank                                   # interleaved sample ids, as a sharded loader gives
 
     def pixels(r, i):
@@ -110,6 +110,7 @@ def _worker(rank, world, port, outdir):
     torch.distributed.all_gather_object(logs, log)
     assert logs[0] == logs[1] and len(log) >= 2                               # same steps, same queue view, same slots on both ranks
     assert all(slots == max(q) for _, q, slots in log) and any(q[0] != q[1] for _, q, _ in log)
+    assert all(slots % 2 == 0 for _, _, slots in log[:-1])                    # whole quanta, except the closing flush
     assert [n for _, n in model.calls] == [slots for _, _, slots in log]       # the exact tier ran on the PADDED size on this rank too
     for i in range(n_steps):
         res = got[i]

@@ -194,24 +194,30 @@ def test_gemm_mid_kernel_bit_identical_to_persistent(env, dt):
 
 def test_gemm_tail_split_changes_nothing(env):
     """pg_gemm_launch cuts a problem whose tiles do not fill the persistent kernel's last round: whole rounds to the persistent
-    kernel, the few rows beyond them to gemm_tail.hip.  With the split switched off (tail rows 0) the same call must give the
-    same bits -- 256-row tiles (N = 1024: 264 tiles on 256 CUs -> 16384 + 300 rows) and 384-row tiles (N = 3072: 528 tiles ->
-    16128 + 556 rows)."""
+    kernel, the few rows beyond them to a small-tile kernel -- gemm_mid.hip where its model says it is the cheaper one (round 6: every
+    K = 1024 GEMM of the model), gemm_tail.hip otherwise (fc2's K = 4096) or when gemm_mid is switched off.  With the split switched
+    off (tail rows 0) the same call must give the same bits -- 256-row tiles (N = 1024: 264 tiles on 256 CUs -> 16384 + 300 rows) and
+    384-row tiles (N = 3072: 528 tiles -> 16128 + 556 rows), every epilogue (the residual + statistics one writes three row-indexed
+    buffers through the moved bases), guard rows untouched."""
     ops, L = env["ops"], env["lib"]
-    M, K = 64 * 256 + 300, 256
+    M = 64 * 256 + 300
     try:
-        ops.tune_gemm_tail_shape(0, 0)                       # the product default splits only K >= 2048 or N >= 4096 (where it pays)
-        for N, variant in ((1024, 36), (3072, 56)):
-            A, W, bias, X0, cs, rs = _tail_problem(M, N, K, 22 + N)
-            ops.tune_gemm_tail_rows(0)
-            ref = _gemm_all_epilogues(ops, L, A, W, bias, X0, cs, rs, M, variant)
-            ops.tune_gemm_tail_rows(768)
-            got = _gemm_all_epilogues(ops, L, A, W, bias, X0, cs, rs, M, variant)
-            for i, (a, b) in enumerate(zip(ref, got)):
-                assert torch.equal(a, b), (N, variant, i)
-            for o in got[:4]:
-                assert bool((o[M:].float() == 7.0).all())
+        ops.tune_gemm_tail_shape(0, 0)                       # gemm_tail.hip for every shape gemm_mid.hip does not take
+        for K in (256, 1024):
+            for N, variant in ((1024, 36), (3072, 56)):
+                A, W, bias, X0, cs, rs = _tail_problem(M, N, K, 22 + N + K)
+                ops.tune_gemm_tail_rows(0)
+                ref = _gemm_all_epilogues(ops, L, A, W, bias, X0, cs, rs, M, variant)
+                ops.tune_gemm_tail_rows(768)
+                for mid in (1, 0):
+                    ops.tune_gemm_mid(mid)
+                    got = _gemm_all_epilogues(ops, L, A, W, bias, X0, cs, rs, M, variant)
+                    for i, (a, b) in enumerate(zip(ref, got)):
+                        assert torch.equal(a, b), (N, K, variant, mid, i)
+                    for o in got[:4]:
+                        assert bool((o[M:].float() == 7.0).all())
     finally:
+        ops.tune_gemm_mid(1)
         ops.tune_gemm_tail_rows(768)
         ops.tune_gemm_tail_shape(2048, 4096)
 
