@@ -158,6 +158,10 @@ int pg_tune_exact_attention(int use_f32_mfma);
  * weights' rounding, a systematic embedding error the same for every image up to its dependence on the activations; 2/3 of the GEMM
  * work.  Process-wide; anything else is PG_EINVAL. */
 int pg_tune_exact_products(int n);
+/* Exact mode's activation splits (round 6; also env PIGEON_EXACT_FUSION=0): 1 = fused into their producers (default: the attention writes
+ * the split-fp16 triple the out-projection reads, fc1's epilogue applies QuickGELU and writes the triple fc2 reads -- csrc/x3.h holds
+ * the one definition of both forms' arithmetic), 0 = an fp32 buffer plus a split kernel each (the checker).  Bit-identical results. */
+int pg_tune_exact_fusion(int on);
 int pg_vit_saturation_check(pg_vit* h, int on);
 int pg_vit_saturation_read(pg_vit* h, int64_t* count, int reset);
 /* Always-on range alarm of the fp16 operand path (no scan, no cost worth naming): the kernel that turns the residual GEMMs' row

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PIGEON_HIP_LIB") or os.path.join(_HERE, "libpigeon_hip.so")
 
 PG_DTYPE_F32, PG_DTYPE_BF16, PG_DTYPE_F16, PG_DTYPE_F64 = 0, 1, 2, 3
-EPI_QKV, EPI_GELU, EPI_RESID, EPI_PATCH, EPI_F32, EPI_RESID_STAT, EPI_QKV_LN, EPI_GELU_LN = 0, 1, 2, 3, 4, 5, 6, 7
+EPI_QKV, EPI_GELU, EPI_RESID, EPI_PATCH, EPI_F32, EPI_RESID_STAT, EPI_QKV_LN, EPI_GELU_LN, EPI_GELU_X3 = 0, 1, 2, 3, 4, 5, 6, 7, 8
 PROF_CLASSES = ["gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2", "gemm_patch", "attention", "layernorm",
                 "im2col", "token_mean"]
 
@@ -59,6 +59,7 @@ SIGNATURES = {
     "pg_tune_gemm_mid": (_I, [_I]),
     "pg_tune_exact_attention": (_I, [_I]),
     "pg_tune_exact_products": (_I, [_I]),
+    "pg_tune_exact_fusion": (_I, [_I]),
     "pg_vit_saturation_check": (_I, [_P, _I]),
     "pg_vit_saturation_read": (_I, [_P, C.POINTER(_I64), _I]),
     "pg_vit_range_alarm_read": (_I, [_P, C.POINTER(_I64), _I]),

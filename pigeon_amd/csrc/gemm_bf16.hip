@@ -505,6 +505,12 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
     if (epi == EPI_RESID_STAT && (!g.ex.x16 || !g.ex.statpart || g.ex.ldx != ldc)) { pg_set_error("gemm: EPI_RESID_STAT needs x16 / statpart and ldx == ldc"); return PG_EINVAL; }
     if ((epi == EPI_QKV_LN || epi == EPI_GELU_LN) && (!g.ex.colsum || !g.ex.rowstat)) { pg_set_error("gemm: LN epilogue needs colsum / rowstat"); return PG_EINVAL; }
     if (epi == EPI_PATCH && !aux) { pg_set_error("gemm: patch epilogue needs aux"); return PG_EINVAL; }
+    if (epi == EPI_GELU_X3 && (ldc != 3 * (int64_t)N || dtype != PG_DTYPE_F16 || N % 256 != 0 || K % 128 != 0)) {
+        pg_set_error("gemm: EPI_GELU_X3 writes the fp16 triple [M][3N]: ldc == 3 N, fp16 operands, N %% 256 == 0, K %% 128 == 0 (ldc=%lld N=%d K=%d)",
+                     (long long)ldc, N, K);
+        return PG_EINVAL;
+    }
+    if (epi < EPI_QKV || epi > EPI_GELU_X3) { pg_set_error("gemm: bad epilogue %d", epi); return PG_EINVAL; }
     if ((lda % 8) || (ldc % 8) || (qcols % 8) || (g.ldw % 8) || g.ldw < K) { pg_set_error("gemm: lda/ldw/ldc/qcols must be multiples of 8, ldw >= K"); return PG_EINVAL; }
     if (variant == 0) variant = pg_default_gemm_variant();
     {

@@ -33,6 +33,8 @@
 //        DMA into it is group 0's LOAD(4t), after B_8t.
 //   Both groups execute 2S+2 barriers per tile (group 1: one extra after B_0, group 0: one extra at the end).
 #include "gemm_epi.h"
+#include "x3.h"
+#include <type_traits>
 
 namespace {
 
@@ -462,8 +464,9 @@ __device__ __forceinline__ void pp_epilogue(AccPP& acc, const GemmArgs& g, char*
     constexpr bool STAT = (EPI == EPI_RESID_STAT);
     constexpr bool RESID = (EPI == EPI_RESID || EPI == EPI_RESID_STAT);
     constexpr bool WIDE = epi_wide<EPI>();
+    constexpr bool X3 = (EPI == EPI_GELU_X3);                // fp16 triple [M][3N]: 4 columns per lane like EPI_F32, three 8-byte stores
     constexpr int ROWPF = PP_SLAB_ROWF;
-    constexpr int ESZ = OUT16 ? 2 : 4;
+    constexpr int ESZ = (OUT16 || X3) ? 2 : 4;
     constexpr int CPL = WIDE ? 8 : 4;                        // columns per lane on the row-major side
     constexpr int LPR = 64 / CPL, RPI = 64 / LPR, ITS = 32 / RPI;
     const int l15 = lane & 15, lq = lane >> 4;               // MFMA side: row inside a 16-row block, column quad
@@ -504,7 +507,8 @@ __device__ __forceinline__ void pp_epilogue(AccPP& acc, const GemmArgs& g, char*
         // no per-store 64-bit address arithmetic: voffset is one VGPR, the slab/iteration row offset is an SGPR.
         int rv = g.M - row0; rv = rv < 0 ? 0 : (rv > 128 ? 128 : rv);
         rv = __builtin_amdgcn_readfirstlane(rv);   // descriptor stays in SGPRs (hipcc clamps with v_med3_i32, see gemm_pp6.hip rowstat_rsrc6)
-        const uint32_t nbytes = rv > 0 ? (uint32_t)(((int64_t)(rv - 1) * g.ldc + 64) * ESZ) : 0u;
+        // (EPI_GELU_X3: a row's three pieces sit N fp16 elements apart -- the range reaches 2N past the lane's first piece)
+        const uint32_t nbytes = rv > 0 ? (uint32_t)(((int64_t)(rv - 1) * g.ldc + 64 + (X3 ? 2 * g.N : 0)) * ESZ) : 0u;
         __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)g.out + ((int64_t)row0 * g.ldc + col0) * ESZ, nbytes);
         const int voff = (rr * (int)g.ldc + cc) * ESZ;
         int rstep = RPI * (int)g.ldc * ESZ;                  // bytes between two store iterations
@@ -608,6 +612,16 @@ __device__ __forceinline__ void pp_epilogue(AccPP& acc, const GemmArgs& g, char*
                         s2 = row8_sum(s2);
                         if ((lane & 7) == 0) { slab[r * ROWPF + 64] = s1; slab[r * ROWPF + 65] = s2; }
                     }
+                } else if constexpr (X3) {                   // EPI_GELU_X3: split_x3_kernel<true>'s arithmetic on (acc + bias)
+                    f32x4 v = lo + bias.lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = x3_quick_gelu(v[e]);
+                    u32x2 ph, pl, ps;
+                    x3_pack4(v, ph, pl, ps);
+                    const int nb = g.N * 2;                  // bytes between the pieces of a row
+                    __builtin_amdgcn_raw_buffer_store_b64(ph, ro, ooff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(pl, ro, ooff + nb, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(ps, ro, ooff + 2 * nb, 0, 0);
                 } else {                                     // EPI_F32
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo + bias.lo), ro, ooff, 0, 0);
                 }
@@ -684,7 +698,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     // stores are still draining to HBM underneath the first K tile.  (The patch epilogue skips stores of out-of-range
     // waves, so its count is not static: full drain.)
     // (EPI_RESID_STAT issues more; 16 is a safe lower bound.  The LN epilogues prefetch after slab 0: 12 stores follow.)
-    constexpr int NST = (EPI == EPI_PATCH) ? 0 : (EPI == EPI_F32 ? 32 : (epi_ln<EPI>() ? 12 : 16));
+    // (EPI_GELU_X3 issues 96; vmcnt counts to 63)
+    constexpr int NST = (EPI == EPI_PATCH) ? 0 : (EPI == EPI_F32 ? 32 : (EPI == EPI_GELU_X3 ? 63 : (epi_ln<EPI>() ? 12 : 16)));
     bool first = true;
     int dbg_iter = 0;                                        // tile counter of the tools build's time stamps (dead code otherwise)
 
@@ -805,9 +820,14 @@ int launch_pp_epi(const GemmArgs& g, int epi, int nblk, hipStream_t s) {
             case EPI_RESID: return launch_pp<T, EPI_RESID, MODE, D0, D1, D2, 0>(g, nblk, s);
             case EPI_PATCH: return launch_pp<T, EPI_PATCH, MODE, D0, D1, D2, 0>(g, nblk, s);
             case EPI_F32: return launch_pp<T, EPI_F32, MODE, D0, D1, D2, 0>(g, nblk, s);
-            case EPI_RESID_STAT: case EPI_QKV_LN: case EPI_GELU_LN:
-                // the LayerNorm-fold epilogues are built only for the production schedule (ping-pong, DMA 4/4/0/0)
+            case EPI_RESID_STAT: case EPI_QKV_LN: case EPI_GELU_LN: case EPI_GELU_X3:
+                // the LayerNorm-fold epilogues (and the exact mode's fused fc1 epilogue) are built only for the production schedule
+                // (ping-pong, DMA 4/4/0/0)
                 if constexpr (MODE == 1 && D0 == 4 && D1 == 4 && D2 == 0) {
+                    if (epi == EPI_GELU_X3) {
+                        if constexpr (std::is_same<T, T_F16>::value) return launch_pp<T, EPI_GELU_X3, MODE, D0, D1, D2, 0>(g, nblk, s);
+                        else { pg_set_error("gemm_pp: EPI_GELU_X3 exists for fp16 operands only (the exact mode)"); return PG_EINVAL; }
+                    }
                     if (epi == EPI_RESID_STAT) return launch_pp<T, EPI_RESID_STAT, MODE, D0, D1, D2, 0>(g, nblk, s);
                     if (epi == EPI_QKV_LN) return launch_pp<T, EPI_QKV_LN, MODE, D0, D1, D2, 0>(g, nblk, s);
                     return launch_pp<T, EPI_GELU_LN, MODE, D0, D1, D2, 0>(g, nblk, s);

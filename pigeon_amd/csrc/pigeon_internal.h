@@ -9,7 +9,11 @@
 //                   operand) and per-(row, 64-column slice) partial sums / sums of squares for the row statistics;
 //   EPI_QKV_LN / EPI_GELU_LN  out = epi(rstd[m] * acc - (mean*rstd)[m] * colsum[n] + bias[n]) where the weight already
 //                   carries gamma and bias carries beta.W^T + b.
-enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_F32 = 4, EPI_RESID_STAT = 5, EPI_QKV_LN = 6, EPI_GELU_LN = 7 };
+// 8 (round 6, gemm_pp.hip's 256 x 256 kernel only; the exact mode's fc1):
+//   EPI_GELU_X3     out = the split-fp16 triple [M][3N] (ldc = 3N fp16 elements) of QuickGELU(acc + bias) with the accurate expf / IEEE
+//                   division: what EPI_F32 followed by split_x3_kernel<true> (precise.hip) writes, bit for bit, without the fp32 round trip.
+enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PATCH = 3, EPI_F32 = 4, EPI_RESID_STAT = 5, EPI_QKV_LN = 6, EPI_GELU_LN = 7,
+       EPI_GELU_X3 = 8 };
 
 struct PgGemmExtra {
     const float* colsum = nullptr;     // [N]   EPI_*_LN: row sums of the (rounded) gamma-folded weight
@@ -70,4 +74,6 @@ int pg_x3_ln_launch(const float* x, const float* gamma, const float* beta, void*
 int pg_x3_split_launch(const float* x, void* y3, int64_t rows, int C, int gelu, hipStream_t s);
 int pg_x3_im2col_launch(const void* pixels, int pix_dtype, void* out3, int n_images, hipStream_t s);
 int pg_attention_f32_launch(const float* qkv, float* out, int n_images, hipStream_t s);
+bool pg_attention_x3out_available();
+int pg_attention_x3out_launch(const float* qkv, void* out3, int n_images, hipStream_t s);
 int pg_sum_parts_launch(const float* parts, int S, int64_t part_elems, float* dst, int64_t n, int resid, hipStream_t s);

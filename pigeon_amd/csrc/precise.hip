@@ -22,30 +22,8 @@
 //   attention_x3_kernel / attention_f32_kernel  fp32 QKV [M][3072] -> fp32 O [M][1024], softmax(q k^T / 8) v per (image, head)
 #include "common.h"
 #include "pigeon_internal.h"
+#include "x3.h"
 #include <cstdlib>
-
-#define X3_SHIFT_DOWN 0.00390625f          // 2^-8 on the activation side ...
-#define X3_SHIFT_UP 256.0f                 // ... 2^8 on the weight side (vit.hip packs the weights with it)
-
-struct X3 { uint16_t hi, lo, hs; };
-__device__ __forceinline__ X3 x3_split(float v) {
-    X3 r;
-    r.hi = f32_to_f16_bits(v);                                   // RNE, saturating at +-65504
-    const float hf = f16_bits_to_f32(r.hi);
-    r.lo = __builtin_bit_cast(uint16_t, (_Float16)(v - hf));     // exact difference, |lo| <= ulp16(v) / 2
-    r.hs = __builtin_bit_cast(uint16_t, (_Float16)(hf * X3_SHIFT_DOWN));
-    return r;
-}
-// 4 consecutive columns c..c+3 of logical width C -> the three 8-byte pieces of the triple row
-__device__ __forceinline__ void x3_store4(uint16_t* row, int C, int c, const f32x4& v) {
-    X3 a = x3_split(v[0]), b = x3_split(v[1]), d = x3_split(v[2]), e = x3_split(v[3]);
-    u32x2 hi = {(uint32_t)a.hi | ((uint32_t)b.hi << 16), (uint32_t)d.hi | ((uint32_t)e.hi << 16)};
-    u32x2 lo = {(uint32_t)a.lo | ((uint32_t)b.lo << 16), (uint32_t)d.lo | ((uint32_t)e.lo << 16)};
-    u32x2 hs = {(uint32_t)a.hs | ((uint32_t)b.hs << 16), (uint32_t)d.hs | ((uint32_t)e.hs << 16)};
-    *(u32x2*)(row + c) = hi;
-    *(u32x2*)(row + C + c) = lo;
-    *(u32x2*)(row + 2 * C + c) = hs;
-}
 
 // ---- LayerNorm -> triple; one wave per 1024-float row (layernorm_kernel's arithmetic, rowops.hip) ------------------------------
 __global__ __launch_bounds__(256) void ln_x3_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -96,7 +74,7 @@ __global__ __launch_bounds__(256) void split_x3_kernel(const float* __restrict__
         f32x4 v = *(const f32x4*)(x + r * C + c);
         if (GELU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-1.702f * v[e]));
+            for (int e = 0; e < 4; ++e) v[e] = x3_quick_gelu(v[e]);
         }
         x3_store4(y + r * (3 * (int64_t)C), C, c, v);
     }
@@ -305,6 +283,10 @@ __device__ __forceinline__ int ax_pos_of(int key) {         // position of tile-
     return (key & 16) + ((w >> 2) & 1) * 8 + (w >> 3) * 4 + (w & 3);
 }
 
+// X3OUT (round 6): the output row is written as the split-fp16 triple the out-projection GEMM reads ([M][3 * 1024] fp16 through
+// x3_store4: what split_x3_kernel would make of the fp32 row, bit for bit) instead of fp32 -- one launch and one fp32 round trip less
+// per layer.
+template <bool X3OUT>
 __global__ __launch_bounds__(256, 3) void attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n_images) {
     __shared__ __attribute__((aligned(16))) _Float16 Kh[2][32 * AX_KS];
     __shared__ __attribute__((aligned(16))) _Float16 Kl[2][32 * AX_KS];
@@ -437,12 +419,19 @@ __global__ __launch_bounds__(256, 3) void attention_x3_kernel(const float* __res
     if (!q_ok) return;
     lsum += __shfl_xor(lsum, 32, 64);
     float* op = out + (row0 + q) * VIT_HIDDEN + head * VIT_HEAD_DIM + 4 * half;
+    uint16_t* op3 = (uint16_t*)out + (row0 + q) * (3 * VIT_HIDDEN);
+    const int c0 = head * VIT_HEAD_DIM + 4 * half;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         f32x4 a = {o0[4 * j] / lsum, o0[4 * j + 1] / lsum, o0[4 * j + 2] / lsum, o0[4 * j + 3] / lsum};
         f32x4 b = {o1[4 * j] / lsum, o1[4 * j + 1] / lsum, o1[4 * j + 2] / lsum, o1[4 * j + 3] / lsum};
-        *(f32x4*)(op + 8 * j) = a;
-        *(f32x4*)(op + 32 + 8 * j) = b;
+        if constexpr (X3OUT) {
+            x3_store4(op3, VIT_HIDDEN, c0 + 8 * j, a);
+            x3_store4(op3, VIT_HIDDEN, c0 + 32 + 8 * j, b);
+        } else {
+            *(f32x4*)(op + 8 * j) = a;
+            *(f32x4*)(op + 32 + 8 * j) = b;
+        }
     }
 }
 
@@ -452,10 +441,22 @@ extern "C" int pg_tune_exact_attention(int use_f32_mfma) {
     g_exact_attn_f32 = use_f32_mfma ? 1 : 0;
     return PG_OK;
 }
+static bool exact_attn_f32() {
+    if (g_exact_attn_f32 < 0) { const char* e = getenv("PIGEON_EXACT_ATTN"); g_exact_attn_f32 = (e && e[0] == 'f') ? 1 : 0; }
+    return g_exact_attn_f32 != 0;
+}
 int pg_attention_f32_launch(const float* qkv, float* out, int n_images, hipStream_t s) {
     if (n_images <= 0) return PG_OK;
-    if (g_exact_attn_f32 < 0) { const char* e = getenv("PIGEON_EXACT_ATTN"); g_exact_attn_f32 = (e && e[0] == 'f') ? 1 : 0; }
-    if (g_exact_attn_f32) hipLaunchKernelGGL(attention_f32_kernel, dim3(n_images * VIT_HEADS * 5), dim3(256), 0, s, qkv, out, n_images);
-    else hipLaunchKernelGGL(attention_x3_kernel, dim3(n_images * VIT_HEADS * 5), dim3(256), 0, s, qkv, out, n_images);
+    if (exact_attn_f32()) hipLaunchKernelGGL(attention_f32_kernel, dim3(n_images * VIT_HEADS * 5), dim3(256), 0, s, qkv, out, n_images);
+    else hipLaunchKernelGGL(attention_x3_kernel<false>, dim3(n_images * VIT_HEADS * 5), dim3(256), 0, s, qkv, out, n_images);
     return pg_check_launch("attention_f32");
+}
+// the same attention with the output written as the triple [M][3 * 1024] fp16 (attention_x3_kernel<true>); not available with the
+// fp32-MFMA A/B arm selected -- the caller then runs pg_attention_f32_launch + pg_x3_split_launch
+bool pg_attention_x3out_available() { return !exact_attn_f32(); }
+int pg_attention_x3out_launch(const float* qkv, void* out3, int n_images, hipStream_t s) {
+    if (n_images <= 0) return PG_OK;
+    if (exact_attn_f32()) { pg_set_error("attention_x3out: not available with the fp32-MFMA attention selected"); return PG_ESTATE; }
+    hipLaunchKernelGGL(attention_x3_kernel<true>, dim3(n_images * VIT_HEADS * 5), dim3(256), 0, s, qkv, (float*)out3, n_images);
+    return pg_check_launch("attention_x3out");
 }

@@ -770,9 +770,8 @@ static int precise_parts(int M, int N, int Ktot, bool resid, const int* cand, in
 // that run as ONE persistent launch (PgGemmExtra::parts: S x tilesM x tilesN tiles on the 256 CUs): part p multiplies columns
 // [p Kp, (p + 1) Kp) of the triple operands into the fp32 partial buffer p (the bias rides in part 0); then
 // dst = (resid ? dst : 0) + sum of the parts, in part order (sum_parts_kernel).
-static int precise_gemm(pg_vit* h, const uint16_t* A3, int64_t lda, const uint16_t* W3, int64_t ldw, const float* bias, float* parts,
-                        float* dst, bool resid, int M, int N, int Ktot, const int* cand, int ncand, hipStream_t s) {
-    (void)h;
+// Which of the three forms a shape takes (a pure function of the shape): 0 = gemm_mid.hip, S >= 1 = the persistent kernel in S parts.
+static int precise_route(int M, int N, int Ktot, bool resid, const int* cand, int ncand) {
     double parts_us = 0.0;
     const int S = precise_parts(M, N, Ktot, resid, cand, ncand, &parts_us);
     // Round 6: a handful of images (a settled-at-once exact pass: serving, certain_forward) -- the 128 x 128 one-tile-per-block kernel
@@ -781,9 +780,16 @@ static int precise_gemm(pg_vit* h, const uint16_t* A3, int64_t lda, const uint16
     if (pg_gemm_mid_on() && N % 128 == 0) {
         const double rounds_m = ceil((double)((M + 127) / 128) * (N / 128) / (double)pg_num_cus());
         const double mid_us = rounds_m * ((Ktot / 64) * 0.6 + (resid ? 6.0 : 5.0));
-        if (mid_us < parts_us)
-            return pg_gemm_launch(PG_DTYPE_F16, A3, lda, W3, ldw, bias, dst, N, M, N, Ktot, resid ? EPI_RESID : EPI_F32, 1.f, 0, nullptr, 71, s);
+        if (mid_us < parts_us) return 0;
     }
+    return S;
+}
+static int precise_gemm(pg_vit* h, const uint16_t* A3, int64_t lda, const uint16_t* W3, int64_t ldw, const float* bias, float* parts,
+                        float* dst, bool resid, int M, int N, int Ktot, const int* cand, int ncand, hipStream_t s) {
+    (void)h;
+    const int S = precise_route(M, N, Ktot, resid, cand, ncand);
+    if (S == 0)
+        return pg_gemm_launch(PG_DTYPE_F16, A3, lda, W3, ldw, bias, dst, N, M, N, Ktot, resid ? EPI_RESID : EPI_F32, 1.f, 0, nullptr, 71, s);
     if (S == 1)
         return pg_gemm_launch(PG_DTYPE_F16, A3, lda, W3, ldw, bias, dst, N, M, N, Ktot, resid ? EPI_RESID : EPI_F32, 1.f, 0, nullptr, 36, s);
     const int Kp = Ktot / S;
@@ -792,6 +798,21 @@ static int precise_gemm(pg_vit* h, const uint16_t* A3, int64_t lda, const uint16
     ex.parts = S; ex.a_part = Kp; ex.w_part = Kp; ex.c_part = part_elems;
     RC(pg_gemm_launch(PG_DTYPE_F16, A3, lda, W3, ldw, bias, parts, N, M, N, Kp, EPI_F32, 1.f, 0, nullptr, 36, s, &ex));
     return pg_sum_parts_launch(parts, S, part_elems, dst, part_elems, resid ? 1 : 0, s);
+}
+
+// pg_tune_exact_fusion (round 6): the exact pass's two activation splits ride in their producers -- the attention
+// writes the triple the out-projection reads (attention_x3_kernel<true>), fc1's epilogue applies QuickGELU and writes the triple fc2
+// reads (EPI_GELU_X3, where fc1 runs as one persistent launch: S = 1) -- instead of an fp32 buffer plus a split_x3 launch each.  The
+// arithmetic per element is the same expression in both forms (x3.h): results are bit-identical (tests/test_gpu_precise.py).  0 = the
+// unfused form (the A/B arm and the checker).
+static int g_exact_fusion = -1;
+extern "C" int pg_tune_exact_fusion(int on) {
+    g_exact_fusion = on ? 1 : 0;
+    return PG_OK;
+}
+static bool exact_fusion_on() {
+    if (g_exact_fusion < 0) { const char* e = getenv("PIGEON_EXACT_FUSION"); g_exact_fusion = (e && e[0] == '0') ? 0 : 1; }
+    return g_exact_fusion != 0;
 }
 
 static int vit_precise_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n, float* emb_out, float* hidden_out, char* ws,
@@ -810,6 +831,8 @@ static int vit_precise_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n
     static const int S2[2] = {1, 2}, S4[3] = {1, 2, 4};       // ... with two products (K' = 2048 / 8192)
     const int np = g_exact_products;                          // partial products per weight GEMM (3; 2: pg_tune_exact_products)
     const int* c1 = np == 3 ? S3 : S2; const int* c2 = np == 3 ? S6 : S4; const int n2 = np == 3 ? 4 : 3;
+    const bool fuse = exact_fusion_on();
+    const bool fuse_fc1 = fuse && precise_route((int)M, F, np * D, false, c1, 2) == 1;    // one persistent launch: the epilogue can finish the job
     RC(pg_x3_im2col_launch(pixels, pix_dtype, G3, n, s));
     RC(pg_gemm_launch(dt, G3, 3 * VIT_PATCH_KPAD, h->wpatch3, 3 * VIT_PATCH_KPAD, nullptr, X, D, n * VIT_PATCHES, D, np * VIT_PATCH_KPAD,
                       EPI_PATCH, 1.f, 0, h->pos, V, s));
@@ -818,12 +841,20 @@ static int vit_precise_chunk(pg_vit* h, const void* pixels, int pix_dtype, int n
         const LayerW& L = h->layers[l];
         RC(pg_x3_ln_launch(X, L.ln1g, L.ln1b, T3, M, eps, s));
         RC(precise_gemm(h, T3, 3 * D, L.wqkv3, 3 * D, L.bqkv_raw, PP, Fb, false, (int)M, 3 * D, np * D, c1, 2, s));
-        RC(pg_attention_f32_launch(Fb, O, n, s));
-        RC(pg_x3_split_launch(O, T3, M, D, 0, s));
+        if (fuse && pg_attention_x3out_available()) {
+            RC(pg_attention_x3out_launch(Fb, T3, n, s));         // (T3's LayerNorm triple is dead: the QKV GEMM has consumed it)
+        } else {
+            RC(pg_attention_f32_launch(Fb, O, n, s));
+            RC(pg_x3_split_launch(O, T3, M, D, 0, s));
+        }
         RC(precise_gemm(h, T3, 3 * D, L.wo3, 3 * D, L.bo, PP, X, true, (int)M, D, np * D, c1, 2, s));
         RC(pg_x3_ln_launch(X, L.ln2g, L.ln2b, T3, M, eps, s));
-        RC(precise_gemm(h, T3, 3 * D, L.w13, 3 * D, L.b1_raw, PP, Fb, false, (int)M, F, np * D, c1, 2, s));
-        RC(pg_x3_split_launch(Fb, G3, M, F, 1, s));
+        if (fuse_fc1) {
+            RC(pg_gemm_launch(dt, T3, 3 * D, L.w13, 3 * D, L.b1_raw, G3, 3 * F, (int)M, F, np * D, EPI_GELU_X3, 1.f, 0, nullptr, V, s));
+        } else {
+            RC(precise_gemm(h, T3, 3 * D, L.w13, 3 * D, L.b1_raw, PP, Fb, false, (int)M, F, np * D, c1, 2, s));
+            RC(pg_x3_split_launch(Fb, G3, M, F, 1, s));
+        }
         RC(precise_gemm(h, G3, 3 * F, L.w23, 3 * F, L.b2, PP, X, true, (int)M, D, np * F, c2, n2, s));
     }
     RC(pg_token_mean_launch(X, emb_out, n, s));

@@ -733,6 +733,11 @@ def tune_gemm_raster(gn: int) -> None:
     check(load().pg_tune_gemm_raster(int(gn)), "pg_tune_gemm_raster")
 
 
+def tune_exact_fusion(on: bool) -> None:
+    """pg_tune_exact_fusion: the exact pass's activation splits inside their producers (default on).  Bit-identical either way."""
+    check(load().pg_tune_exact_fusion(1 if on else 0), "pg_tune_exact_fusion")
+
+
 def tune_gemm_mid(on: bool) -> None:
     """pg_tune_gemm_mid: small batches through the 128 x 128 kernel when the cost model says so (default on).  Timing only."""
     check(load().pg_tune_gemm_mid(1 if on else 0), "pg_tune_gemm_mid")

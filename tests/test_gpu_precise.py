@@ -112,6 +112,59 @@ def test_x3_layernorm_and_gelu(env):
     assert _rel(t[:, :4096] + t[:, 4096:8192], ref) < 1e-6
 
 
+def test_gelu_x3_epilogue_equals_f32_epilogue_plus_split_kernel(env):
+    """EPI_GELU_X3 (round 6: the exact mode's fc1 writes the triple fc2 reads from its own epilogue) against the form it replaces --
+    EPI_F32 into an fp32 buffer, then split_x3_kernel<true> -- BIT for bit: ragged M (a last row panel of 19 rows, one of 1 row),
+    more tiles than CUs, fc1's own shape; the guard rows behind row M and nothing else are left alone."""
+    ops, lib = env["ops"], env["lib"]
+    g = torch.Generator().manual_seed(41)
+    for (M, N, K) in ((1000, 512, 256), (70 * 256 + 19, 1024, 128), (2 * 577, 4096, 3072), (257, 256, 384)):
+        A = torch.randn((M, K), generator=g).half().to(DEV)
+        W = (torch.randn((N, K), generator=g) * 0.05).half().to(DEV)
+        bias = torch.randn((N,), generator=g).to(DEV)
+        f32 = torch.empty((M, N), dtype=torch.float32, device=DEV)
+        ops.gemm16(A, W, bias, f32, lib.EPI_F32, variant=36)
+        want = ops.x3_split(f32, gelu=True)
+        got = torch.full((M + 3, 3 * N), 7.0, dtype=torch.float16, device=DEV)
+        ops.gemm16(A, W, bias, got, lib.EPI_GELU_X3, variant=36, M=M)
+        torch.cuda.synchronize()
+        assert torch.equal(got[:M].view(torch.int16), want.view(torch.int16)), (M, N, K)
+        assert bool((got[M:].float() == 7.0).all())
+        # and it is the triple of QuickGELU(A W^T + b) to fp32 grade
+        ref = A.double() @ W.double().t() + bias.double()
+        ref = ref * torch.sigmoid(1.702 * ref)
+        t = got[:M].float().double()
+        assert _rel((t[:, :N] + t[:, N:2 * N]).cpu(), ref.cpu()) < 1e-6
+    # shapes / operands the epilogue does not exist for are refused, not mis-run
+    bad = torch.empty((8, 3 * 512), dtype=torch.float16, device=DEV)
+    with pytest.raises(lib.PigeonHipError):                                  # row stride 2 N instead of 3 N
+        ops.gemm16(A[:8, :256].contiguous(), W[:512, :256].contiguous(), bias[:512].contiguous(),
+                   torch.empty((8, 2 * 512), dtype=torch.float16, device=DEV), lib.EPI_GELU_X3, variant=36)
+    with pytest.raises(lib.PigeonHipError):
+        ops.gemm16(A[:8, :256].bfloat16().contiguous(), W[:512, :256].bfloat16().contiguous(), bias[:512].contiguous(), bad.bfloat16(), lib.EPI_GELU_X3, variant=36)
+
+
+def test_exact_pass_fusion_changes_no_bit(env):
+    """pg_tune_exact_fusion: the exact pass with its activation splits inside their producers (attention_x3_kernel<true>, EPI_GELU_X3)
+    against the unfused form (fp32 buffers + split_x3 launches) -- embeddings AND the last hidden state bit for bit, at a batch whose fc1
+    runs as one persistent launch (the fused epilogue), and at one whose GEMMs go through the small-batch kernel (only the attention is
+    fused there)."""
+    ops, syn = env["ops"], env["syn"]
+    enc = ops.VitEncoder(syn.make_vit_weights(seed=5, layers=3), layers=3, precise=True)
+    g = torch.Generator().manual_seed(9)
+    try:
+        for n in (30, 2):
+            px = torch.randn((n, 3, 336, 336), generator=g).to(DEV)
+            ops.tune_exact_fusion(False)
+            e0, h0 = enc.forward_precise(px, return_hidden=True)
+            ops.tune_exact_fusion(True)
+            e1, h1 = enc.forward_precise(px, return_hidden=True)
+            torch.cuda.synchronize()
+            assert torch.equal(e0, e1) and torch.equal(h0, h1), n
+    finally:
+        ops.tune_exact_fusion(True)
+
+
 @pytest.mark.parametrize("kernel", ["split_fp16", "fp32_mfma"])
 def test_attention_f32_vs_fp64(env, capsys, kernel):
     """The exact mode's attention against fp64: round 5's kernel on split-fp16 operands (v_mfma_f32_32x32x16_f16, three partial
