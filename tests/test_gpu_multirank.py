@@ -30,7 +30,7 @@ def _worker(rank, world, port):
     assert comm.world_size == world and comm.rank == rank
     dev = torch.device(f"cuda:{rank}")
     B, k = 16, 5
-    mk = lambda r: [                                                     # the five buffers PanoramaPipeline.step gathers
+    mk = lambda r: [                                                     # five of the buffers a step's first grouped gather carries (deferred.py submit)
         (torch.arange(B * 4 * 1024, dtype=torch.float32).reshape(B, 4, 1024) + 1e6 * r),
         (torch.arange(B * k, dtype=torch.int64).reshape(B, k) + 1000 * r),
         (torch.rand((B, k), generator=torch.Generator().manual_seed(r)) .float()),
@@ -127,7 +127,7 @@ def _deferred_worker(rank, world, port, tmp):
     kq = torch.tensor([float(torch.quantile(tols.clamp(max=1e9), 0.17 if rank == 0 else 0.5)) / m.certainty.rel_tol], device=dev)
     kq_all = comm.gather(kq)
     m.certainty.kappa = float(kq_all.mean())
-    pipe = PanoramaPipeline(m, ref, comm, min_flush=4, max_lag=3)
+    pipe = PanoramaPipeline(m, ref, comm, min_flush=4, max_lag=3, pass_quantum=2)   # passes of 4, 6 .. slots from the queue heads; the rest waits
     got = {}
     idx = torch.arange(6, device=dev) * world + rank
     for i, px in enumerate(steps):

@@ -63,7 +63,9 @@ for cls, (pats, bytes_per_row) in CLASSES.items():
             # ... and of the small-tile launch that takes the rows beyond the persistent kernel's last whole round (gemm_tail.hip,
             # same epilogue number): a GEMM of the model = the two launches together
             epi = pat.split("<T_F16,")[1].strip().split(",")[0].split(">")[0].strip() if "<T_F16," in pat else None
-            tail = [v for k, v in avg_ms.items() if epi is not None and f"gemm_tail_kernel<T_F16, {epi}>" in k.replace(" >", ">")]
+            # (round 6: a K = 1024 tail -- fc1's -- goes through gemm_mid.hip; in a 512-image step that kernel name has no other use)
+            tail = [v for k, v in avg_ms.items() if epi is not None and (f"gemm_tail_kernel<T_F16, {epi}>" in k.replace(" >", ">") or
+                                                                         f"gemm_mid_kernel<T_F16, {epi}>" in k.replace(" >", ">"))]
             if tail and cls in TAIL_SPLIT:
                 e["rocprof_tail_avg_ms"] = tail[0]
             break
