@@ -195,6 +195,32 @@ def _preprocessor(in_h: int, in_w: int, device_index: int) -> "hip_ops.Preproces
     return p
 
 
+# Pinned host staging buffers of gpu_preprocess's PIL / ndarray-list path, one per (count, image shape, device): [tensor, event of the
+# last host-to-device copy that read it].  A buffer is rewritten only after that copy has run (the event is long past in practice).
+_STAGING: Dict = {}
+_STAGING_MAX = 8
+
+
+def _staging(n: int, shape, dev) -> Tensor:
+    key = (int(n), tuple(int(v) for v in shape), int(dev.index))
+    ent = _STAGING.get(key)
+    if ent is None:
+        if len(_STAGING) >= _STAGING_MAX:
+            _STAGING.pop(next(iter(_STAGING)))
+        ent = _STAGING[key] = [torch.empty((key[0],) + key[1], dtype=torch.uint8).pin_memory(), None]
+    elif ent[1] is not None:
+        ent[1].synchronize()
+    return ent[0]
+
+
+def _staging_done(t: Tensor) -> None:
+    for ent in _STAGING.values():
+        if ent[0] is t:
+            ent[1] = torch.cuda.Event()
+            ent[1].record()
+            return
+
+
 def gpu_preprocess(images, device="cuda", out_dtype: torch.dtype = torch.float32) -> Tensor:
     """CLIP preprocessing on the GPU (pg_prep_forward): `images` is a uint8 RGB tensor / ndarray (N,H,W,3) or (H,W,3),
     or a list of PIL images / arrays (grouped by size; every size gets its own coefficient tables).  Returns the
@@ -210,18 +236,34 @@ def gpu_preprocess(images, device="cuda", out_dtype: torch.dtype = torch.float32
             t = t[None]
         groups = [(None, t)]
     else:
-        arrs = [np.asarray(im.convert("RGB")) if hasattr(im, "convert") else np.asarray(im) for im in images]
+        # (a PIL image that is RGB already is not copied by `convert`: a serving request's four views are; round 6)
+        arrs = [np.asarray(im if getattr(im, "mode", None) == "RGB" else im.convert("RGB")) if hasattr(im, "convert") else np.asarray(im)
+                for im in images]
         by_size: Dict = {}
         for i, a in enumerate(arrs):
             by_size.setdefault(a.shape, []).append(i)
-        groups = [(idx, torch.from_numpy(np.stack([arrs[i] for i in idx]))) for idx in by_size.values()]
+        groups = []
+        for idx in by_size.values():
+            a0 = arrs[idx[0]]
+            if a0.dtype != np.uint8 or a0.ndim != 3:
+                groups.append((idx, torch.from_numpy(np.stack([arrs[i] for i in idx]))))       # refused below with the usual message
+                continue
+            # the images of one size go straight into a PINNED staging buffer (one copy instead of np.stack + the driver's own staging
+            # of a pageable source), from which the transfer below is asynchronous
+            stage = _staging(len(idx), a0.shape, dev)
+            view = stage.numpy()
+            for j, i in enumerate(idx):
+                view[j] = arrs[i]
+            groups.append((idx, stage))
     n_total = sum(g[1].shape[0] for g in groups)
     out = torch.empty((n_total, 3, 336, 336), dtype=out_dtype, device=dev)
     for idx, t in groups:
         if t.dtype != torch.uint8 or t.shape[-1] != 3:
             raise ValueError(f"gpu_preprocess expects uint8 RGB (N,H,W,3), got {t.dtype} {tuple(t.shape)}")
         with torch.cuda.device(dev):
-            px = _preprocessor(t.shape[1], t.shape[2], dev.index)(t.to(dev, non_blocking=True).contiguous(), out_dtype)
+            on_dev = t.to(dev, non_blocking=True).contiguous()
+            _staging_done(t)                                       # (a pinned staging buffer is reused only after this copy has run)
+            px = _preprocessor(t.shape[1], t.shape[2], dev.index)(on_dev, out_dtype)
         if idx is None:
             out = px
         else:

@@ -40,3 +40,24 @@ for i, views in enumerate(reqs):
 lat = np.sort(np.asarray(lat))
 print(f"PIGEON_GEMM_MID={os.environ.get('PIGEON_GEMM_MID', '1')}: {len(lat)} requests (4 views of 640x640 each, PIL -> answer): median {np.median(lat):.2f} ms, "
       f"p10 {lat[len(lat) // 10]:.2f}, p90 {lat[9 * len(lat) // 10]:.2f}, max {lat[-1]:.2f} ms; {exact} went through the exact tier")
+if "--profile" in sys.argv:                                   # where the host side of a request goes (cProfile, 40 more requests)
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for views in reqs[5:45]:
+        predict_panorama(views, model, refiner)
+    torch.cuda.synchronize()
+    pr.disable()
+    st = pstats.Stats(pr, stream=sys.stdout)
+    st.sort_stats("cumulative").print_stats(45)
+    # and the device side: events around the whole request against the host clock
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dts = []
+    for views in reqs[5:25]:
+        torch.cuda.synchronize()
+        ev0.record()
+        predict_panorama(views, model, refiner)
+        ev1.record()
+        torch.cuda.synchronize()
+        dts.append(ev0.elapsed_time(ev1))
+    print(f"stream time first launch -> last launch of a request: median {np.median(dts):.2f} ms")
