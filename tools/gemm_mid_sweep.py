@@ -27,7 +27,8 @@ def timeit(fn, iters=50):
 
 shapes = [("qkv  1024->3072 LN fold", 3072, 1024, "ln", L.EPI_QKV_LN), ("out  1024->1024 resid+stat", 1024, 1024, "rs", None),
           ("fc1  1024->4096 LN fold + GELU", 4096, 1024, "ln", L.EPI_GELU_LN), ("fc2  4096->1024 resid+stat", 1024, 4096, "rs", None)]
-print(f"{'shape':34s} " + " ".join(f"n={n:<3d} pers/mid us" for n in (1, 2, 4, 8, 12, 16, 24, 32, 64)))
+THREE = "--three" in sys.argv      # third arm: the 256 x 256 persistent kernel (variant 36) where variant 56 means the 384 x 256 one
+print(f"{'shape':34s} " + " ".join(f"n={n:<3d} pers/{'p256/' if THREE else ''}mid us" for n in (1, 2, 4, 8, 12, 16, 24, 32, 64)))
 for name, N, K, kind, epi in shapes:
     W = (torch.randn((N, K), generator=g) * 0.05).half().to(dev)
     bias = torch.randn(N, generator=g).to(dev)
@@ -40,7 +41,7 @@ for name, N, K, kind, epi in shapes:
         X = torch.randn((M + 400, N), generator=g).to(dev)
         t, outs = {}, {}
         X0 = X.clone()
-        for v in (56, 71):
+        for v in ((56, 36, 71) if THREE else (56, 71)):
             ops.tune_gemm_mid(False)                                   # variant 56 = the persistent kernels themselves, no small-batch routing
             if kind == "ln":
                 fn = lambda: ops.gemm16_ln(A, W, bias, cs, rs, epi, qscale=0.25, qcols=1024, variant=v)      # noqa: E731
@@ -57,5 +58,9 @@ for name, N, K, kind, epi in shapes:
                     (lambda: ops.gemm16_resid_stat(A, W, bias * 0, Xt[:M], variant=56)))
         same = all(torch.equal(a, b) for a, b in zip(outs[56], outs[71]))
         pick = "m" if abs(tp - t[71]) < abs(tp - t[56]) else "p"       # what the cost model of pg_gemm_launch chose (by its time)
-        cells.append(f"{t[56]:6.1f}/{t[71]:6.1f}{pick}{'' if same else ' DIFF'}")
+        if THREE:
+            same = same and all(torch.equal(a, b) for a, b in zip(outs[56], outs[36]))
+            cells.append(f"{t[56]:6.1f}/{t[36]:6.1f}/{t[71]:6.1f}{pick}{'' if same else ' DIFF'}")
+        else:
+            cells.append(f"{t[56]:6.1f}/{t[71]:6.1f}{pick}{'' if same else ' DIFF'}")
     print(f"{name:34s} " + "  ".join(cells))
