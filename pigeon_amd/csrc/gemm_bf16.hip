@@ -457,6 +457,34 @@ static bool use_pp6(int variant, int epi, int N, int K) {
     return variant == 56 && pg_gemm_pp6_supported(epi, N, K) && (epi != EPI_RESID_STAT || resid6_enabled(K));
 }
 
+// Modelled time (us) of one GEMM launch on `ncu` CUs through kernel `kind` (0 = 384 x 256 persistent, 1 = 256 x 256 persistent,
+// 2 = gemm_mid.hip), for batches of up to ~64 images: the routing of pg_gemm_launch below.  A persistent launch is a sequence of
+// rounds; a round's tile period grows with the share f of the CUs it keeps busy (the power cap: 2.4 GHz on an idle chip, ~1.7 GHz on
+// a full one), c(f) = ci + (cf - ci) f^2 microseconds per 64-wide K tile, plus an epilogue the first round pays in full and the later
+// ones partly (the next tile's operands are in flight under it).  Constants fitted to profiles/r06/gemm_three_sweep.txt (the model's
+// four GEMM shapes x 1 .. 64 images x the three kernels): the pick is the measured best, or within 0.4 % of it, in all 36 cells.
+static double gemm_model_us(int kind, int M, int N, int K, int epi, int ncu) {
+    const bool resid = epi == EPI_RESID || epi == EPI_RESID_STAT;
+    const bool gelu = epi == EPI_GELU || epi == EPI_GELU_LN;
+    const double kt = K / 64;
+    if (kind == 2) {
+        const int64_t tiles = (int64_t)((M + 127) / 128) * (N / 128);
+        return (double)((tiles + ncu - 1) / ncu) * (kt * PG_MID_US_KT_MID + (resid ? 7.0 : 5.5));
+    }
+    const int bm = kind == 0 ? 384 : 256;
+    const double ci = kind == 0 ? 1.6 : 1.1, cf = kind == 0 ? 3.0 : 1.8;
+    const double e1 = kind == 0 ? (resid ? 7.0 : (gelu ? 9.0 : 6.0)) : (resid ? 12.0 : (gelu ? 9.0 : 7.0));
+    const double e2 = kind == 0 ? 3.0 : 6.0;
+    const int64_t tiles = (int64_t)((M + bm - 1) / bm) * (N / 256);
+    const int64_t full = tiles / ncu;
+    const double f = (double)(tiles % ncu) / (double)ncu;
+    double t = 0.0;
+    if (full > 0) t += kt * cf + e1 + (double)(full - 1) * (kt * cf + e2);
+    if (f > 0.0) t += kt * (ci + (cf - ci) * f * f) + (full > 0 ? e2 : e1);
+    return t;
+}
+#define PG_ROUTE_MAX_ROWS 40000   // the routing model is fitted up to 64 images (36 928 token rows); above that a variant means its kernel
+
 template <typename T>
 static int gemm_dispatch(GemmArgs& g, int epi, int variant, hipStream_t s) {
     switch (variant) {
@@ -539,27 +567,28 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
         return pg_gemm_tail_launch(dtype, g, epi, 0, s);
     }
     {
-        // Small batches (gemm_mid.hip, round 6): when the persistent kernel's tiles do not even fill ONE round -- a panorama or two:
-        // serving, calibration, a settled-at-once exact pass -- its launch takes one whole tile period with most CUs idle; the
-        // 128 x 128 one-tile-per-block kernel puts 2 - 4.5 x as many blocks on the chip.  Both produce the same bits for a row: the
-        // choice is a timing decision, taken by a two-line cost model of the shape (constants measured on MI355X,
-        // profiles/r06/gemm_mid_sweep.txt; pg_tune_gemm_mid(0) / PIGEON_GEMM_MID=0: never).
+        // Small and middle batches (round 6).  The product variant (56) means "384 x 256 tiles where they exist, 256 x 256 elsewhere",
+        // chosen for the 512-image step, where a launch is 12 - 50 rounds.  Up to ~64 images a launch is 1 - 7 rounds and what
+        // decides is how the row panels of a tile shape fill whole rounds of the CUs: one panorama (2308 rows) is 7 panels of 384
+        // or 10 of 256 or 19 of 128; 16 images leave the 384-row kernel a second round with 44 of 256 CUs busy.  All three kernels
+        // produce the same bits for a row (tests/test_gpu_parity.py), so the choice is a timing decision, taken by gemm_model_us
+        // above (pg_tune_gemm_mid(0) / PIGEON_GEMM_MID=0: the variant's own kernel, always).  Measured
+        // (profiles/r06/gemm_three_sweep.txt, latency_route.txt): 16 images QKV 79.7 -> 64.6 us, fc2 123.5 -> 94.6; one panorama fc1
+        // 38.7 -> 31.7.
         const bool six = use_pp6(variant, epi, N, K);
         const bool pp = !six && (variant == 56 || (variant >= 30 && variant < 50)) && N % 256 == 0 && K % 128 == 0;
-        if ((six || pp) && pg_gemm_mid_on() && pg_gemm_mid_supported(epi, N, K)) {
+        if ((six || pp) && pg_gemm_mid_on() && M <= PG_ROUTE_MAX_ROWS && epi != EPI_PATCH && epi <= EPI_GELU_LN) {
             int ncu = pg_num_cus();
             if (pg_gemm_block_cap() > 0 && pg_gemm_block_cap() < ncu) ncu = pg_gemm_block_cap();
-            const int bm = six ? 384 : 256;
-            const int64_t tiles_p = (int64_t)((M + bm - 1) / bm) * (N / 256);
-            if (tiles_p < ncu) {
-                const bool resid = epi == EPI_RESID || epi == EPI_RESID_STAT;
-                const double kt = K / 64;
-                const double t_p = six ? kt * PG_MID_US_KT_P6 + (resid ? 14.0 : 9.0) : kt * PG_MID_US_KT_PP + (resid ? 20.0 : 8.0);
-                const int64_t tiles_m = (int64_t)((M + 127) / 128) * (N / 128);
-                const double rounds_m = (double)((tiles_m + ncu - 1) / ncu);
-                const double t_m = rounds_m * (kt * PG_MID_US_KT_MID + (resid ? 6.0 : 5.0));
-                if (t_m < t_p) return pg_gemm_mid_launch(dtype, g, epi, s);
-            }
+            const double t_own = gemm_model_us(six ? 0 : 1, M, N, K, epi, ncu);
+            const double t_pp = (six && pg_gemm_route_pp256()) ? gemm_model_us(1, M, N, K, epi, ncu) : 1e30;
+            const double t_mid = pg_gemm_mid_supported(epi, N, K) ? gemm_model_us(2, M, N, K, epi, ncu) : 1e30;
+            // the 256 x 256 kernel has to win by a margin: where the model calls it level with the 384 x 256 kernel (64 images) or with
+            // gemm_mid (2 and 8 images) the encoder measured 1 - 3 % SLOWER with it in place (profiles/r06/latency_route_ab.txt: a
+            // launch in a forward is not a launch in a loop of its own); where it wins by more, the encoder gains 3 - 9 %
+            const bool pp_wins = t_pp < 0.90 * t_own && t_pp < 0.90 * t_mid;
+            if (!pp_wins && t_mid < t_own) return pg_gemm_mid_launch(dtype, g, epi, s);
+            if (pp_wins) return pg_gemm_pp_launch(dtype, g, epi, 36, s);
         }
     }
     {

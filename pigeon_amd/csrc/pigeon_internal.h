@@ -38,6 +38,7 @@ int pg_gemm_tail_min_n();                        // env PIGEON_GEMM_TAIL_MIN_N: 
 int pg_gemm_tail_min_k();                        // env PIGEON_GEMM_TAIL_MIN_K: smallest K for which the tail split is used
 int pg_gemm_tail_rows();                         // env PIGEON_GEMM_TAIL_ROWS / pg_tune_gemm_tail_rows: most rows handed to gemm_tail.hip (0 = never)
 int pg_gemm_raster_gn();                       // pg_tune_gemm_raster / env PIGEON_GEMM_RASTER_GN: N tiles per raster group of the 384 x 256 kernel (0 = default 4, -1 = all)
+bool pg_gemm_route_pp256();                     // the small-batch routing may also swap the 384 x 256 kernel for the 256 x 256 one (PIGEON_GEMM_MID=2: no)
 bool pg_gemm_mid_on();                          // pg_tune_gemm_mid / env PIGEON_GEMM_MID: small batches through gemm_mid.hip when the cost model says so
 unsigned long long pg_tune_epoch();             // bumped by every pg_tune_* call: captured hipGraphs of an older epoch are stale
 float pg_gemm_stagger_fraction();                // env PIGEON_GEMM_STAGGER / pg_tune_gemm_stagger: XCD start spread, fraction of a tile period

@@ -114,11 +114,12 @@ extern "C" int pg_tune_gemm_tail_shape(int min_k, int min_n) {
 }
 static int g_gemm_mid = -1;
 bool pg_gemm_mid_on() {
-    if (g_gemm_mid < 0) { const char* e = getenv("PIGEON_GEMM_MID"); g_gemm_mid = (e && e[0] == '0') ? 0 : 1; }
+    if (g_gemm_mid < 0) { const char* e = getenv("PIGEON_GEMM_MID"); g_gemm_mid = (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); }
     return g_gemm_mid != 0;
 }
+bool pg_gemm_route_pp256() { return pg_gemm_mid_on() && g_gemm_mid != 2; }   // 2 (A/B arm): gemm_mid.hip is the only alternative
 extern "C" int pg_tune_gemm_mid(int on) {
-    g_gemm_mid = on ? 1 : 0; ++g_tune_epoch;
+    g_gemm_mid = on == 2 ? 2 : (on ? 1 : 0); ++g_tune_epoch;
     return PG_OK;
 }
 static float g_stagger = -1.f;

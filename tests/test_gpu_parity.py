@@ -196,11 +196,12 @@ def test_gemm_tail_split_changes_nothing(env):
     """pg_gemm_launch cuts a problem whose tiles do not fill the persistent kernel's last round: whole rounds to the persistent
     kernel, the few rows beyond them to a small-tile kernel -- gemm_mid.hip where its model says it is the cheaper one (round 6: every
     K = 1024 GEMM of the model), gemm_tail.hip otherwise (fc2's K = 4096) or when gemm_mid is switched off.  With the split switched
-    off (tail rows 0) the same call must give the same bits -- 256-row tiles (N = 1024: 264 tiles on 256 CUs -> 16384 + 300 rows) and
-    384-row tiles (N = 3072: 528 tiles -> 16128 + 556 rows), every epilogue (the residual + statistics one writes three row-indexed
-    buffers through the moved bases), guard rows untouched."""
+    off (tail rows 0) the same call must give the same bits -- 256-row tiles (N = 1024: 776 tiles on 256 CUs -> 3 rounds = 49152 rows +
+    300) and 384-row tiles (N = 3072: 1548 tiles -> 6 rounds = 49152 rows + 300), every epilogue (the residual + statistics one writes
+    three row-indexed buffers through the moved bases), guard rows untouched.  (More rows than the small-batch routing of
+    pg_gemm_launch looks at: a variant means its own kernel here.)"""
     ops, L = env["ops"], env["lib"]
-    M = 64 * 256 + 300
+    M = 192 * 256 + 300
     try:
         ops.tune_gemm_tail_shape(0, 0)                       # gemm_tail.hip for every shape gemm_mid.hip does not take
         for K in (256, 1024):
@@ -220,6 +221,28 @@ def test_gemm_tail_split_changes_nothing(env):
         ops.tune_gemm_mid(1)
         ops.tune_gemm_tail_rows(768)
         ops.tune_gemm_tail_shape(2048, 4096)
+
+
+def test_small_batch_routing_changes_nothing(env):
+    """pg_gemm_launch routes batches of up to ~64 images between the 384 x 256 kernel, the 256 x 256 kernel and gemm_mid.hip by a cost
+    model of how their row panels fill rounds of the CUs (round 6).  A routing decision must never be a numerical one: with the
+    routing off (pg_tune_gemm_mid(0): the variant's own kernel) every epilogue gives the same bits -- QKV's shape at 16 images (the
+    model sends it to the 256 x 256 kernel), fc1's at one panorama (256 x 256), fc2's at 16 images (256 x 256 instead of 384 x 256),
+    QKV's at one image (gemm_mid)."""
+    ops, L = env["ops"], env["lib"]
+    try:
+        for M, N, K in ((16 * 577, 3072, 1024), (4 * 577, 4096, 1024), (16 * 577, 1024, 4096), (577, 3072, 1024)):
+            A, W, bias, X0, cs, rs = _tail_problem(M, N, K, 77 + N + M)
+            ops.tune_gemm_mid(0)
+            ref = _gemm_all_epilogues(ops, L, A, W, bias, X0, cs, rs, M, 56)
+            ops.tune_gemm_mid(1)
+            got = _gemm_all_epilogues(ops, L, A, W, bias, X0, cs, rs, M, 56)
+            for i, (a, b) in enumerate(zip(ref, got)):
+                assert torch.equal(a, b), (M, N, K, i)
+            for o in got[:4]:
+                assert bool((o[M:].float() == 7.0).all())
+    finally:
+        ops.tune_gemm_mid(1)
 
 
 def test_gemm_raster_knob_changes_nothing(env):

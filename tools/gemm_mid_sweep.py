@@ -1,7 +1,8 @@
 """Round 6: where does the 128 x 128 small-batch kernel (gemm_mid.hip, variant 71) beat the persistent kernels (variant 56 = the product
 default: 384 x 256 where it exists, 256 x 256 elsewhere)?  The model's four GEMM shapes with their fused epilogues, M = 577 x n images;
 microseconds per launch (HIP events over 50 launches), outputs compared bit for bit; the letter is what pg_gemm_launch's cost model
-picks when left alone (p = persistent, m = the 128 x 128 kernel).
+picks when left alone (p = the variant's persistent kernel, m = the 128 x 128 kernel; with --three a third arm and letter: q = the
+256 x 256 persistent kernel where variant 56 means the 384 x 256 one).
    python tools/gemm_mid_sweep.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -57,7 +58,10 @@ for name, N, K, kind, epi in shapes:
         tp = timeit((lambda: ops.gemm16_ln(A, W, bias, cs, rs, epi, qscale=0.25, qcols=1024, variant=56)) if kind == "ln" else
                     (lambda: ops.gemm16_resid_stat(A, W, bias * 0, Xt[:M], variant=56)))
         same = all(torch.equal(a, b) for a, b in zip(outs[56], outs[71]))
-        pick = "m" if abs(tp - t[71]) < abs(tp - t[56]) else "p"       # what the cost model of pg_gemm_launch chose (by its time)
+        arms = {"p": t[56], "m": t[71]}
+        if THREE:
+            arms["q"] = t[36]                                          # q = the 256 x 256 persistent kernel
+        pick = min(arms, key=lambda k: abs(tp - arms[k]))             # what the cost model of pg_gemm_launch chose (by its time)
         if THREE:
             same = same and all(torch.equal(a, b) for a, b in zip(outs[56], outs[36]))
             cells.append(f"{t[56]:6.1f}/{t[36]:6.1f}/{t[71]:6.1f}{pick}{'' if same else ' DIFF'}")
