@@ -484,6 +484,11 @@ static double gemm_model_us(int kind, int M, int N, int K, int epi, int ncu) {
     return t;
 }
 #define PG_ROUTE_MAX_ROWS 40000   // the routing model is fitted up to 64 images (36 928 token rows); above that a variant means its kernel
+static int route_max_rows() {     // (env PIGEON_GEMM_ROUTE_MAX_ROWS: experiments beyond the fitted range)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PIGEON_GEMM_ROUTE_MAX_ROWS"); v = e ? atoi(e) : PG_ROUTE_MAX_ROWS; if (v < 0) v = 0; }
+    return v;
+}
 
 template <typename T>
 static int gemm_dispatch(GemmArgs& g, int epi, int variant, hipStream_t s) {
@@ -577,7 +582,7 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
         // 38.7 -> 31.7.
         const bool six = use_pp6(variant, epi, N, K);
         const bool pp = !six && (variant == 56 || (variant >= 30 && variant < 50)) && N % 256 == 0 && K % 128 == 0;
-        if ((six || pp) && pg_gemm_mid_on() && M <= PG_ROUTE_MAX_ROWS && epi != EPI_PATCH && epi <= EPI_GELU_LN) {
+        if ((six || pp) && pg_gemm_mid_on() && M <= route_max_rows() && epi != EPI_PATCH && epi <= EPI_GELU_LN) {
             int ncu = pg_num_cus();
             if (pg_gemm_block_cap() > 0 && pg_gemm_block_cap() < ncu) ncu = pg_gemm_block_cap();
             const double t_own = gemm_model_us(six ? 0 : 1, M, N, K, epi, ncu);
