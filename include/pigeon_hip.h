@@ -146,8 +146,10 @@ int pg_tune_gemm_tail_shape(int min_k, int min_n);
  * (each activation panel crosses the fabric once, the weight panels are re-streamed per XCD), 1..64 = explicit (honoured for a GEMM only when it divides that
  * GEMM's count of 256-column tiles, or is at least that count; otherwise the default stays).  Timing only, never results. */
 int pg_tune_gemm_raster(int gn);
-/* Small batches (round 6; also env PIGEON_GEMM_MID=0): GEMMs whose tiles do not fill one round of the persistent kernels -- one or two
- * panoramas -- go to a 128 x 128 one-tile-per-block kernel (csrc/gemm_mid.hip) when a cost model of the shape says it is faster; 0 = never.
+/* Small and middle batches (round 6; also env PIGEON_GEMM_MID=0 / 1 / 2): a GEMM launch of up to ~64 images (40 000 token rows) is
+ * routed between the variant's own persistent kernel (384 x 256 tiles where they exist), the 256 x 256 persistent kernel and a 128 x 128
+ * one-tile-per-block kernel (csrc/gemm_mid.hip) by a cost model of how their row panels fill rounds of the CUs (csrc/gemm_bf16.hip
+ * gemm_model_us).  1 = on (default), 0 = a variant always means its own kernel, 2 = gemm_mid.hip is the only alternative (A/B arm).
  * All GEMM kernels produce the same bits for a row: timing only, never results. */
 int pg_tune_gemm_mid(int on);
 /* Exact mode's attention (also env PIGEON_EXACT_ATTN=f32): 0 = split-fp16 operands on v_mfma_f32_32x32x16_f16 (default, round 5),
