@@ -67,7 +67,7 @@ def test_bench_world8_equal_work_under_unequal_uncertain_counts():
     rank ran the exact tier in the SAME steps on the SAME number of slots (the longest queue), so that the exact tier's time per rank
     is equal although rank 0 had nothing to re-encode and rank 7 seven panoramas per step."""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--panoramas", "12",
-                        "--cells", "50", "--steps", "6", "--warmup", "1", "--min-flush", "10", "--pixel-batches", "4"],
+                        "--cells", "50", "--steps", "6", "--warmup", "1", "--min-flush", "7", "--pass-quantum", "7", "--pixel-batches", "4"],
                        capture_output=True, text=True, timeout=600, env=_env())
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -80,8 +80,10 @@ def test_bench_world8_equal_work_under_unequal_uncertain_counts():
     assert len(sp["compute"]) == 8 and len(sp["gather_incl_wait"]) == 8 and len(r["per_rank_ms_per_step"]) == 8
     sched = r["exact_pass_schedule"]
     assert sched["same_on_every_rank"] is True and len(sched["this_rank"]) >= 2          # ... same flush steps, same slots everywhere
+    assert sched["min_flush"] == 7 and sched["pass_quantum"] == 7                        # what the GPU defaults to on 256 CUs
     for f in sched["this_rank"]:
         assert f["slots_run"] == max(f["queued_per_rank"]) and f["queued_per_rank"][0] == 0 and f["queued_per_rank"][7] > 0
+    assert all(f["slots_run"] % 7 == 0 for f in sched["this_rank"][:-1])                 # whole pass quanta from the queue heads
     # 6 steps x 7 panoramas on the longest queue = 42 slots x 2 ms = 84 ms of exact tier on EVERY rank (14 ms per step)
     ex = sp["exact_passes_per_step"]
     assert sum(f["slots_run"] for f in sched["this_rank"]) == 42
