@@ -15,7 +15,7 @@ for 1.8 % of the work.  Here
     tier runs ONCE over queued rows and its results are scattered into the ring (pg_scatter_rows), judged again at the exact tier's
     floor.  A pass takes a whole number of `pass_quantum`s from the head of the queue and leaves the rest for the next one: the exact
     encoder's GEMMs work in 256-row panels, 64 of which (x 4 column tiles at N = 1024) are one round of the 256 CUs -- 16 384 rows = 28
-    images = 7 panoramas.  Measured (profiles/r06/exact_sweep.txt): 28 / 56 / 84 / 112 images cost 1.19-1.21 ms per image, 32-44
+    images = 7 panoramas.  (Several ranks: the pass is triggered by the MEDIAN queue, see `_pass_size`.)  Measured (profiles/r06/exact_sweep.txt): 28 / 56 / 84 / 112 images cost 1.19-1.21 ms per image, 32-44
     images 1.32-1.40, 60 images 1.33: a pass of "whatever is queued" (10-12 panoramas) pays for rounds it leaves half empty;
   * a step is handed out only when all its rows are settled.  The reference's loops collect at the end
     (training/train_eval_loop.py:98-112, preprocessing/embed.py:36-43): handing results out a few steps late changes nothing for them.
@@ -130,7 +130,7 @@ class DeferredExact:
             self.pass_quantum = round_quantum(px_rows)
             if self._min_flush_arg is None:
                 self.min_flush = self.pass_quantum or 10
-        self.cap = (self.B if self.immediate else self.min_flush + 2 * self.B)
+        self.cap = (self.B if self.immediate else self.min_flush + (self.pass_quantum or 0) + 2 * self.B)
         self.q_pixels = torch.zeros((self.cap,) + tuple(px_rows.shape[1:]), dtype=px_rows.dtype, device=px_rows.device)
         self.slot_dst = torch.zeros((self.cap,), dtype=torch.int64, device=px_rows.device)
         self._true_cap = torch.ones((self.cap,), dtype=torch.bool, device=px_rows.device)
@@ -306,15 +306,36 @@ class DeferredExact:
                 waited = last - first_waiting['step'] if first_waiting is not None else 0
                 if final or self.immediate or waited >= self.max_lag:
                     self._exact_pass(lens, at_step=last)
-                elif max(lens) >= self.min_flush:
-                    q = self.pass_quantum or 0
-                    take = (max(lens) // q) * q if q and max(lens) >= q else max(lens)
-                    self._exact_pass([min(n, take) for n in lens], at_step=last)   # the head of every queue; the rest waits
+                else:
+                    take = self._pass_size(lens)
+                    if take > 0:
+                        self._exact_pass([min(n, take) for n in lens], at_step=last)   # the head of every queue; the rest waits
         done = []
         while self.pending and self.pending[0]['appended'] is not None and \
                 all(f >= a for a, f in zip(self.pending[0]['appended'], self.flushed)):
             done.append(self._emit(self.pending.popleft()))
         return done
+
+    def _pass_size(self, lens: List[int]) -> int:
+        """Slots the next regular pass takes from the head of every queue (0: no pass yet) -- a pure function of the gathered queue
+        lengths, so every rank decides the same.  Without a quantum: everything, once the longest queue holds min_flush.  With one: a
+        whole number of quanta, when the MEDIAN queue (lower median; one rank: the queue) holds min_flush -- every rank runs the same
+        number of slots, so a pass triggered by the longest of 8 queues while the others hold 4-5 rows runs them a third empty
+        (tools/pass_policy_sim.py, Poisson arrivals: 1.54 slots run per real row on 8 ranks, 1.36 on 4, 1.18 on 2); at the median half
+        the ranks fill their slots and the others miss one or two (1.17 / 1.12 / 1.05) -- or when the longest queue has got one
+        quantum ahead of min_flush (a rank that finds more: the pass then takes all but about one quantum of it), so that no queue
+        holds more than min_flush + quantum + the two steps the host has not seen."""
+        q = self.pass_quantum or 0
+        longest = max(lens)
+        if not q or longest < q:
+            return longest if longest >= self.min_flush else 0
+        median = sorted(lens)[(len(lens) - 1) // 2]
+        take = 0
+        if median >= self.min_flush:
+            take = q * max(1, median // q)
+        if longest >= self.min_flush + q:
+            take = max(take, q * max(1, (longest - q) // q))
+        return take
 
     @torch.no_grad()
     def _exact_pass(self, lens: List[int], at_step: int):

@@ -277,7 +277,7 @@ def test_deferred_engine_pass_quantum_takes_whole_rounds_and_leaves_the_rest_que
             if torch.is_tensor(now[i]["state"][k]):
                 assert torch.equal(now[i]["state"][k], later[i]["state"][k]), (i, "state", k)
     sizes = [n for _, n in m.calls]
-    assert sum(sizes) == sum(n for _, n in m_now.calls) and eng.cap == 3 + 2 * 6
+    assert sum(sizes) == sum(n for _, n in m_now.calls) and eng.cap == 3 + 3 + 2 * 6        # min_flush + one quantum + two unseen steps
     # every pass but the closing flush (and a max_lag one, which takes everything) is a whole number of quanta; some pass left rows behind
     assert all(n % 3 == 0 for n in sizes[:-1]) and len(sizes) >= 4
     assert max(lag) <= 8 + 1
@@ -289,6 +289,26 @@ def test_deferred_engine_pass_quantum_takes_whole_rounds_and_leaves_the_rest_que
     assert order2 == list(range(18)) and sum(n for _, n in m2.calls) == sum(sizes)
     for i in range(18):
         assert torch.equal(now[i]["embedding"], later2[i]["embedding"]) and torch.equal(now[i]["refined_geocell"], later2[i]["refined_geocell"])
+
+
+def test_pass_size_is_a_pure_function_of_the_gathered_queue_lengths():
+    """DeferredExact._pass_size: one rank -- whole quanta once the queue holds min_flush; several ranks -- the LOWER MEDIAN queue
+    triggers (all ranks run the same number of slots: triggering on the longest of 8 queues runs the others a third empty,
+    tools/pass_policy_sim.py), the longest queue triggers one quantum later and then takes all but about one quantum of it; without a
+    quantum: everything, once the longest queue holds min_flush."""
+    from pigeon_amd.deferred import DeferredExact
+    eng = DeferredExact.__new__(DeferredExact)
+    eng.pass_quantum, eng.min_flush = 7, 7
+    assert [eng._pass_size([n]) for n in (0, 6, 7, 13, 14, 15, 30)] == [0, 0, 7, 7, 14, 14, 28]
+    assert eng._pass_size([5, 6, 7, 4, 8, 7, 6, 9]) == 0                     # sorted 4 5 6 [6] 7 7 8 9: the lower median holds 6
+    assert eng._pass_size([5, 7, 7, 4, 8, 7, 6, 9]) == 7                     # ... 7
+    assert eng._pass_size([3, 4, 5, 2, 13, 4, 5, 6]) == 0                    # the longest is not a quantum ahead yet
+    assert eng._pass_size([3, 4, 5, 2, 14, 4, 5, 6]) == 7 and eng._pass_size([0, 0, 0, 30]) == 21
+    assert eng._pass_size([14, 15]) == 14 and eng._pass_size([6, 13]) == 0 and eng._pass_size([6, 14]) == 7
+    eng.pass_quantum, eng.min_flush = 0, 10                                   # no quantum (off the GPU): the first form of the round
+    assert eng._pass_size([9, 3]) == 0 and eng._pass_size([12, 3]) == 12
+    eng.pass_quantum, eng.min_flush = 5, 2                                    # min_flush below the quantum: what there is
+    assert eng._pass_size([3]) == 3 and eng._pass_size([1]) == 0
 
 
 def test_deferred_engine_max_lag_and_queue_wrap():
