@@ -152,6 +152,10 @@ int pg_tune_gemm_raster(int gn);
  * gemm_model_us).  1 = on (default), 0 = a variant always means its own kernel, 2 = gemm_mid.hip is the only alternative (A/B arm).
  * All GEMM kernels produce the same bits for a row: timing only, never results. */
 int pg_tune_gemm_mid(int on);
+/* Which kernel pg_op_gemm16* / the encoder would launch for this shape under the current knobs: *kind = 0 the 384 x 256 persistent
+ * kernel, 1 the 256 x 256 one, 2 csrc/gemm_mid.hip, -1 none of them (a non-persistent variant or shape).  variant 0 = the default.
+ * Host arithmetic only: no launch, no device work (tests/test_host_cpu.py checks the picks against profiles/r06/gemm_three_sweep.txt). */
+int pg_gemm_route(int variant, int epi, int M, int N, int K, int* kind);
 /* Exact mode's attention (also env PIGEON_EXACT_ATTN=f32): 0 = split-fp16 operands on v_mfma_f32_32x32x16_f16 (default, round 5),
  * 1 = plain fp32 on v_mfma_f32_32x32x2_f32 (round 4's kernel; the A/B arm).  Both are fp32-grade (6e-7 / 8e-7 against fp64). */
 int pg_tune_exact_attention(int use_f32_mfma);

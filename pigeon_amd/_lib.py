@@ -60,6 +60,7 @@ SIGNATURES = {
     "pg_tune_exact_attention": (_I, [_I]),
     "pg_tune_exact_products": (_I, [_I]),
     "pg_tune_exact_fusion": (_I, [_I]),
+    "pg_gemm_route": (_I, [_I, _I, _I, _I, _I, _P]),
     "pg_vit_saturation_check": (_I, [_P, _I]),
     "pg_vit_saturation_read": (_I, [_P, C.POINTER(_I64), _I]),
     "pg_vit_range_alarm_read": (_I, [_P, C.POINTER(_I64), _I]),

@@ -490,6 +490,33 @@ static int route_max_rows() {     // (env PIGEON_GEMM_ROUTE_MAX_ROWS: experiment
     return v;
 }
 
+// Which kernel a launch of the persistent variants takes: 0 = 384 x 256 persistent, 1 = 256 x 256 persistent, 2 = gemm_mid.hip; -1 = not
+// a persistent variant / shape (the caller's dispatch decides).  A pure function of the shape, the knobs and the CU count.
+static int gemm_route(int variant, int epi, int M, int N, int K) {
+    const bool six = use_pp6(variant, epi, N, K);
+    const bool pp = !six && (variant == 56 || (variant >= 30 && variant < 50)) && N % 256 == 0 && K % 128 == 0;
+    if (!six && !pp) return -1;
+    const int own = six ? 0 : 1;
+    if (!(pg_gemm_mid_on() && M <= route_max_rows() && epi != EPI_PATCH && epi >= EPI_QKV && epi <= EPI_GELU_LN)) return own;
+    int ncu = pg_num_cus();
+    if (pg_gemm_block_cap() > 0 && pg_gemm_block_cap() < ncu) ncu = pg_gemm_block_cap();
+    const double t_own = gemm_model_us(own, M, N, K, epi, ncu);
+    const double t_pp = (six && pg_gemm_route_pp256()) ? gemm_model_us(1, M, N, K, epi, ncu) : 1e30;
+    const double t_mid = pg_gemm_mid_supported(epi, N, K) ? gemm_model_us(2, M, N, K, epi, ncu) : 1e30;
+    // the 256 x 256 kernel has to win by a margin: where the model calls it level with the 384 x 256 kernel (64 images) or with
+    // gemm_mid (2 and 8 images) the encoder measured 1 - 3 % SLOWER with it in place (profiles/r06/latency_route_ab.txt: a
+    // launch in a forward is not a launch in a loop of its own); where it wins by more, the encoder gains 3 - 9 %
+    const bool pp_wins = t_pp < 0.90 * t_own && t_pp < 0.90 * t_mid;
+    if (pp_wins) return 1;
+    return t_mid < t_own ? 2 : own;
+}
+// (exported for the host-logic tests and tools: no launch, no device work)
+extern "C" int pg_gemm_route(int variant, int epi, int M, int N, int K, int* kind) {
+    if (!kind || M <= 0 || N <= 0 || K <= 0) { pg_set_error("gemm_route: bad argument"); return PG_EINVAL; }
+    *kind = gemm_route(variant ? variant : pg_default_gemm_variant(), epi, M, N, K);
+    return PG_OK;
+}
+
 template <typename T>
 static int gemm_dispatch(GemmArgs& g, int epi, int variant, hipStream_t s) {
     switch (variant) {
@@ -580,21 +607,9 @@ int pg_gemm_launch(int dtype, const void* A, int64_t lda, const void* W, int64_t
         // above (pg_tune_gemm_mid(0) / PIGEON_GEMM_MID=0: the variant's own kernel, always).  Measured
         // (profiles/r06/gemm_three_sweep.txt, latency_route.txt): 16 images QKV 79.7 -> 64.6 us, fc2 123.5 -> 94.6; one panorama fc1
         // 38.7 -> 31.7.
-        const bool six = use_pp6(variant, epi, N, K);
-        const bool pp = !six && (variant == 56 || (variant >= 30 && variant < 50)) && N % 256 == 0 && K % 128 == 0;
-        if ((six || pp) && pg_gemm_mid_on() && M <= route_max_rows() && epi != EPI_PATCH && epi <= EPI_GELU_LN) {
-            int ncu = pg_num_cus();
-            if (pg_gemm_block_cap() > 0 && pg_gemm_block_cap() < ncu) ncu = pg_gemm_block_cap();
-            const double t_own = gemm_model_us(six ? 0 : 1, M, N, K, epi, ncu);
-            const double t_pp = (six && pg_gemm_route_pp256()) ? gemm_model_us(1, M, N, K, epi, ncu) : 1e30;
-            const double t_mid = pg_gemm_mid_supported(epi, N, K) ? gemm_model_us(2, M, N, K, epi, ncu) : 1e30;
-            // the 256 x 256 kernel has to win by a margin: where the model calls it level with the 384 x 256 kernel (64 images) or with
-            // gemm_mid (2 and 8 images) the encoder measured 1 - 3 % SLOWER with it in place (profiles/r06/latency_route_ab.txt: a
-            // launch in a forward is not a launch in a loop of its own); where it wins by more, the encoder gains 3 - 9 %
-            const bool pp_wins = t_pp < 0.90 * t_own && t_pp < 0.90 * t_mid;
-            if (!pp_wins && t_mid < t_own) return pg_gemm_mid_launch(dtype, g, epi, s);
-            if (pp_wins) return pg_gemm_pp_launch(dtype, g, epi, 36, s);
-        }
+        const int kind = gemm_route(variant, epi, M, N, K);
+        if (kind == 2) return pg_gemm_mid_launch(dtype, g, epi, s);
+        if (kind == 1 && use_pp6(variant, epi, N, K)) return pg_gemm_pp_launch(dtype, g, epi, 36, s);
     }
     {
         // Tail split: if the tiles do not fill the persistent kernel's last round and the rows beyond the last whole round are

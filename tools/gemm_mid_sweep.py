@@ -58,10 +58,11 @@ for name, N, K, kind, epi in shapes:
         tp = timeit((lambda: ops.gemm16_ln(A, W, bias, cs, rs, epi, qscale=0.25, qcols=1024, variant=56)) if kind == "ln" else
                     (lambda: ops.gemm16_resid_stat(A, W, bias * 0, Xt[:M], variant=56)))
         same = all(torch.equal(a, b) for a, b in zip(outs[56], outs[71]))
-        arms = {"p": t[56], "m": t[71]}
-        if THREE:
-            arms["q"] = t[36]                                          # q = the 256 x 256 persistent kernel
-        pick = min(arms, key=lambda k: abs(tp - arms[k]))             # what the cost model of pg_gemm_launch chose (by its time)
+        import ctypes as C
+        kind = C.c_int(-1)                                             # what pg_gemm_launch's routing takes for this shape (pg_gemm_route)
+        L.load().pg_gemm_route(56, epi if epi is not None else L.EPI_RESID_STAT, M, N, K, C.byref(kind))
+        own_is_256 = epi is None and K < 2048                          # out-projection: the variant's own kernel is the 256 x 256 one
+        pick = "m" if kind.value == 2 else ("p" if (kind.value == 0 or own_is_256) else "q")
         if THREE:
             same = same and all(torch.equal(a, b) for a, b in zip(outs[56], outs[36]))
             cells.append(f"{t[56]:6.1f}/{t[36]:6.1f}/{t[71]:6.1f}{pick}{'' if same else ' DIFF'}")
