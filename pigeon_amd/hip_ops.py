@@ -742,4 +742,5 @@ def tune_gemm_mid(on) -> None:
     """pg_tune_gemm_mid: the routing of GEMM launches of up to ~64 images between the 384 x 256 / 256 x 256 persistent kernels and the
     128 x 128 small-batch kernel (True / 1: on, the default; False / 0: a variant means its own kernel; 2: only the 128 x 128 kernel
     as an alternative -- the A/B arm).  Timing only: all kernels give the same bits for a row."""
-    check(load().pg_tune_gemm_mid(2 if on == 2 and on is not True else (1 if on else 0)), "pg_tune_gemm_mid")
+    mode = 2 if (not isinstance(on, bool) and on == 2) else (1 if on else 0)
+    check(load().pg_tune_gemm_mid(mode), "pg_tune_gemm_mid")

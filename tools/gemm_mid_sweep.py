@@ -4,6 +4,7 @@ microseconds per launch (HIP events over 50 launches), outputs compared bit for 
 picks when left alone (p = the variant's persistent kernel, m = the 128 x 128 kernel; with --three a third arm and letter: q = the
 256 x 256 persistent kernel where variant 56 means the 384 x 256 one).
    python tools/gemm_mid_sweep.py"""
+import ctypes as C
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -58,7 +59,6 @@ for name, N, K, kind, epi in shapes:
         tp = timeit((lambda: ops.gemm16_ln(A, W, bias, cs, rs, epi, qscale=0.25, qcols=1024, variant=56)) if kind == "ln" else
                     (lambda: ops.gemm16_resid_stat(A, W, bias * 0, Xt[:M], variant=56)))
         same = all(torch.equal(a, b) for a, b in zip(outs[56], outs[71]))
-        import ctypes as C
         kind = C.c_int(-1)                                             # what pg_gemm_launch's routing takes for this shape (pg_gemm_route)
         L.load().pg_gemm_route(56, epi if epi is not None else L.EPI_RESID_STAT, M, N, K, C.byref(kind))
         own_is_256 = epi is None and K < 2048                          # out-projection: the variant's own kernel is the 256 x 256 one
