@@ -105,7 +105,9 @@ def parse(argv=None):
     ap.add_argument("--fast", action="store_true",
                     help="time the 16-bit fast mode (SuperGuessr(exact_top1=False): no certainty-driven exact re-encode) as the headline; "
                          "its geocell argmax is NOT guaranteed to be the reference's -- A/B and kernel-profiling runs only")
-    ap.add_argument("--fast-steps", type=int, default=3, help="steps of the fast-mode leg after the timed region (0 = skip)")
+    ap.add_argument("--fast-steps", type=int, default=10,
+                    help="timed steps of the fast-mode leg after the timed region (0 = skip); the leg runs every resident batch anyway (the "
+                         "parity legs want them), so timing 10 of them instead of round 5's 3 costs nothing and steadies exact_cost_vs_fast")
     ap.add_argument("--raster-gn", type=int, default=None, help="pg_tune_gemm_raster for this run (A/B of the 384x256 GEMM raster)")
     ap.add_argument("--weights", choices=["default", "spread"], default="default",
                     help="default: HF-init tower (seed 0), head centred on the mean embedding and scaled to sigma(logit) = 4 (BASELINE's synthetic "
