@@ -834,6 +834,9 @@ def _worker(args, comm):
     from pigeon_amd.evaluate import PanoramaPipeline
 
     rank, world = comm.rank, comm.world_size
+    if os.environ.get("PIGEON_BENCH_TEST_NOISE"):                # tests/test_bench_dry_run.py: stdout stays ONE line regardless
+        print("noise through print")
+        os.write(1, b"noise through fd 1\n")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: either leave WORLD_SIZE unset (bench.py then starts "
                          f"its {args.gpus} ranks itself) or launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -1096,7 +1099,7 @@ def _worker(args, comm):
     if dry:
         result.update({"dry_run": True, "roofline": None, "cpu_baseline": None,
                        "collective": {"backend": "gloo (CPU stand-in for pg_allgather_many)", "nranks": world}})
-        print(json.dumps(result))
+        _emit(result)
         return
 
     from pigeon_amd import _lib
@@ -1351,7 +1354,29 @@ def _worker(args, comm):
         del pixel_batches
         torch.cuda.empty_cache()
         result["secondary_baseline"] = secondary_baseline(dev, vit_sd, args.layers)
-    print(json.dumps(result))
+    _emit(result)
+
+
+_PROTOCOL_OUT = None
+
+
+def _claim_stdout():
+    """stdout of this command is a protocol -- ONE JSON line, from rank 0.  Everything else that anything in the process writes to
+    file descriptor 1 (the product's status prints -- the reference's classes print, they do not log --, RCCL's banner, a library's
+    warning) goes to stderr from here on; `_emit` writes the line to the descriptor stdout had."""
+    global _PROTOCOL_OUT
+    if _PROTOCOL_OUT is not None:
+        return
+    sys.stdout.flush()
+    _PROTOCOL_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
+
+
+def _emit(result):
+    out = _PROTOCOL_OUT if _PROTOCOL_OUT is not None else sys.stdout
+    out.write(json.dumps(result) + "\n")
+    out.flush()
 
 
 def main():
@@ -1361,6 +1386,7 @@ def main():
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    _claim_stdout()
     worker(args)
 
 

@@ -102,6 +102,15 @@ def test_bench_single_rank_dry_run_and_world_mismatch():
                         "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=_env())
     assert p.returncode == 0, p.stderr[-2000:]
     _check(p.stdout, 1, 2, 1, "direct")
+    # stdout is the protocol: the JSON line and nothing else, whatever the product or a library prints on the way (file descriptor 1
+    # is pointed at stderr for the run; PIGEON_BENCH_TEST_NOISE makes the worker print through Python AND through the descriptor)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--panoramas", "6", "--cells", "50",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300,
+                       env=dict(_env(), PIGEON_BENCH_TEST_NOISE="1"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{") and json.loads(lines[0])["n_gpus"] == 1, p.stdout[:400]
+    assert "noise through print" in p.stderr and "noise through fd 1" in p.stderr
     env = dict(_env(), WORLD_SIZE="1", RANK="0")                    # a launcher that disagrees with --gpus: loud, not silent
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
                        text=True, timeout=300, env=env)
