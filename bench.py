@@ -929,8 +929,13 @@ def _worker(args, comm):
         # the exact encoder: the systematic part of their difference and the RMS of the rest (pigeon_amd/certainty.py); frozen
         # afterwards.  (A whole batch, not 32 panoramas: every fast-path launch of this process then has the step's shape, so that
         # rocprofv3's per-kernel averages of this command are the step's.)
+        # (Its own batch, from a seed every rank shares: the systematic part it measures is SUBTRACTED from every fast embedding --
+        # pigeon_amd/certainty.py `debias` -- so the replicas of a data-parallel job must measure the same vector, and none of the
+        # timed batches is in the sample it was fitted on.)
         try:
-            model.calibrate_certainty(pixel_batches[nb - 1], max_samples=args.panoramas)
+            cal_px = torch.randn((args.panoramas, 12, 336, 336), generator=torch.Generator(device=dev).manual_seed(4321), device=dev)
+            model.calibrate_certainty(cal_px, max_samples=args.panoramas)
+            del cal_px
         except Exception as e:  # noqa  (nothing depends on it but the size of the re-encoded set: the threshold stays at the contract's 1e-3)
             print(f"[bench] certainty calibration failed: {e!r}", file=sys.stderr)
     for i in range(max(args.warmup, 1)):

@@ -37,9 +37,9 @@ extern "C" {
 #define PG_DTYPE_F16     2
 #define PG_DTYPE_F64     3
 
-#define PG_ABI_VERSION   4   /* 2: pg_vit_cfg.precise, pg_vit_forward_precise, pg_head_margin (round 4); 3: pg_head_certainty, pg_refine_forward_ex,
+#define PG_ABI_VERSION   5   /* 2: pg_vit_cfg.precise, pg_vit_forward_precise, pg_head_margin (round 4); 3: pg_head_certainty, pg_refine_forward_ex,
                               * pg_refine_certainty, pg_tune_gemm_raster (round 5); 4: the deferred exact tier -- pg_requeue_append,
-                              * pg_rows_to_slots, pg_requeue_take, pg_scatter_rows, pg_head_wstats (round 6) */
+                              * pg_rows_to_slots, pg_requeue_take, pg_scatter_rows, pg_head_wstats (round 6); 5: pg_embedding_debias (round 6) */
 
 const char* pg_last_error(void);
 int pg_abi_version(void);
@@ -322,6 +322,15 @@ int pg_requeue_take(const int64_t* slot_dst, int64_t cap, int64_t head, int n_va
 int pg_scatter_rows(const void* src, int64_t row_bytes, const int64_t* dst_row, int n, void* dst, int64_t dst_rows,
                     int64_t remap_wb, int64_t remap_b, int64_t remap_off, void* stream);
 int pg_head_wstats(const float* W, int C, const float* beta, float* out2, void* stream);
+
+/* The systematic part of the 16-bit encoder's error taken out of its embeddings, in place:  emb[r] <- emb[r] - |emb[r]|_2 * bias
+ * for every row r < n of the DEVICE (n, dim) fp32 matrix (dim must be 1024); bias DEVICE (1024) fp32 = the mean over a few calibration
+ * images of (fast - exact) / |exact| (pigeon_amd/certainty.py: measured once per set of weights by sending the same images through
+ * pg_vit_forward and pg_vit_forward_precise).  The reference's encoder is fp32 (models/clip_embedder.py:63-65,
+ * models/super_guessr.py:395-398) and has no such term; what is left of this path's error after the subtraction is the part that
+ * differs from image to image, which pg_head_certainty / pg_refine_certainty account for.  The norm is summed in a fixed order (a row's
+ * bits do not depend on the batch).  Asynchronous on `stream`. */
+int pg_embedding_debias(float* emb, int64_t n, int dim, const float* bias, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * CLIP image preprocessing (the step in front of the encoder): uint8 RGB -> pixel_values.

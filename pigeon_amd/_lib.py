@@ -91,6 +91,7 @@ SIGNATURES = {
     "pg_requeue_take": (_I, [_P, _I64, _I64, _I, _I, _P, _P]),
     "pg_scatter_rows": (_I, [_P, _I64, _P, _I, _P, _I64, _I64, _I64, _I64, _P]),
     "pg_head_wstats": (_I, [_P, _I, _P, _P, _P]),
+    "pg_embedding_debias": (_I, [_P, _I64, _I, _P, _P]),
     "pg_op_gemm16": (_I, [_I, _P, _I64, _P, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _P, _I, _P]),
     "pg_op_gemm16_ld": (_I, [_I, _P, _I64, _P, _I64, _P, _P, _I64, _I, _I, _I, _I, _F, _I, _P, _I, _P]),
     "pg_op_rowstat_cast": (_I, [_P, _P, _I, _P, _I64, _F, _P]),

@@ -319,6 +319,8 @@ class CLIPEmbedding(torch.nn.Module):
             raise ValueError(f"contract_guard must be 'exact', 'raise' or 'off', got {self.contract_guard!r}")
         self.guard_stats = None                  # what the first forward measured (None until then / with the guard off)
         self.force_exact = False
+        self.debias = os.environ.get('PIGEON_DEBIAS', '1') not in ('', '0')
+        self.bias = None                         # (1024,) fp32: the systematic part `_check_contract` measured, subtracted from every fast embedding
 
         if load_checkpoint:
             sd = torch.load(model_name, map_location='cpu')
@@ -349,7 +351,13 @@ class CLIPEmbedding(torch.nn.Module):
             if self.contract_guard != 'off' and self.guard_stats is None and pixel_values.shape[0] > 0:
                 self._check_contract(base, pixel_values)
             # last_hidden_state.mean(dim=1), fused in the library (token_mean kernel)
-            return base.embed_precise(pixel_values) if self.force_exact else base.embed(pixel_values)
+            if self.force_exact:
+                return base.embed_precise(pixel_values)
+            emb = base.embed(pixel_values)
+            if self.bias is not None:
+                # the 16-bit encoder's measured systematic error taken out of every image's embedding (pigeon_amd/certainty.py `debias`)
+                hip_ops.embedding_debias(emb, self.bias if self.bias.device == emb.device else self.bias.to(emb.device))
+            return emb
 
     def _check_contract(self, base, pixel_values: Tensor, max_images: int = 32, contract: float = 1e-3) -> dict:
         """Once per set of weights: the 16-bit encoder against the exact one on up to `max_images` images of the first batch."""
@@ -366,12 +374,32 @@ class CLIPEmbedding(torch.nn.Module):
             dist.all_gather_object(every, (st['image_rel_err'], st['worst_image_rel_err']))
             st['image_rel_err_all_ranks'] = max(e[0] for e in every)
             st['worst_image_rel_err_all_ranks'] = max(e[1] for e in every)
+        # the part of that error that is the SAME for every image (relative to |e|): with PIGEON_DEBIAS (default on) it is subtracted from
+        # every fast embedding this module returns (pg_embedding_debias), when a held-out half of the images confirms that what is left
+        # is smaller.  The verdict below is taken on the RAW error (the conservative reading).
+        bias = None
+        if self.debias and px.shape[0] >= 8:
+            rel = (fast - exact) / exact.norm(dim=1, keepdim=True).clamp_min(1e-30)
+            from .certainty import Certainty
+            held = Certainty.apply_bias(fast[1::2], rel[0::2].mean(dim=0))
+            left = float(((held - exact[1::2]).norm(dim=1) / exact[1::2].norm(dim=1).clamp_min(1e-30)).pow(2).mean().sqrt())
+            raw = float(err.pow(2).mean().sqrt())
+            st['bias_norm'], st['residual_rms'] = float(rel.mean(dim=0).norm()), left
+            if left < 0.9 * raw:
+                bias = rel.mean(dim=0).contiguous()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            every = [None] * dist.get_world_size()                   # one vector for the whole job: the mean of the ranks', if all keep one
+            dist.all_gather_object(every, None if bias is None else bias.cpu())
+            bias = None if any(b is None for b in every) else torch.stack(every).mean(dim=0).to(fast.device)
+        self.bias = bias
+        st['debias'] = bias is not None
         overall = st.get('image_rel_err_all_ranks', st['image_rel_err'])
         worst = st.get('worst_image_rel_err_all_ranks', st['worst_image_rel_err'])
         st['outside'] = overall > 0.85 * contract or worst > 0.95 * contract
         self.guard_stats = st
         print(f"pigeon_amd.CLIPEmbedding: 16-bit encoder vs exact encoder on {st['images']} images of the first batch: "
-              f"{st['image_rel_err']:.2e} relative overall, worst image {st['worst_image_rel_err']:.2e} (contract {contract:g})")
+              f"{st['image_rel_err']:.2e} relative overall, worst image {st['worst_image_rel_err']:.2e} (contract {contract:g})"
+              + (f"; its systematic part ({st['bias_norm']:.2e}) is subtracted from every embedding, {st['residual_rms']:.2e} left" if bias is not None else ""))
         if st['outside']:
             if self.contract_guard == 'raise':
                 raise RuntimeError('CLIPEmbedding: the 16-bit encoder is outside the 1e-3 embedding contract on these weights '

@@ -302,7 +302,37 @@ __global__ __launch_bounds__(256) void refine_certainty_kernel(pg_bank bank, con
     if (tid == 0) { tol[b] = res.t; code[b] = res.code; }
 }
 
+// emb[r] -= |emb[r]| * bias  (one wave per row of 1024; the norm's summation order is fixed: 16 columns per lane in ld16's order, then
+// wave_sum's butterfly).  The systematic part of the 16-bit encoder's error, measured once per set of weights against the exact
+// encoder (pigeon_amd/certainty.py, `debias`), taken out of every fast embedding before anything downstream reads it.
+__global__ __launch_bounds__(256) void embedding_debias_kernel(float* __restrict__ emb, int64_t n, const float* __restrict__ bias) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    float* row = emb + r * CT_DIM;
+    f32x4 e[4], b[4];
+    ld16(row, lane, e);
+    ld16(bias, lane, b);
+    const float norm = sqrtf(dot16(e, e));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = __fmaf_rn(-norm, b[i][c], e[i][c]);
+        *(f32x4*)(row + i * 256 + lane * 4) = o;
+    }
+}
+
 }  // namespace
+
+extern "C" int pg_embedding_debias(float* emb, int64_t n, int dim, const float* bias, void* stream) {
+    if (n < 0 || dim != CT_DIM) { pg_set_error("embedding_debias: n = %lld, dim = %d (must be %d)", (long long)n, dim, CT_DIM); return PG_EINVAL; }
+    if (n == 0) return PG_OK;
+    if (!emb || !bias) { pg_set_error("embedding_debias: null pointer argument"); return PG_EINVAL; }
+    if ((n + 3) / 4 > 2147483647LL) { pg_set_error("embedding_debias: n = %lld rows exceed the launch grid", (long long)n); return PG_EINVAL; }
+    hipLaunchKernelGGL(embedding_debias_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, emb, n, bias);
+    return pg_check_launch("embedding_debias");
+}
 
 extern "C" int pg_head_certainty(const float* logits, int B, int C, const float* emb, int P, const float* W, const int64_t* topk_idx,
                                  int kx, const float* beta, const float* wstats, float* tol, int32_t* code, float* margin,

@@ -497,6 +497,17 @@ def head_certainty(logits: torch.Tensor, emb: torch.Tensor, W: torch.Tensor, top
     return tol, code, margin, sens
 
 
+def embedding_debias(emb: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """pg_embedding_debias, in place: emb[r] -= |emb[r]| * bias for every row of the (n,1024) fp32 matrix `emb` (contiguous; any
+    leading shape).  bias (1024,) fp32: the calibrated systematic part of the 16-bit encoder's error (pigeon_amd/certainty.py)."""
+    _dev(emb, torch.float32); _dev(bias, torch.float32); _shape(bias, "bias", HIDDEN)
+    if emb.dim() < 1 or emb.shape[-1] != HIDDEN or not emb.is_contiguous():
+        raise ValueError(f"embedding_debias: emb must be contiguous (..., {HIDDEN}), got {tuple(emb.shape)}")
+    n = emb.numel() // HIDDEN
+    check(load().pg_embedding_debias(_p(emb), n, HIDDEN, _p(bias), _stream()), "pg_embedding_debias")
+    return emb
+
+
 # ----------------------------------------------------------------------------------------- deferred exact tier (csrc/requeue.hip)
 def head_wstats(W: torch.Tensor, drift: Optional[torch.Tensor]) -> torch.Tensor:
     """pg_head_wstats: (2,) fp32 = [largest row norm of W, max over cells of |W[c].drift| (0 without drift)]."""

@@ -57,7 +57,9 @@ class SuperGuessr(nn.Module):
         With a ProtoRefiner, `pigeon_amd.evaluate.certain_forward` extends the same statement to the refined cell and point.
         Caller-supplied `embedding`s are judged against `embedding_rel_tol` (keyword; default `margin_rel_tol_exact`: they carry no
         16-bit error of this forward).
-        Extra keywords: `exact_top1`, `margin_kappa` (z-score, default 3.6), `margin_rel_tol` (default 1e-3 = the contract's embedding
+        Extra keywords: `debias` (default True / env PIGEON_DEBIAS: the calibrated systematic part of the 16-bit encoder's error is
+        subtracted from every fast embedding -- pg_embedding_debias -- instead of only being accounted for in the certainty test),
+        `exact_top1`, `margin_kappa` (z-score, default 3.6), `margin_rel_tol` (default 1e-3 = the contract's embedding
         tolerance until `calibrate_certainty` -- called explicitly, or by the first forward that sees >= 8 samples with pixels, or
         once 16 samples have come in through smaller batches -- replaces it by the measured error of THIS set of weights), `margin_rel_tol_exact` (5e-6).
         """
@@ -67,7 +69,7 @@ class SuperGuessr(nn.Module):
         self.exact_top1 = (os.environ.get('PIGEON_EXACT_TOP1', '1') not in ('', '0')) if exact_top1 is None else bool(exact_top1)
         self.certainty = Certainty(kappa=float(kwargs.pop('margin_kappa', os.environ.get('PIGEON_MARGIN_KAPPA', 3.6))),
                                    rel_tol=float(kwargs.pop('margin_rel_tol', os.environ.get('PIGEON_MARGIN_REL_TOL', 1e-3))),
-                                   rel_tol_exact=float(kwargs.pop('margin_rel_tol_exact', 5e-6)))
+                                   rel_tol_exact=float(kwargs.pop('margin_rel_tol_exact', 5e-6)), debias=kwargs.pop('debias', None))
         self.margin_autocalibrate = bool(kwargs.pop('margin_autocalibrate', True))
         self.embedding_rel_tol = float(kwargs.pop('embedding_rel_tol', self.certainty.rel_tol_exact))
         self.last_margin = self.last_certain = self.last_tol = None
@@ -168,7 +170,7 @@ class SuperGuessr(nn.Module):
         if isinstance(self.base_model, HipCLIPVisionModel):
             self.base_model._weights_changed()
         # other weights: the measured error is void -- back to the constructor's tolerance (not a hard-coded one), nothing half-collected
-        self.certainty = Certainty(self.certainty.kappa, self._rel_tol0, self.certainty.rel_tol_exact)
+        self.certainty = Certainty(self.certainty.kappa, self._rel_tol0, self.certainty.rel_tol_exact, debias=self.certainty.debias)
         self._cal_buffer = []
         self._engines = {}
 
@@ -262,6 +264,11 @@ class SuperGuessr(nn.Module):
             # a tower on which the calibration measured the 16-bit path OUTSIDE the embedding contract: every sample through the exact encoder
             exact_tier = bool(self.certainty.force_exact and self.exact_top1)
             embedding = self._encoder().embed_precise(px) if exact_tier else self._encoder().embed(px)   # :395-398 (ViT + token mean)
+            bias = None if exact_tier else self.certainty.bias_on(dev)
+            if bias is not None:
+                # the 16-bit encoder's measured systematic error, taken out of every image's embedding (pigeon_amd/certainty.py `debias`):
+                # what the head, the refiner and the caller see is the corrected embedding; the certainty kernels get no drift
+                hip_ops.embedding_debias(embedding, bias)
             if self.panorama:
                 embedding = embedding.reshape((num_samples, 4, embedding.shape[-1]))   # :404-405 (explicit width: B = 0 stays legal)
         else:

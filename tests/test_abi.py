@@ -25,7 +25,7 @@ def test_header_symbols_exported(hip_lib):
 def test_ctypes_signatures_cover_header(hip_lib):
     from pigeon_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()
-    assert hip_lib.pg_abi_version() == 4
+    assert hip_lib.pg_abi_version() == 5
 
 
 def test_no_gpu_fails_loudly(hip_lib):

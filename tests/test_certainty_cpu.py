@@ -43,6 +43,38 @@ def test_calibrate_recovers_systematic_part_and_residual():
     assert not c.force_exact and "calibrated on 64 samples" in c.describe()
 
 
+def test_calibrate_debias_takes_the_systematic_part_out_of_the_images():
+    """`debias` (the default): with the per-image embeddings at hand the systematic part becomes a per-image BIAS that is subtracted
+    from the embeddings (pg_embedding_debias; `apply_bias` is its arithmetic) -- the certainty kernels then get no drift, and rel_tol is
+    the held-out residual of the corrected panel means."""
+    n, P = 64, 4
+    fi, ei, beta = _pairs(n * P, beta_norm=2.6e-4, eps=5e-5, seed=11)
+    common = torch.randn((1, D), generator=torch.Generator().manual_seed(12)) * 6.0       # images of one tower share most of their embedding
+    ei = ei + common
+    fi = ei + ei.norm(dim=1, keepdim=True) * ((fi - (ei - common)) / (ei - common).norm(dim=1, keepdim=True))   # same beta + r, relative to the new |e|
+    fast, exact = fi.reshape((n, P, D)).mean(dim=1), ei.reshape((n, P, D)).mean(dim=1)
+    c = Certainty(debias=True)
+    st = c.calibrate(fast, exact, fast_images=fi, exact_images=ei)
+    assert st["debias"] and st["drift_used"] and c.drift is None and c.drift_on(torch.device("cpu")) is None
+    assert c.bias is not None and float((c.bias - beta).norm()) < 0.1 * 5e-5 and c.bias_on(torch.device("cpu")) is c.bias
+    assert abs(st["drift_norm"] - 2.6e-4) < 0.02 * 2.6e-4
+    # four images with independent rests: the panel mean's residual is about half an image's (a little more: the norms differ)
+    assert 0.4 * 5e-5 < st["residual_rms"] < 0.75 * 5e-5 and c.rel_tol == pytest.approx(1.1 * st["residual_rms"])
+    fixed = Certainty.apply_bias(fi, c.bias)
+    err = ((fixed - ei).norm(dim=1) / ei.norm(dim=1))
+    assert float(err.pow(2).mean().sqrt()) < 1.1 * 5e-5 and st["image_rel_err_debiased"] < 0.25 * st["image_rel_err"]
+    assert "subtracted from every fast embedding" in c.describe() and "margin / (|e|" in c.describe()
+    # the switch: the former behaviour (a drift vector for the kernels, nothing subtracted)
+    c0 = Certainty(debias=False)
+    st0 = c0.calibrate(fast, exact, fast_images=fi, exact_images=ei)
+    assert not st0["debias"] and st0["drift_used"] and c0.bias is None and c0.drift is not None
+    # no systematic part: nothing is subtracted
+    fi2, ei2, _ = _pairs(n * P, beta_norm=0.0, eps=3e-4, seed=13)
+    c2 = Certainty(debias=True)
+    st2 = c2.calibrate(fi2.reshape((n, P, D)).mean(dim=1), ei2.reshape((n, P, D)).mean(dim=1), fast_images=fi2, exact_images=ei2)
+    assert not st2["debias"] and c2.bias is None and c2.drift is None and c2.rel_tol == pytest.approx(1.1 * st2["fast_vs_exact_rms"])
+
+
 def test_calibrate_without_a_systematic_part_keeps_none():
     fast, exact, _ = _pairs(64, beta_norm=0.0, eps=3e-4, seed=2)
     c = Certainty()

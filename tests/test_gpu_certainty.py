@@ -296,6 +296,36 @@ def test_refine_certainty_vs_restatement(env, topk, k, T, max_km, with_drift):
         assert not ((code >= 2000) & (code < 3000)).any()
 
 
+def test_embedding_debias_kernel(env):
+    """pg_embedding_debias == emb - |emb| bias (pigeon_amd.certainty.Certainty.apply_bias), in place, any leading shape; a row's bits
+    do not depend on the rows around it; bad shapes are refused."""
+    from pigeon_amd.certainty import Certainty
+    ops, lib = env["ops"], env["lib"]
+    g = torch.Generator().manual_seed(5)
+    emb = (torch.randn((37, 1024), generator=g) * (torch.rand((37, 1), generator=g) * 20 + 0.1)).float()
+    emb[5] = 0.0                                                    # a zero row stays zero
+    bias = (2.6e-4 * torch.randn((1024,), generator=g) / 32).float()
+    want = Certainty.apply_bias(emb.double(), bias.double())
+    got = ops.embedding_debias(emb.clone().to(DEV), bias.to(DEV))
+    assert got.dtype == torch.float32 and float((got.cpu().double() - want).abs().max() / want.abs().max()) < 2e-7
+    assert torch.equal(got[5].cpu(), torch.zeros(1024))
+    # the correction itself (2.6e-4 relative) is reproduced to 1e-3 of its size, not lost in the subtraction
+    assert float(((got.cpu().double() - emb.double()) - (want - emb.double())).norm() / (want - emb.double()).norm()) < 1e-3
+    one = ops.embedding_debias(emb[11:12].clone().to(DEV), bias.to(DEV))
+    assert torch.equal(one[0], got[11])                             # batch-invariant bits
+    pan = ops.embedding_debias(emb[:36].reshape(9, 4, 1024).clone().to(DEV), bias.to(DEV))
+    assert pan.shape == (9, 4, 1024) and torch.equal(pan.reshape(36, 1024), got[:36])
+    x = emb.clone().to(DEV)
+    assert ops.embedding_debias(x, bias.to(DEV)).data_ptr() == x.data_ptr()      # in place
+    assert ops.embedding_debias(torch.empty((0, 1024), device=DEV), bias.to(DEV)).shape == (0, 1024)
+    with pytest.raises(Exception):
+        ops.embedding_debias(torch.zeros((4, 512), device=DEV), bias.to(DEV))
+    with pytest.raises(Exception):
+        ops.embedding_debias(emb.to(DEV).t(), bias.to(DEV))          # not contiguous
+    with pytest.raises(Exception):
+        ops.embedding_debias(emb.clone(), bias)                     # host tensors: no CPU fallback
+
+
 def test_certain_forward_end_to_end_small(env, tmp_path):
     """pigeon_amd.evaluate.certain_forward on a 2-layer tower: with everything forced uncertain every sample is re-encoded and the
     outputs equal the exact encoder's chain; with nothing uncertain they are the fast path's; the info dict is consistent."""

@@ -123,7 +123,8 @@ def _contract_run(env, vit, golden_dir, tmp_path, fixture, capsys):
                 pe = emb.mean(dim=1).double()
                 Wd = W.double()
                 beta = calib.drift.cpu().double() if calib.drift is not None else torch.zeros(1024, dtype=torch.float64)
-                eps = calib.stats["residual_rms"] if calib.drift is not None else calib.stats["fast_vs_exact_rms"]
+                # (`debias`, the default: the systematic part is already out of `emb` -- beta = 0 here -- and eps is the corrected residual)
+                eps = calib.stats["residual_rms"] if (calib.drift is not None or calib.bias is not None) else calib.stats["fast_vs_exact_rms"]
                 cells8 = torch.from_numpy(g["top8_cells"])
                 ref8 = torch.from_numpy(g["top8_logits"]).double()
                 hip8 = (pe @ Wd.t() + b.double())[torch.arange(NP)[:, None], cells8]
@@ -164,6 +165,58 @@ def _contract_run(env, vit, golden_dir, tmp_path, fixture, capsys):
     with open(os.path.join(ROOT, "gpurun_out", f"{fixture}_contract_report.txt"), "w") as f:
         f.write("\n".join(lines + fails) + "\n")
     assert not fails, "\n".join(fails)
+
+
+def test_debias_against_the_real_reference(env, vit24, golden_dir, tmp_path, capsys):
+    """The calibrated systematic part of the 16-bit encoder's error, subtracted from the embeddings (`debias`, the default) against only
+    being accounted for in the certainty test (`debias=False`, the behaviour until round 6): judged on the REAL reference's outputs
+    for one bench step (pipeline24_wide: 128 panoramas, default-init tower).  The corrected embeddings are several times closer to the
+    reference's, fewer samples need the exact tier, and in neither mode is a sample that differs from the reference called certain."""
+    from pigeon_amd.evaluate import certain_forward
+    from pigeon_amd.proto_refiner import ProtoRefiner
+    from pigeon_amd.super_guessr import SuperGuessr
+    syn, orc, ops = env["syn"], env["orc"], env["ops"]
+    g = np.load(os.path.join(golden_dir, "pipeline24_wide.npz"))
+    wseed, layers, NP, pseed, C, ppc, bseed, maxm = [int(x) for x in g["meta"]]
+    W0, _ = syn.make_head_weights(C, seed=0)
+    W, b = W0 * float(g["head_scale"]), torch.from_numpy(g["head_bias"])
+    px = syn.make_pixels(4 * NP, seed=pseed, panorama=True).to(DEV)
+    cal_px = syn.make_pixels(4 * 32, seed=pseed + 1, panorama=True).to(DEV)
+    ref_emb = torch.from_numpy(g["embedding"])
+    bank = syn.make_bank(C, ppc, seed=bseed, empty_frac=0.01, max_members=maxm, center=g["center"], radius=float(g["radius"]))
+    refiner = ProtoRefiner(topk=5, max_refinement=1000.0, temperature=1.6, bank=bank, device=DEV).eval()
+    res, lines = {}, []
+    for debias in (False, True):
+        model = SuperGuessr(vit24[1], panorama=True, freeze_base=True, num_candidates=50, geocell_path=_geocells_csv(tmp_path, C),
+                            exact_top1=False, margin_autocalibrate=False, debias=debias)
+        with torch.no_grad():
+            model.cell_layer.weight.copy_(W); model.cell_layer.bias.copy_(b)
+        model.to(DEV).eval()
+        model.calibrate_certainty(cal_px)
+        st = model.certainty.stats
+        assert st["debias"] == debias and st["drift_used"] and (model.certainty.bias is not None) == debias and (model.certainty.drift is None) == debias
+        out, info = certain_forward(model, refiner, pixel_values=px)
+        emb = out.embedding.cpu()
+        bad = ((out.preds_geocell.cpu().numpy() != g["preds_geocell"]) | (out.preds_LLH.cpu().numpy() != g["preds_LLH"]).any(axis=1)
+               | (info["refined_geocell"].cpu().numpy() != g["default_cell"]) | (info["refined_LLH"].cpu().numpy() != g["default_LLH"]).any(axis=1))
+        certain = info["certain"].cpu().numpy()
+        res[debias] = dict(err=orc.rel_err(emb, ref_emb), worst=orc.max_rel_err_rows(emb.reshape(-1, 1024), ref_emb.reshape(-1, 1024)),
+                           flagged=int((~certain).sum()), bad=int(bad.sum()), missed=int((bad & certain).sum()), rel_tol=model.certainty.rel_tol)
+        lines.append(f"pipeline24_wide, fast mode, debias={debias}: embedding rel err vs the real reference {res[debias]['err']:.2e} (worst image "
+                     f"{res[debias]['worst']:.2e}); flagged {res[debias]['flagged']}/{NP}; outputs differing from the reference {res[debias]['bad']}, of "
+                     f"those called certain {res[debias]['missed']}; rel_tol {res[debias]['rel_tol']:.3g}")
+        if debias:                                                   # the embedding IS the fast encoder's minus |e| bias, per image
+            raw = vit24[1].embed(px.reshape(-1, 3, 336, 336))
+            assert torch.equal(out.embedding.reshape(-1, 1024), ops.embedding_debias(raw.clone(), model.certainty.bias_on(raw.device)))
+    with capsys.disabled():
+        print("\n" + "\n".join(lines))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "debias_vs_reference_report.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    on, off = res[True], res[False]
+    assert on["missed"] == 0 and off["missed"] == 0
+    assert on["err"] < 0.5 * off["err"] and on["worst"] < 0.6 * off["worst"] and on["err"] < EMB_TOL
+    assert on["flagged"] <= off["flagged"] and on["bad"] <= off["bad"]
 
 
 def test_contract_pipeline24(env, vit24, golden_dir, tmp_path, capsys):
