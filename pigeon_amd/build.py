@@ -27,12 +27,6 @@ HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "pigeon_internal.h
            os.path.join(CSRC, "attention_common.h"),
            os.path.join(os.path.dirname(HERE), "include", "pigeon_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-# per-source additions.  preprocess.hip: Pillow's fixed-point arithmetic restated -- no fused multiply-adds the reference does not make.
-# gemm_mid.hip: its software-pipelined mainloop (two fragment sets, MFMAs of one k-step under the reads of the next) has the
-# accumulators live across a loop with three exits; left to itself the register allocator parks half of them in AGPRs and moves 96
-# registers between the files per K tile (v_accvgpr_read / _write) -- with the MFMAs selected in their VGPR form the kernel needs 143
-# VGPRs, no AGPRs, no copies (one wave per SIMD: 512 are available).
-PER_FILE_FLAGS = {"preprocess.hip": ["-ffp-contract=off"], "gemm_mid.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def hipcc() -> str:
@@ -73,7 +67,7 @@ def _build(OBJ: str, LIB: str, FLAGS, force: bool, verbose: bool, SOURCES) -> st
 
     def compile_one(job):
         s, o = job
-        cmd = [cc] + FLAGS + ["-I", CSRC] + PER_FILE_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
+        cmd = [cc] + FLAGS + ["-I", CSRC] + (["-ffp-contract=off"] if s.endswith("preprocess.hip") else []) + ["-c", s, "-o", o]
         if verbose:
             print("[pigeon_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

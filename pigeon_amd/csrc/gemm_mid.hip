@@ -6,9 +6,8 @@
 // the accumulation order -- a row's bits would then depend on the batch it rides in.  This kernel keeps the order and shrinks the
 // tile instead: 128 x 128 block tiles, 4 waves (2 x 2) of 64 x 64 each, one tile per block, up to 2.2 x the blocks of a 256 x 256
 // tiling (152 for fc2 / out-projection, 456 for QKV, 608 for fc1 at one panorama), operands through LDS by direct-to-LDS DMA in a
-// THREE-stage ring (a K tile is 32 KB; up to three K tiles are in flight or landed ahead of the one being multiplied: a block has too
-// few MFMAs per K tile -- 32 per wave, 0.25 us -- to hide a DMA's latency behind a single tile), and the fragment reads of a k-step run
-// under the MFMAs of the one before (two fragment sets: see the mainloop).
+// THREE-stage ring (a K tile is 32 KB; two K tiles are in flight while one is consumed: a block has too few MFMAs per K tile
+// -- 32 per wave, 0.25 us -- to hide a DMA's latency behind a single tile).
 //
 // RESULTS ARE BIT-IDENTICAL to the persistent kernels and to gemm_tail.hip (tests/test_gpu_parity.py::test_gemm_mid_*): every output
 // element is the same chain of v_mfma_f32_16x16x32 over ascending k (weights as the first operand, first step onto 0), the accumulators
@@ -159,75 +158,50 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(GemmArgs g) {
     const int nt = g.K / BK;
     md_issue(ra, rw, smem, wave, voffA, voffW, 0);
     if (nt > 1) md_issue(ra, rw, smem + MD_STAGE, wave, voffA, voffW, BK * 2);
-    if (nt > 2) md_issue(ra, rw, smem + 2 * MD_STAGE, wave, voffA, voffW, 2 * BK * 2);
 
     const int l15 = lane & 15, lq = lane >> 4;
     const int sw = (lane >> 1) & 7;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const uint32_t a_base = lds0 + (wm * 64 + l15) * ROWB, b_base = lds0 + MD_W_OFF + (wn * 64 + l15) * ROWB;
-    const uint32_t x0 = (uint32_t)(((0 * 4 + lq) ^ sw) << 4), x1 = (uint32_t)(((1 * 4 + lq) ^ sw) << 4);   // the two k-steps of a K tile
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // The mainloop is software-pipelined INSIDE the wave (second session of round 6): a block has one wave per SIMD, so nothing else
-    // covers the fragment reads -- read, wait, 16 MFMAs, read, wait, 16 MFMAs took 1 250 cycles per K tile against 512 of MFMA issue,
-    // the CU's LDS port being busy 256 cycles per k-step (4 waves x 8 KB) while every matrix pipe waited.  Two fragment sets: the
-    // reads of k-step s + 1 are in flight while the MFMAs of k-step s run (LDS returns a wave's reads in order: lgkmcnt(8) = the older
-    // set has arrived).  Across K tiles: a wave that has READ both k-steps of tile kt waits for tile kt + 1 and meets the others
-    // at the barrier; then the stage of tile kt is free -- the DMAs of tile kt + 3 go there, three tiles ahead instead of two -- and
-    // the reads of (kt + 1, 0) run under the MFMAs of (kt, 1).  The MFMA chain of every output element is unchanged (ascending k).
-    typename T::v8 a0[4], b0[4], a1[4], b1[4];
-#define MD_READ8(A, B, XO)                                                                        \
-    do {                                                                                          \
-        const uint32_t aa_ = a_base + (XO), ab_ = b_base + (XO);                                  \
-        md_lds_read<0 * 16 * ROWB>(A[0], aa_); md_lds_read<1 * 16 * ROWB>(A[1], aa_);             \
-        md_lds_read<2 * 16 * ROWB>(A[2], aa_); md_lds_read<3 * 16 * ROWB>(A[3], aa_);             \
-        md_lds_read<0 * 16 * ROWB>(B[0], ab_); md_lds_read<1 * 16 * ROWB>(B[1], ab_);             \
-        md_lds_read<2 * 16 * ROWB>(B[2], ab_); md_lds_read<3 * 16 * ROWB>(B[3], ab_);             \
-    } while (0)
-    // swapped operands (weights first) as in every GEMM kernel of the library
-#define MD_MFMA16(A, B)                                                                           \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma16(B[j], A[i], acc[i][j])
-
-    // K tile 0 has landed (this wave's DMAs: at most those of tiles 1 and 2 are outstanding; then everybody's)
-    if (nt > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MD_NDMA) : "memory");
-    else if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MD_NDMA) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    MD_READ8(a0, b0, x0);
     int cur = 0;                                             // byte offset of the stage that holds K tile kt
     for (int kt = 0; kt < nt; ++kt) {
-        MD_READ8(a1, b1, x1 + (uint32_t)cur);
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // set 0 (issued before set 1) is in the registers
+        // this wave's DMAs of K tile kt have landed when at most the 8 of tile kt + 1 are outstanding (vmcnt retires in order)
+        if (kt + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MD_NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        MD_MFMA16(a0, b0);
+        __builtin_amdgcn_s_barrier();                        // ... and everybody's; everybody has also left K tile kt - 1's stage
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // set 1 too: this wave has read all of K tile kt
-        int nxt = cur + MD_STAGE;
-        if (nxt >= MD_LDS) nxt = 0;
-        if (kt + 1 < nt) {
-            // this wave's DMAs of K tile kt + 1 have landed when at most the 8 of tile kt + 2 are outstanding (vmcnt retires in order)
-            if (kt + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MD_NDMA) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();                    // ... and everybody's; everybody has also finished READING K tile kt
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + 3 < nt) md_issue(ra, rw, smem + cur, wave, voffA, voffW, (kt + 3) * BK * 2);   // into the stage of K tile kt
-            MD_READ8(a0, b0, x0 + (uint32_t)nxt);
+        if (kt + 2 < nt) {
+            int nxt = cur + 2 * MD_STAGE;
+            if (nxt >= MD_LDS) nxt -= MD_LDS;                // stage (kt + 2) % 3 == the stage of K tile kt - 1
+            md_issue(ra, rw, smem + nxt, wave, voffA, voffW, (kt + 2) * BK * 2);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        MD_MFMA16(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint32_t xo = (uint32_t)(((ks * 4 + lq) ^ sw) << 4) + (uint32_t)cur;
+            const uint32_t aa = a_base + xo, ab = b_base + xo;
+            typename T::v8 a[4], b[4];
+            md_lds_read<0 * 16 * ROWB>(a[0], aa); md_lds_read<1 * 16 * ROWB>(a[1], aa);
+            md_lds_read<2 * 16 * ROWB>(a[2], aa); md_lds_read<3 * 16 * ROWB>(a[3], aa);
+            md_lds_read<0 * 16 * ROWB>(b[0], ab); md_lds_read<1 * 16 * ROWB>(b[1], ab);
+            md_lds_read<2 * 16 * ROWB>(b[2], ab); md_lds_read<3 * 16 * ROWB>(b[3], ab);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // swapped operands (weights first) as in every GEMM kernel of the library
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma16(b[j], a[i], acc[i][j]);
+        }
+        cur += MD_STAGE;
+        if (cur >= MD_LDS) cur = 0;
     }
-#undef MD_READ8
-#undef MD_MFMA16
     __syncthreads();                                         // every wave has left the operand stages: the slabs may overlay them
     float* slab = (float*)(smem + wave * MD_SLAB_BYTES);
     const int row0 = m0 + wm * 64, col0 = n0 + wn * 64;

@@ -25,10 +25,8 @@ def test_hot_kernels_have_no_waterfall_loops_and_no_spills(hip_lib):
     for name, v in hot.items():
         if "gemm_pp6_kernel" in name or "gemm_pp_kernel" in name:
             assert v["vgpr"] <= 256 and v["agpr"] == 0, name
-        if "gemm_mid_kernel" in name:
-            # round 6: the small-batch kernel (4 waves = one per SIMD, 64 accumulators + two fragment sets of 32 registers each); the
-            # MFMAs in their VGPR form (pigeon_amd/build.py PER_FILE_FLAGS): no AGPRs, i.e. no v_accvgpr copies inside the K loop
-            assert v["vgpr"] <= 160 and v["agpr"] == 0 and v["scratch"] == 0, (name, v)
+        if "gemm_mid_kernel" in name:                     # round 6: the small-batch kernel (4 waves, 64 accumulators each)
+            assert v["vgpr"] <= 128 and v["scratch"] == 0, (name, v)
 
 
 def test_mfma_result_hazard_detector_on_synthetic_isa():
