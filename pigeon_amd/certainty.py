@@ -28,6 +28,9 @@ tower 5e-5 instead of 2.7e-4 per image) -- the head and the refiner decide on th
 systematic part any more (beta = 0): a decision survives when m / (|e| |g| / 32) > kappa * rel_tol, rel_tol being the held-out residual
 of the CORRECTED panel means.  Nothing else changes: which samples are certain is still a statement about `r` alone, the exact tier's
 results carry no correction, and the audits against the reference module are what backs it (profiles/r06/certainty_audit_ref_debias_*.txt).
+Data-parallel jobs: the vector enters outputs, so replicas that should return the same embedding for the same image must measure the
+same vector -- call `calibrate_certainty` with one batch every rank shares (bench.py does); left to the first-batch auto-calibration
+each rank measures its own (they differ by the calibration noise, ~residual / sqrt(images) = a few 1e-6 relative).
 The exact tier's own floor is `rel_tol_exact`: 5e-6 = 3 x the exact encoder's measured error against the real reference (1.6e-6 at 24
 layers, 1.7e-6 on the stress towers; the reference's CPU result itself moves by ~1e-6 with the thread partition).  Until round 6 it was
 2e-5, which left a third of the re-encoded samples `uncertain` although nothing more exact exists to send them to.

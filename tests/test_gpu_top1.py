@@ -213,6 +213,26 @@ def test_debias_against_the_real_reference(env, vit24, golden_dir, tmp_path, cap
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "debias_vs_reference_report.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
+    # the EMBED path (`run.py embed` -> CLIPEmbedding, reference models/clip_embedder.py:63-65): the vector its contract guard measures on
+    # the first batch is subtracted by the same rule; PIGEON_DEBIAS=0 returns the 16-bit encoder's embeddings as they are
+    from pigeon_amd.clip_embedder import CLIPEmbedding
+    flat = px.reshape(-1, 3, 336, 336)
+    raw = vit24[1].embed(flat)
+    ce = CLIPEmbedding("random", device=DEV, clip_model=vit24[1])
+    got = ce(flat)
+    assert ce.guard_stats["debias"] and ce.bias is not None and not ce.force_exact
+    assert torch.equal(got, ops.embedding_debias(raw.clone(), ce.bias))
+    e_raw, e_got = orc.rel_err(raw.cpu(), ref_emb.reshape(-1, 1024)), orc.rel_err(got.cpu(), ref_emb.reshape(-1, 1024))
+    lines.append(f"CLIPEmbedding on the same 512 images: embedding rel err vs the real reference {e_raw:.2e} -> {e_got:.2e} ({ce.guard_stats})")
+    assert e_got < 0.5 * e_raw
+    os.environ["PIGEON_DEBIAS"] = "0"
+    try:
+        ce0 = CLIPEmbedding("random", device=DEV, clip_model=vit24[1])
+        assert torch.equal(ce0(flat), raw) and ce0.bias is None and not ce0.guard_stats["debias"]
+    finally:
+        del os.environ["PIGEON_DEBIAS"]
+    with open(os.path.join(ROOT, "gpurun_out", "debias_vs_reference_report.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
     on, off = res[True], res[False]
     assert on["missed"] == 0 and off["missed"] == 0
     assert on["err"] < 0.5 * off["err"] and on["worst"] < 0.6 * off["worst"] and on["err"] < EMB_TOL
