@@ -45,6 +45,7 @@ their discrete outputs do not.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -52,7 +53,6 @@ import torch
 
 class Certainty:
     def __init__(self, kappa: float = 3.6, rel_tol: float = 1e-3, rel_tol_exact: float = 5e-6, debias: Optional[bool] = None):
-        import os
         self.debias = (os.environ.get('PIGEON_DEBIAS', '1') not in ('', '0')) if debias is None else bool(debias)
         self.bias: Optional[torch.Tensor] = None      # (1024,) fp32 per-IMAGE relative bias that pg_embedding_debias subtracts, or None
         self.kappa = float(kappa)
