@@ -22,7 +22,10 @@
 namespace {
 
 constexpr int MD_BM = 128, MD_BN = 128;
-constexpr int MD_STAGES = 3;
+#ifndef PG_MID_STAGES
+#define PG_MID_STAGES 3                                        // A/B knob (python -m pigeon_amd.build --variant s5 -DPG_MID_STAGES=5): 3 .. 5
+#endif
+constexpr int MD_STAGES = PG_MID_STAGES;
 constexpr int MD_STAGE = (MD_BM + MD_BN) * ROWB;               // 32 KB
 constexpr int MD_W_OFF = MD_BM * ROWB;
 constexpr int MD_NDMA = (MD_BM + MD_BN) / 8 / 4;               // DMAs per wave per K tile (8 rows x 128 B each): 8
@@ -156,8 +159,9 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(GemmArgs g) {
         voffW[d] = r * (int)g.ldw * 2 + c * 16;
     }
     const int nt = g.K / BK;
-    md_issue(ra, rw, smem, wave, voffA, voffW, 0);
-    if (nt > 1) md_issue(ra, rw, smem + MD_STAGE, wave, voffA, voffW, BK * 2);
+#pragma unroll
+    for (int t = 0; t < MD_STAGES - 1; ++t)
+        if (t < nt) md_issue(ra, rw, smem + t * MD_STAGE, wave, voffA, voffW, t * BK * 2);
 
     const int l15 = lane & 15, lq = lane >> 4;
     const int sw = (lane >> 1) & 7;
@@ -171,16 +175,21 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(GemmArgs g) {
 
     int cur = 0;                                             // byte offset of the stage that holds K tile kt
     for (int kt = 0; kt < nt; ++kt) {
-        // this wave's DMAs of K tile kt have landed when at most the 8 of tile kt + 1 are outstanding (vmcnt retires in order)
-        if (kt + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MD_NDMA) : "memory");
+        // this wave's DMAs of K tile kt have landed when at most those of the tiles issued after it (kt + 1 .. kt + STAGES - 2, 8 each)
+        // are outstanding (vmcnt retires in order)
+        static_assert(MD_STAGES >= 3 && MD_STAGES <= 5, "the vmcnt ladder below covers 3 .. 5 stages");
+        const int ahead = min(MD_STAGES - 2, nt - 1 - kt);
+        if (MD_STAGES >= 5 && ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * MD_NDMA) : "memory");
+        else if (MD_STAGES >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MD_NDMA) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MD_NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                        // ... and everybody's; everybody has also left K tile kt - 1's stage
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < nt) {
-            int nxt = cur + 2 * MD_STAGE;
-            if (nxt >= MD_LDS) nxt -= MD_LDS;                // stage (kt + 2) % 3 == the stage of K tile kt - 1
-            md_issue(ra, rw, smem + nxt, wave, voffA, voffW, (kt + 2) * BK * 2);
+        if (kt + MD_STAGES - 1 < nt) {
+            int nxt = cur - MD_STAGE;                        // stage (kt + STAGES - 1) % STAGES == the stage of K tile kt - 1
+            if (nxt < 0) nxt += MD_LDS;
+            md_issue(ra, rw, smem + nxt, wave, voffA, voffW, (kt + MD_STAGES - 1) * BK * 2);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
