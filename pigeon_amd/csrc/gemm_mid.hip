@@ -26,6 +26,17 @@ constexpr int MD_BM = 128, MD_BN = 128;
 #define PG_MID_STAGES 3                                        // A/B knob (python -m pigeon_amd.build --variant s5 -DPG_MID_STAGES=5): 3 .. 5
 #endif
 constexpr int MD_STAGES = PG_MID_STAGES;
+// A FIFTH wave that does nothing but issue the operand DMAs (second session of round 6).  tools/dma_rate_probe.hip: the 32 DMAs of a K
+// tile (32 KB) take the CU's texture path 0.33 us whoever issues them, and a wave that issues VMEM instructions faster than the path
+// takes them stalls IN ORDER -- with the four MFMA waves issuing their own 8 DMAs each, every K tile was 0.33 us of DMA issue followed
+// by 0.25 us of fragment reads and MFMAs on a SIMD that has no second wave to switch to: the 0.58 us no ring depth and no software
+// pipelining moved.  A producer wave takes the issue stall out of the MFMA waves' instruction stream (it shares SIMD 0 with wave 0;
+// one wave issuing all 32 DMAs sustains 0.355 us per K tile).  Same MFMA chains, same epilogue: the same bits.
+#ifndef PG_MID_PRODUCER
+#define PG_MID_PRODUCER 1                                      // A/B knob: python -m pigeon_amd.build --variant noprod -DPG_MID_PRODUCER=0
+#endif
+constexpr bool MD_PROD = PG_MID_PRODUCER != 0;
+constexpr int MD_THREADS = MD_PROD ? 320 : 256;
 constexpr int MD_STAGE = (MD_BM + MD_BN) * ROWB;               // 32 KB
 constexpr int MD_W_OFF = MD_BM * ROWB;
 constexpr int MD_NDMA = (MD_BM + MD_BN) / 8 / 4;               // DMAs per wave per K tile (8 rows x 128 B each): 8
@@ -133,7 +144,7 @@ __device__ __forceinline__ void md_slab(const GemmArgs& g, float* slab, int lane
 }
 
 template <typename T, int EPI>
-__global__ __launch_bounds__(256) void gemm_mid_kernel(GemmArgs g) {
+__global__ __launch_bounds__(MD_THREADS) void gemm_mid_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -159,9 +170,48 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(GemmArgs g) {
         voffW[d] = r * (int)g.ldw * 2 + c * 16;
     }
     const int nt = g.K / BK;
+    if constexpr (MD_PROD) {
+        static_assert(!MD_PROD || MD_STAGES == 3, "the producer form is written for the three-stage ring");
+        if (wave == 4) {
+            // THE PRODUCER: all 32 DMAs of a K tile -- row group gr (8 rows) of a panel = the lane offsets of group (gr & 1) + (gr >> 1)
+            // x 16 rows, in the VGPR offset (the descriptor's bounds check, which zero-fills the A rows past M, looks at that one only)
+            int pvA[2], pvW[2];
 #pragma unroll
-    for (int t = 0; t < MD_STAGES - 1; ++t)
-        if (t < nt) md_issue(ra, rw, smem + t * MD_STAGE, wave, voffA, voffW, t * BK * 2);
+            for (int d = 0; d < 2; ++d) {
+                const int r = d * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                pvA[d] = r * (int)g.lda * 2 + c * 16;
+                pvW[d] = r * (int)g.ldw * 2 + c * 16;
+            }
+            const int stepA = 16 * (int)g.lda * 2, stepW = 16 * (int)g.ldw * 2;
+            auto issue = [&](int t, char* stage) {
+#pragma unroll
+                for (int gr = 0; gr < 16; ++gr) md_dma16(ra, stage + gr * 8 * ROWB, pvA[gr & 1] + (gr >> 1) * stepA, t * BK * 2);
+#pragma unroll
+                for (int gr = 0; gr < 16; ++gr) md_dma16(rw, stage + MD_W_OFF + gr * 8 * ROWB, pvW[gr & 1] + (gr >> 1) * stepW, t * BK * 2);
+            };
+            issue(0, smem);
+            if (nt > 1) issue(1, smem + MD_STAGE);
+            int freed = 2 * MD_STAGE;                        // where K tile t + 2 goes: stage (t + 2) % 3 == the stage of K tile t - 1
+            for (int t = 0; t < nt; ++t) {
+                // K tile t has landed when at most the 32 DMAs of tile t + 1 are outstanding (vmcnt retires in order)
+                if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();                // publishes K tile t; the MFMA waves have finished K tile t - 1
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 2 < nt) issue(t + 2, smem + freed);
+                freed += MD_STAGE;
+                if (freed >= MD_LDS) freed = 0;
+            }
+            __builtin_amdgcn_s_barrier();                    // the MFMA waves have left the operand stages (their slabs overlay them)
+            return;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < MD_STAGES - 1; ++t)
+            if (t < nt) md_issue(ra, rw, smem + t * MD_STAGE, wave, voffA, voffW, t * BK * 2);
+    }
 
     const int l15 = lane & 15, lq = lane >> 4;
     const int sw = (lane >> 1) & 7;
@@ -178,15 +228,17 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(GemmArgs g) {
         // this wave's DMAs of K tile kt have landed when at most those of the tiles issued after it (kt + 1 .. kt + STAGES - 2, 8 each)
         // are outstanding (vmcnt retires in order)
         static_assert(MD_STAGES >= 3 && MD_STAGES <= 5, "the vmcnt ladder below covers 3 .. 5 stages");
-        const int ahead = min(MD_STAGES - 2, nt - 1 - kt);
-        if (MD_STAGES >= 5 && ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * MD_NDMA) : "memory");
-        else if (MD_STAGES >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MD_NDMA) : "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MD_NDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!MD_PROD) {
+            const int ahead = min(MD_STAGES - 2, nt - 1 - kt);
+            if (MD_STAGES >= 5 && ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * MD_NDMA) : "memory");
+            else if (MD_STAGES >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MD_NDMA) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MD_NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                        // ... and everybody's; everybody has also left K tile kt - 1's stage
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + MD_STAGES - 1 < nt) {
+        if (!MD_PROD && kt + MD_STAGES - 1 < nt) {
             int nxt = cur - MD_STAGE;                        // stage (kt + STAGES - 1) % STAGES == the stage of K tile kt - 1
             if (nxt < 0) nxt += MD_LDS;
             md_issue(ra, rw, smem + nxt, wave, voffA, voffW, (kt + MD_STAGES - 1) * BK * 2);
@@ -211,7 +263,12 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(GemmArgs g) {
         cur += MD_STAGE;
         if (cur >= MD_LDS) cur = 0;
     }
-    __syncthreads();                                         // every wave has left the operand stages: the slabs may overlay them
+    if constexpr (MD_PROD) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // (the producer wave joins this one and leaves)
+    } else {
+        __syncthreads();                                     // every wave has left the operand stages: the slabs may overlay them
+    }
     float* slab = (float*)(smem + wave * MD_SLAB_BYTES);
     const int row0 = m0 + wm * 64, col0 = n0 + wn * 64;
     md_slab<T, EPI, 0>(g, slab, lane, row0, col0, acc);
@@ -227,7 +284,7 @@ int launch_mid(const GemmArgs& g, int nblk, hipStream_t s) {
         if (e != hipSuccess) { pg_set_error("gemm_mid: set LDS attr: %s", hipGetErrorString(e)); return PG_EHIP; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kfn, dim3(nblk), dim3(256), MD_LDS, s, g);
+    hipLaunchKernelGGL(kfn, dim3(nblk), dim3(MD_THREADS), MD_LDS, s, g);
     return pg_check_launch("gemm_mid");
 }
 

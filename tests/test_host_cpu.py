@@ -481,7 +481,7 @@ def test_evaluate_accepts_the_references_base_model_strings(tmp_path, monkeypatc
 
 def test_gemm_routing_model_against_the_measured_sweep():
     """pg_gemm_route (host arithmetic, no launch): which of the three bit-identical GEMM kernels a launch of up to ~64 images takes.
-    Checked against the sweep the model was fitted to (profiles/r06/gemm_three_sweep.txt: the model's four GEMM shapes x 1 .. 64 images
+    Checked against the sweeps the model was fitted to (profiles/r06/gemm_three_sweep.txt, gemm_three_sweep_producer.txt: the model's four GEMM shapes x 1 .. 64 images
     x 384 x 256 persistent / 256 x 256 persistent / gemm_mid.hip, microseconds on MI355X): the pick is never more than 10 % off the
     measured best of its cell (the 256 x 256 kernel must win by 10 % in the model to be taken -- in a forward the ties went the other
     way, profiles/r06/latency_route_ab.txt); the benchmark's 512-image launches keep the variant's own kernel; switching the routing off
@@ -499,25 +499,34 @@ def test_gemm_routing_model_against_the_measured_sweep():
     shapes = {"qkv": (3072, 1024, _lib.EPI_QKV_LN), "out": (1024, 1024, _lib.EPI_RESID_STAT), "fc1": (4096, 1024, _lib.EPI_GELU_LN),
               "fc2": (1024, 4096, _lib.EPI_RESID_STAT)}
     ns = (1, 2, 4, 8, 12, 16, 24, 32, 64)
-    picks, worst, seen = {}, 1.0, 0
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for line in open(os.path.join(root, "profiles", "r06", "gemm_three_sweep.txt")):
-        name = line.split()[0] if line.strip() else ""
-        if name not in shapes:
-            continue
-        N, K, epi = shapes[name]
-        cells = re.findall(r"([\d.]+)/\s*([\d.]+)/\s*([\d.]+)[pqm]", line)
-        assert len(cells) == len(ns), (name, len(cells))
-        for n, cell in zip(ns, cells):
-            t = [float(v) for v in cell]                       # [variant 56's own kernel, 256 x 256, gemm_mid]
-            kind = route(56, epi, 577 * n, N, K)
-            picks[(name, n)] = kind
-            took = t[2] if kind == 2 else (t[0] if (kind == 0 or name == "out") else t[1])     # (out-projection: own kernel IS 256 x 256)
-            worst = max(worst, took / min(t))
-            seen += 1
+
+    def against(sweep, only=None):
+        picks, worst, seen = {}, 1.0, 0
+        for line in open(os.path.join(root, "profiles", "r06", sweep)):
+            name = line.split()[0] if line.strip() else ""
+            if name not in shapes or (only and name not in only):
+                continue
+            N, K, epi = shapes[name]
+            cells = re.findall(r"([\d.]+)/\s*([\d.]+)/\s*([\d.]+)[pqm]", line)
+            assert len(cells) == len(ns), (name, len(cells))
+            for n, cell in zip(ns, cells):
+                t = [float(v) for v in cell]                   # [variant 56's own kernel, 256 x 256, gemm_mid]
+                kind = route(56, epi, 577 * n, N, K)
+                picks[(name, n)] = kind
+                took = t[2] if kind == 2 else (t[0] if (kind == 0 or name == "out") else t[1])     # (out-projection: own kernel IS 256 x 256)
+                worst = max(worst, took / min(t))
+                seen += 1
+        return picks, worst, seen
+    # the first session's sweep: its gemm_mid column is the kernel BEFORE the producer wave, i.e. an upper bound for the cells that take it
+    picks, worst, seen = against("gemm_three_sweep.txt")
     assert seen == 36 and worst < 1.10, worst
-    assert picks[("qkv", 1)] == 2 and picks[("qkv", 16)] == 1 and picks[("qkv", 12)] == 0 and picks[("fc1", 4)] == 1
+    # the sweep with the producer wave: the two residual shapes (its LN-fold rows carry the standalone loop's artefact, profiles/r06/README.md)
+    _, worst2, seen2 = against("gemm_three_sweep_producer.txt", only=("out", "fc2"))
+    assert seen2 == 18 and worst2 < 1.05, worst2
+    assert picks[("qkv", 1)] == 2 and picks[("qkv", 16)] == 1 and picks[("qkv", 12)] == 0 and picks[("fc1", 4)] == 1 and picks[("qkv", 4)] == 2
     assert picks[("fc2", 4)] == 2 and picks[("fc2", 16)] == 1 and picks[("fc2", 32)] == 0 and picks[("out", 4)] == 2 and picks[("out", 16)] == 1
+    assert picks[("out", 8)] == 2 and picks[("out", 12)] == 2          # (the 256 x 256 kernel until the producer wave made gemm_mid the faster one there)
     # the benchmark step (295 424 rows) is outside the routed range: the variant's own kernel (fc2 / QKV / fc1 384 x 256, out-projection 256 x 256)
     assert [route(56, shapes[s][2], 295424, shapes[s][0], shapes[s][1]) for s in ("qkv", "out", "fc1", "fc2")] == [0, 1, 0, 0]
     assert route(36, _lib.EPI_F32, 16156, 1024, 3072) == 1 and route(8, _lib.EPI_QKV, 577, 3072, 1024) == -1

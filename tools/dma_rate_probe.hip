@@ -23,7 +23,8 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wav
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_wave_uniform, 16, voff, soff, 0, 0);
 }
 
-template <int DEPTH, bool BARRIER>
+// PRODUCER: ONE wave issues all 32 DMAs of a K tile (the other three only meet it at the barrier) -- can a single wave feed the CU?
+template <int DEPTH, bool BARRIER, bool PRODUCER = false>
 __global__ __launch_bounds__(256) void dma_only(const uint16_t* A, const uint16_t* W, int M, int K, int tilesN, int reps, unsigned* sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -44,6 +45,13 @@ __global__ __launch_bounds__(256) void dma_only(const uint16_t* A, const uint16_
         const int r = (wave + 4 * d) * 8 + (lane >> 3);
         voff[d] = r * K * 2 + ((lane & 7) ^ ((r >> 1) & 7)) * 16;
     }
+    // producer form: row group gr (8 rows) of a panel = lane offset of group (gr & 1) + an SGPR offset (gr >> 1) * 16 rows
+    int pvoff[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const int r = d * 8 + (lane >> 3);
+        pvoff[d] = r * K * 2 + ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+    }
     const int nt = K / 64;
     for (int rep = 0; rep < reps; ++rep) {
         int issued = 0;
@@ -51,14 +59,28 @@ __global__ __launch_bounds__(256) void dma_only(const uint16_t* A, const uint16_
             // keep DEPTH K tiles in flight: before waiting for tile kt, tiles kt .. kt + DEPTH - 1 have been issued
             while (issued < nt && issued < kt + DEPTH) {
                 char* st = smem + (issued % 3) * STAGE;
+                if (PRODUCER) {
+                    if (wave == 0) {
 #pragma unroll
-                for (int d = 0; d < 4; ++d) dma16(ra, st + (wave + 4 * d) * 8 * ROWB, voff[d], issued * 128);
+                        for (int gr = 0; gr < 16; ++gr) dma16(ra, st + gr * 8 * ROWB, pvoff[gr & 1], issued * 128 + (gr >> 1) * 16 * K * 2);
 #pragma unroll
-                for (int d = 0; d < 4; ++d) dma16(rw, st + 128 * ROWB + (wave + 4 * d) * 8 * ROWB, voff[d], issued * 128);
+                        for (int gr = 0; gr < 16; ++gr) dma16(rw, st + 128 * ROWB + gr * 8 * ROWB, pvoff[gr & 1], issued * 128 + (gr >> 1) * 16 * K * 2);
+                    }
+                } else {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) dma16(ra, st + (wave + 4 * d) * 8 * ROWB, voff[d], issued * 128);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) dma16(rw, st + 128 * ROWB + (wave + 4 * d) * 8 * ROWB, voff[d], issued * 128);
+                }
                 ++issued;
             }
-            const int ahead = issued - kt - 1;              // tiles issued after tile kt: their 8 DMAs each may stay outstanding
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            const int ahead = issued - kt - 1;              // tiles issued after tile kt: their DMAs (8 per wave, 32 for a producer) may stay outstanding
+            if (PRODUCER) {
+                if (wave == 0) {
+                    if (ahead >= 1) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // (two tiles ahead would be 64 > the counter's 63)
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            } else if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (BARRIER) __builtin_amdgcn_s_barrier();
@@ -67,9 +89,9 @@ __global__ __launch_bounds__(256) void dma_only(const uint16_t* A, const uint16_
     if (sink && tid == 0) sink[blockIdx.x] = ((volatile unsigned*)smem)[lane];
 }
 
-template <int DEPTH, bool BARRIER>
+template <int DEPTH, bool BARRIER, bool PRODUCER = false>
 static int run(const uint16_t* A, const uint16_t* W, int M, int K, int blocks, unsigned* sink) {
-    auto k = dma_only<DEPTH, BARRIER>;
+    auto k = dma_only<DEPTH, BARRIER, PRODUCER>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     const int reps = 40, nt = K / 64;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -82,7 +104,7 @@ static int run(const uint16_t* A, const uint16_t* W, int M, int K, int blocks, u
         if (it && ms < best) best = ms;
     }
     const double us_tile = best * 1e3 / (reps * nt);
-    printf("  %d K tiles in flight, %s: %6.3f us per K tile and CU = %5.1f KB/us per CU, %5.2f TB/s over %d CUs\n", DEPTH,
+    printf("  %s%d K tiles in flight, %s: %6.3f us per K tile and CU = %5.1f KB/us per CU, %5.2f TB/s over %d CUs\n", PRODUCER ? "ONE wave issues all 32 DMAs, " : "", DEPTH,
            BARRIER ? "barrier per K tile" : "no barrier        ", us_tile, 32.0 / us_tile, blocks * 32768.0 / us_tile / 1e6, blocks);
     return 0;
 }
@@ -99,6 +121,8 @@ int main() {
         if (run<2, true>(A, W, M, K, blocks, sink)) return 1;
         if (run<3, true>(A, W, M, K, blocks, sink)) return 1;
         if (run<3, false>(A, W, M, K, blocks, sink)) return 1;
+        if (run<1, true, true>(A, W, M, K, blocks, sink)) return 1;
+        if (run<2, true, true>(A, W, M, K, blocks, sink)) return 1;
     }
     return 0;
 }
