@@ -772,6 +772,14 @@ static int precise_parts(int M, int N, int Ktot, bool resid, const int* cand, in
 // [p Kp, (p + 1) Kp) of the triple operands into the fp32 partial buffer p (the bias rides in part 0); then
 // dst = (resid ? dst : 0) + sum of the parts, in part order (sum_parts_kernel).
 // Which of the three forms a shape takes (a pure function of the shape): 0 = gemm_mid.hip, S >= 1 = the persistent kernel in S parts.
+#ifndef PG_EXACT_MID_US_KT
+#define PG_EXACT_MID_US_KT 0.6
+#endif
+static double precise_mid_us_kt() {     // microseconds per K tile of a gemm_mid round in the exact tier's routing (env PIGEON_EXACT_MID_US: A/B)
+    static double v = -1.0;
+    if (v < 0.0) { const char* e = getenv("PIGEON_EXACT_MID_US"); v = e ? atof(e) : PG_EXACT_MID_US_KT; if (!(v > 0.0)) v = PG_EXACT_MID_US_KT; }
+    return v;
+}
 static int precise_route(int M, int N, int Ktot, bool resid, const int* cand, int ncand) {
     double parts_us = 0.0;
     const int S = precise_parts(M, N, Ktot, resid, cand, ncand, &parts_us);
@@ -780,7 +788,7 @@ static int precise_route(int M, int N, int Ktot, bool resid, const int* cand, in
     // (0.6 us per K tile of a round + epilogue).  Bit-identical to the S = 1 persistent launch.
     if (pg_gemm_mid_on() && N % 128 == 0) {
         const double rounds_m = ceil((double)((M + 127) / 128) * (N / 128) / (double)pg_num_cus());
-        const double mid_us = rounds_m * ((Ktot / 64) * 0.6 + (resid ? 6.0 : 5.0));
+        const double mid_us = rounds_m * ((Ktot / 64) * precise_mid_us_kt() + (resid ? 6.0 : 5.0));
         if (mid_us < parts_us) return 0;
     }
     return S;
