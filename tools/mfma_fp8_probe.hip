@@ -100,27 +100,28 @@ int main() {
             }
         }
     }
-    // issue rate: 256 blocks x 4 waves, 8 independent accumulators, 2000 iterations
+    // issue rate: 1024 blocks x 4 waves = FOUR waves per SIMD (one wave per SIMD does not keep the matrix pipe full: the first
+    // record of this probe read 746 TFLOP/s for the fp16 instruction), 8 independent accumulators per wave
     std::vector<int> junk(1024 * 8);
     for (auto& x : junk) x = 0x38383838 ^ (rand() & 0x07070707);
     i32x8* din; float* dout; long long* dc;
-    CK(hipMalloc(&din, 1024 * 32)); CK(hipMalloc(&dout, 256 * 256 * 4)); CK(hipMalloc(&dc, 8));
+    CK(hipMalloc(&din, 1024 * 32)); CK(hipMalloc(&dout, 1024 * 256 * 4)); CK(hipMalloc(&dc, 8));
     CK(hipMemcpy(din, junk.data(), 1024 * 32, hipMemcpyHostToDevice));
     for (int kind = 0; kind < 4; ++kind) {
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         const int iters = 4000;
         for (int rep = 0; rep < 2; ++rep) {
             CK(hipEventRecord(e0));
-            if (kind == 0) hipLaunchKernelGGL(rate<0>, dim3(256), dim3(256), 0, 0, din, dout, iters, dc);
-            else if (kind == 2) hipLaunchKernelGGL(rate<2>, dim3(256), dim3(256), 0, 0, din, dout, iters, dc);
-            else if (kind == 3) hipLaunchKernelGGL(rate<3>, dim3(256), dim3(256), 0, 0, din, dout, iters, dc);
-            else hipLaunchKernelGGL(rate<1>, dim3(256), dim3(256), 0, 0, din, dout, iters, dc);
+            if (kind == 0) hipLaunchKernelGGL(rate<0>, dim3(1024), dim3(256), 0, 0, din, dout, iters, dc);
+            else if (kind == 2) hipLaunchKernelGGL(rate<2>, dim3(1024), dim3(256), 0, 0, din, dout, iters, dc);
+            else if (kind == 3) hipLaunchKernelGGL(rate<3>, dim3(1024), dim3(256), 0, 0, din, dout, iters, dc);
+            else hipLaunchKernelGGL(rate<1>, dim3(1024), dim3(256), 0, 0, din, dout, iters, dc);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         }
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         long long cyc; CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost));
-        const double flop = 2.0 * 16 * 16 * (kind != 1 ? 128 : 32) * 8.0 * iters * 4 * 256;
-        printf("%s: %.1f shader cycles per instruction and wave, %.0f TFLOP/s on 256 CUs x 4 waves (%.2f ms)\n",
+        const double flop = 2.0 * 16 * 16 * (kind != 1 ? 128 : 32) * 8.0 * iters * 4 * 1024;
+        printf("%s: %.1f shader cycles per instruction and wave (4 waves per SIMD), %.0f TFLOP/s on 256 CUs (%.2f ms)\n",
                kind == 0 ? "v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3)" : kind == 2 ? "v_mfma_scale_f32_16x16x128_f8f6f4 (e2m3)" : kind == 3 ? "v_mfma_scale_f32_16x16x128_f8f6f4 (e2m1)" : "v_mfma_f32_16x16x32_f16              ", (double)cyc / (8.0 * iters), flop / (ms * 1e-3) / 1e12, ms);
     }
     return 0;
