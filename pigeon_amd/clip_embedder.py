@@ -360,7 +360,9 @@ class CLIPEmbedding(torch.nn.Module):
             return emb
 
     def _check_contract(self, base, pixel_values: Tensor, max_images: int = 32, contract: float = 1e-3) -> dict:
-        """Once per set of weights: the 16-bit encoder against the exact one on up to `max_images` images of the first batch."""
+        """Once per set of weights: the 16-bit encoder against the exact one on up to `max_images` images of the first batch.
+        (A first batch of fewer than 8 images measures the error but fits no bias: nothing is subtracted for the lifetime of this
+        object -- hand the embed path a full first batch, as `run.py embed` does, or set PIGEON_DEBIAS=0 on both entry points.)"""
         px = _to_device_pixels(pixel_values[:max_images], base._dummy.device)
         fast, exact = base.embed(px), base.embed_precise(px)
         err = (fast - exact).norm(dim=1) / exact.norm(dim=1).clamp_min(1e-30)
